@@ -1,0 +1,39 @@
+"""Build libblueice_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m blueice_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, 'csrc', 'blueice_hip.hip')
+HDR = os.path.join(os.path.dirname(_HERE), 'include', 'blueice_hip.h')
+OUT_DIR = os.path.join(_HERE, 'lib')
+OUT = os.path.join(OUT_DIR, 'libblueice_hip.so')
+ARCH = 'gfx950'
+
+
+def hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    return 'hipcc'
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(OUT):
+        newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+        if os.path.getmtime(OUT) >= newest:
+            return OUT
+    cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-shared', '-fPIC',
+           '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,248 @@
+"""Thin object wrapper over the C ABI (include/blueice_hip.h): one `DeviceContext` = one GPU + stream.
+
+Everything numerical happens in libblueice_hip.so; this module only marshals numpy arrays.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import as_f64, ptr
+from .exceptions import DeviceError, NotPreparedException
+
+__all__ = ['DeviceContext', 'EvalPlan', 'default_device']
+
+
+def default_device():
+    """LOCAL_RANK when launched by torch.distributed.run (one process per GPU), else 0."""
+    return int(os.environ.get('BLUEICE_AMD_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+
+
+class DeviceContext:
+    """Owns the anchor tensors and binned data of one likelihood in HBM."""
+
+    def __init__(self, device=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        device = default_device() if device is None else int(device)
+        rc = self._lib.bi_create(device, C.byref(self._h))
+        if rc != 0:
+            raise DeviceError("bi_create(device=%d) failed: %s" % (
+                device, self._lib.bi_last_error(None).decode()))
+        self.device = device
+        self.d = self.S = self.B = None
+        self.T = 0
+        self.bb_source = -1
+
+    # -- plumbing --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.bi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self._lib.bi_last_error(self._h).decode()
+        if rc == _capi.ERR_STATE:
+            raise NotPreparedException(msg)
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(msg)
+        raise DeviceError("libblueice_hip error %d: %s" % (rc, msg))
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(256)
+        ncu = C.c_int()
+        hbm = C.c_int64()
+        self._check(self._lib.bi_device_info(self._h, name, arch, 256, C.byref(ncu), C.byref(hbm)))
+        return dict(name=name.value.decode(), arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    def set_param(self, name, value):
+        self._check(self._lib.bi_set_param(self._h, name.encode(), int(value)))
+
+    def get_param(self, name):
+        return int(self._lib.bi_get_param(self._h, name.encode()))
+
+    def sync(self):
+        self._check(self._lib.bi_sync(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.bi_stream(self._h)
+
+    # -- model -----------------------------------------------------------------------------
+    def _grid_args(self, anchor_z):
+        anchor_z = [np.ascontiguousarray(g, dtype=np.float64) for g in anchor_z]
+        n_anchor = np.array([len(g) for g in anchor_z], dtype=np.int32)
+        flat = np.concatenate(anchor_z) if len(anchor_z) else np.zeros(0)
+        return anchor_z, n_anchor, np.ascontiguousarray(flat, dtype=np.float64)
+
+    def upload_model(self, anchor_z, ps, mus, n_model=None, bb_source=-1):
+        """anchor_z: list of d ascending arrays; ps [A.., S, *bins]; mus [A.., S]; n_model like ps."""
+        anchor_z, n_anchor, flat = self._grid_args(anchor_z)
+        d = len(anchor_z)
+        grid_shape = tuple(int(n) for n in n_anchor)
+        ps = np.asarray(ps)
+        if ps.ndim < d + 2 and not (ps.ndim == d + 1):
+            raise ValueError("ps must have shape [A.., S, *bins]")
+        S = int(ps.shape[d])
+        B = int(np.prod(ps.shape[d + 1:], dtype=np.int64)) if ps.ndim > d + 1 else 1
+        ps = as_f64(ps).reshape(grid_shape + (S, B))
+        mus = as_f64(mus, grid_shape + (S,))
+        if n_model is not None:
+            n_model = as_f64(n_model).reshape(grid_shape + (S, B))
+        self._check(self._lib.bi_upload_model(self._h, d, ptr(n_anchor), ptr(flat), S, B, ptr(ps), ptr(mus),
+                                              ptr(n_model), int(bb_source)))
+        self.d, self.S, self.B, self.bb_source = d, S, B, int(bb_source)
+        self.anchor_z = anchor_z
+        self.T = 0
+
+    def begin_model(self, anchor_z, S, B, bb_source=-1):
+        anchor_z, n_anchor, flat = self._grid_args(anchor_z)
+        self._check(self._lib.bi_model_begin(self._h, len(anchor_z), ptr(n_anchor), ptr(flat), int(S), int(B),
+                                             int(bb_source)))
+        self.d, self.S, self.B, self.bb_source = len(anchor_z), int(S), int(B), int(bb_source)
+        self.anchor_z = anchor_z
+        self.T = 0
+
+    def set_anchor(self, anchor_index, ps, mus, n_model_row=None):
+        ps = as_f64(ps).reshape(self.S, self.B)
+        mus = as_f64(mus, (self.S,))
+        if n_model_row is not None:
+            n_model_row = as_f64(n_model_row).reshape(self.B)
+        self._check(self._lib.bi_model_set_anchor(self._h, int(anchor_index), ptr(ps), ptr(mus), ptr(n_model_row)))
+
+    def end_model(self):
+        self._check(self._lib.bi_model_end(self._h))
+
+    def set_allow_negative(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.int32)
+        if flags.shape != (self.S,):
+            raise ValueError("need one flag per source")
+        self._check(self._lib.bi_set_allow_negative(self._h, ptr(flags)))
+
+    # -- data ------------------------------------------------------------------------------
+    def upload_counts(self, counts):
+        """counts: [*bins] (one dataset) or [T, *bins]."""
+        c = as_f64(counts)
+        if c.size % self.B:
+            raise ValueError("counts size %d is not a multiple of B=%d" % (c.size, self.B))
+        T = c.size // self.B
+        c = c.reshape(T, self.B)
+        self._check(self._lib.bi_upload_counts(self._h, T, ptr(c)))
+        self.T = T
+
+    # -- evaluation ------------------------------------------------------------------------
+    def _point_args(self, z, rate_scale, dataset):
+        if self.d:
+            z = as_f64(z).reshape(-1, self.d)
+            P = len(z)
+        else:
+            P = 1 if rate_scale is None else len(np.atleast_2d(rate_scale))
+            z = None
+        if rate_scale is not None:
+            rate_scale = np.ascontiguousarray(np.broadcast_to(as_f64(np.atleast_2d(rate_scale)), (P, self.S)))
+        if dataset is not None:
+            dataset = np.ascontiguousarray(np.broadcast_to(np.asarray(dataset, dtype=np.int64), (P,)))
+        return P, z, rate_scale, dataset
+
+    def eval(self, z, rate_scale=None, dataset=None):
+        """-> (ll [P], status [P]); z [P, d] (or [d]), rate_scale [P, S] or None, dataset [P] or None."""
+        P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)
+        out = np.empty(P, dtype=np.float64)
+        status = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.bi_eval(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), ptr(out), ptr(status)))
+        return out, status
+
+    def eval_datasets(self, z, rate_scale=None, t0=0, t1=None):
+        """One parameter point against datasets [t0, t1) -> (ll [t1-t0], status)."""
+        t1 = self.T if t1 is None else int(t1)
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        out = np.empty(max(t1 - int(t0), 0), dtype=np.float64)
+        status = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.bi_eval_datasets(self._h, ptr(z), ptr(rate_scale), int(t0), t1, ptr(out), ptr(status)))
+        return out, int(status[0])
+
+    def interpolate(self, which, z):
+        """which: 'ps' -> [S, B], 'mus' -> [S], 'n_model' -> [B] (the Beeston-Barlow source row)."""
+        code = {'ps': 0, 'mus': 1, 'n_model': 2}[which]
+        shape = {0: (self.S, self.B), 1: (self.S,), 2: (self.B,)}[code]
+        z = as_f64(z).reshape(self.d) if self.d else None
+        out = np.empty(shape, dtype=np.float64)
+        self._check(self._lib.bi_interpolate(self._h, code, ptr(z), ptr(out)))
+        return out
+
+    def eval_full(self, z, rate_scale=None, dataset=0):
+        """full_output form -> (ll, mus [S], ps [S, B], status)."""
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        ll = np.zeros(1)
+        mus = np.zeros(self.S)
+        ps = np.zeros((self.S, self.B))
+        st = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.bi_eval_full(self._h, ptr(z), ptr(rate_scale), int(dataset), ptr(ll), ptr(mus), ptr(ps),
+                                           ptr(st)))
+        return float(ll[0]), mus, ps, int(st[0])
+
+    def plan(self, z, rate_scale=None, dataset=None):
+        P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)
+        h = C.c_void_p()
+        self._check(self._lib.bi_plan_points(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), C.byref(h)))
+        return EvalPlan(self, h, P)
+
+    # -- measurement -----------------------------------------------------------------------
+    def profile(self, on):
+        self._check(self._lib.bi_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        n = C.c_int64()
+        ms = C.c_double()
+        self._check(self._lib.bi_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class EvalPlan:
+    """A batch of points whose host-side preparation (cell lookup, rates, grouping) is done and
+    resident on the device; `run()` only launches kernels."""
+
+    def __init__(self, ctx, handle, P):
+        self.ctx, self._h, self.P = ctx, handle, P
+
+    @property
+    def bytes(self):
+        return int(self.ctx._lib.bi_plan_bytes(self._h))
+
+    @property
+    def launches(self):
+        return int(self.ctx._lib.bi_plan_launches(self._h))
+
+    def run(self, out_dev_ptr=None):
+        self.ctx._check(self.ctx._lib.bi_run_plan(self.ctx._h, self._h, out_dev_ptr))
+
+    def read(self):
+        out = np.empty(self.P, dtype=np.float64)
+        status = np.zeros(self.P, dtype=np.int32)
+        self.ctx._check(self.ctx._lib.bi_plan_read(self.ctx._h, self._h, ptr(out), ptr(status)))
+        return out, status
+
+    def close(self):
+        if self._h is not None and self._h.value and self.ctx._h.value:
+            self.ctx._lib.bi_plan_destroy(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,154 @@
+/* blueice_hip.h -- C ABI of libblueice_hip.so: the MI355X (gfx950) binned-likelihood hot path.
+ *
+ * The reference (JelleAalbers/blueice v1.2.1) is pure Python and has no FFI; its extension
+ * points for this path are Python-level.  Every entry point below cites the reference
+ * interface (file:line under /root/reference) whose work it takes over.  Python binds this
+ * header with ctypes (blueice_amd/_capi.py); INTEGRATION.md shows the stub a blueice
+ * maintainer would add.
+ *
+ * Conventions
+ *   - All host buffers are borrowed for the duration of the call; the library copies what it
+ *     needs.  Device memory is owned by the context until bi_destroy.
+ *   - Return value: 0 = BI_OK, negative = error (message via bi_last_error).  Nothing throws
+ *     across the boundary.  Numerical edge cases are VALUES (-inf / nan as the reference
+ *     produces them), not errors.
+ *   - One context = one device + one HIP stream.  A context is not re-entrant; distinct
+ *     contexts are independent (one per GPU / per process in multi-GPU runs).
+ *   - All floating point is IEEE binary64.  Layouts are C order.
+ */
+#ifndef BLUEICE_HIP_H
+#define BLUEICE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bi_ctx bi_ctx;
+
+enum {
+    BI_OK = 0,
+    BI_ERR_INVALID = -1, /* bad argument / shape mismatch */
+    BI_ERR_HIP = -2,     /* HIP runtime failure (message has the hipError string) */
+    BI_ERR_STATE = -3,   /* model or data not uploaded yet (reference: NotPreparedException,
+                            blueice/likelihood.py:30-50) */
+    BI_ERR_NOMEM = -4
+};
+
+/* per-point status bits written by bi_eval (reference behaviour in brackets) */
+enum {
+    BI_ST_OUT_OF_BOUNDS = 1, /* z outside the anchor box or nan [-inf, likelihood.py:345-347] */
+    BI_ST_UNPHYSICAL = 2,    /* rates not in [0, inf) [-inf or ValueError, likelihood.py:397-415] */
+    BI_ST_BB_ROOT1 = 4,      /* Beeston-Barlow `assert all(A1 <= 0)` would fail [likelihood.py:649] */
+    BI_ST_BB_NEG = 8,        /* Beeston-Barlow `assert all(0 <= A)` would fail [likelihood.py:655] */
+    BI_ST_BAD_DATASET = 16   /* dataset index out of range */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int bi_create(int device, bi_ctx** out);
+void bi_destroy(bi_ctx* ctx);
+const char* bi_last_error(const bi_ctx* ctx); /* ctx == NULL: last error of a failed bi_create */
+const char* bi_version(void);
+/* name (<= len bytes), compute units, total HBM bytes, gfx arch string (<= len bytes) */
+int bi_device_info(bi_ctx* ctx, char* name, char* arch, int len, int* n_cu, int64_t* hbm_bytes);
+
+/* ---- model: the anchor tensors built by GridInterpolator.make_interpolator ---------------
+ * (blueice/pdf_morphers.py:57-67 fills `anchor_scores[A_0..A_{d-1}, *extra_dims]` and wraps it
+ * in a RegularGridInterpolator; BinnedLogLikelihood.prepare builds three of them,
+ * blueice/likelihood.py:248-251 (mus), :593-596 (ps), :598-601 (n_model_events)).
+ *
+ *   d          number of shape parameters (0 allowed: no morphing, likelihood.py:359-363)
+ *   n_anchor   [d]   anchors per axis
+ *   anchor_z   concatenated, ascending per axis (pdf_morphers.py:48)
+ *   S, B       sources, total analysis bins (product of the analysis-space shape)
+ *   ps         [A_0..A_{d-1}][S][B]
+ *   mus        [A_0..A_{d-1}][S]
+ *   n_model    NULL or [A_0..A_{d-1}][S][B]; only row `bb_source` is kept (likelihood.py:643)
+ *   bb_source  -1 = no Beeston-Barlow, else the 'bb_single_source' index (likelihood.py:625-630)
+ */
+int bi_upload_model(bi_ctx* ctx, int d, const int32_t* n_anchor, const double* anchor_z, int S, int64_t B,
+                    const double* ps, const double* mus, const double* n_model, int bb_source);
+
+/* Streaming variant of the same: declare the grid, then hand over one anchor model at a time in
+ * any order -- exactly the loop of pdf_morphers.py:62-65 -- so no dense host tensor is needed. */
+int bi_model_begin(bi_ctx* ctx, int d, const int32_t* n_anchor, const double* anchor_z, int S, int64_t B,
+                   int bb_source);
+/* anchor_index: C-order linear index into the anchor grid; ps [S][B]; mus [S];
+ * n_model_row NULL or [B] (= n_model_events[bb_source]) */
+int bi_model_set_anchor(bi_ctx* ctx, int64_t anchor_index, const double* ps, const double* mus,
+                        const double* n_model_row);
+int bi_model_end(bi_ctx* ctx);
+
+/* per-source `allow_negative` flags (likelihood.py:82-83,397-415); default all 0 */
+int bi_set_allow_negative(bi_ctx* ctx, const int32_t* allow /*[S]*/);
+
+/* ---- data: what BinnedLogLikelihood.set_data leaves in data_events_per_bin.histogram ------
+ * (blueice/likelihood.py:603-609).  T datasets of B float64 counts each (toy MC: T > 1). */
+int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
+
+/* ---- the hot path -----------------------------------------------------------------------
+ * P independent evaluations of LogLikelihoodBase.__call__ (blueice/likelihood.py:318-427)
+ * without the Python-callable priors:
+ *   mus = mus_interpolator(z); ps = ps_interpolator(z) [; n_model_events_interpolator(z)]
+ *   (:355-357, scipy RegularGridInterpolator semantics, pdf_morphers.py:67-70)
+ *   mus *= rate_scale (rate multiplier :366-368, livetime :374-382, efficiency :385-393)
+ *   unphysical check (:397-415) -> -inf
+ *   adjust_expectations ('bb_single', :618-660)
+ *   _compute_likelihood = sum_bins poisson.logpmf(n | sum_s mus_s ps_s) (:662-675)
+ *
+ *   z          [P][d]   (ignored when d == 0)
+ *   rate_scale [P][S]   or NULL (= all ones)
+ *   dataset    [P]      or NULL (= dataset 0)
+ *   out        [P]      log likelihoods (-inf / nan exactly where the reference gives them)
+ *   status     [P]      or NULL; BI_ST_* bits
+ * Points are grouped by (grid cell, dataset) internally so that corner templates are read once
+ * per group. */
+int bi_eval(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
+            double* out, int32_t* status);
+
+/* One parameter point against datasets [t0, t1): the toy-MC form.  mu_b / log mu_b are computed
+ * once and every dataset reduces sum_b xlogy(n, mu) against them.  Not available with
+ * Beeston-Barlow (mu then depends on the data).  out [t1 - t0]. */
+int bi_eval_datasets(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
+                     double* out, int32_t* status /*[1] or NULL*/);
+
+/* ---- compatibility mode: materialise what the morpher closures return ---------------------
+ * `ps_interpolator(zs)` / `mus_interpolator(zs)` / `n_model_events_interpolator(zs)`
+ * (pdf_morphers.py:70) and `full_output=True` (likelihood.py:424-425).
+ *   which: 0 = ps [S][B], 1 = mus [S], 2 = n_model row [B]
+ * returns BI_ERR_INVALID for out-of-bounds z (scipy raises ValueError, bounds_error=True). */
+int bi_interpolate(bi_ctx* ctx, int which, const double* z, double* out);
+/* adjusted (mus [S], ps [S][B]) after rate scaling and Beeston-Barlow, as full_output returns */
+int bi_eval_full(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t dataset, double* ll,
+                 double* mus_out, double* ps_out, int32_t* status);
+
+/* ---- asynchronous / device-resident form (inputs already in HBM, no host round trip) -------
+ * bi_plan_points does the host-side part of bi_eval once (cell lookup, rates, grouping) and
+ * keeps the plan on the device; bi_run_plan launches the kernels on the context stream and
+ * writes to a DEVICE buffer of P doubles (e.g. a torch / RCCL tensor's data pointer);
+ * bi_sync waits for the stream. */
+typedef struct bi_plan bi_plan;
+int bi_plan_points(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
+                   bi_plan** out);
+int bi_run_plan(bi_ctx* ctx, bi_plan* plan, double* out_dev /* NULL: internal buffer */);
+int bi_plan_read(bi_ctx* ctx, bi_plan* plan, double* out /*[P]*/, int32_t* status /*[P] or NULL*/);
+int64_t bi_plan_bytes(const bi_plan* plan);    /* algorithmic HBM bytes one bi_run_plan moves */
+int64_t bi_plan_launches(const bi_plan* plan); /* morph+reduce launches per bi_run_plan */
+void bi_plan_destroy(bi_ctx* ctx, bi_plan* plan);
+int bi_sync(bi_ctx* ctx);
+void* bi_stream(bi_ctx* ctx); /* the hipStream_t the context launches on */
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * While enabled, every morph+reduce launch is bracketed by HIP events on the context stream;
+ * bi_profile_read drains them: number of launches and summed GPU time in milliseconds. */
+int bi_profile_enable(bi_ctx* ctx, int on);
+int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
+/* tunables: "tile_bins" is fixed at build time; "blocks_per_cu", "max_group" (points per pass) */
+int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
+int64_t bi_get_param(bi_ctx* ctx, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUEICE_HIP_H */

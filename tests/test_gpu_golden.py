@@ -1,0 +1,104 @@
+"""GPU parity proper: libblueice_hip (through the C ABI) against the golden vectors produced by
+the reference and against the CPU oracle on the same inputs.
+
+Tolerance (BASELINE.json north_star): |gpu - cpu| <= 1e-10 * max(1, |cpu|); +-inf / nan exact."""
+import numpy as np
+import pytest
+
+from golden_util import case_names, load_case, rate_scale_of, same
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from blueice_amd.device import DeviceContext
+    c = DeviceContext(0)
+    yield c
+    c.close()
+
+
+def upload_case(ctx, c):
+    bb = c['bb_source']
+    ctx.upload_model(c['model']['anchor_z'], c['model']['ps'], c['model']['mus'],
+                     n_model=c['model']['n_model'] if bb >= 0 else None, bb_source=bb)
+    ctx.upload_counts(c['counts'])
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_eval_matches_reference_goldens(ctx, name):
+    from blueice_amd import _capi
+    c = load_case(name)
+    upload_case(ctx, c)
+    n = len(c['call_ll'])
+    rs = np.array([rate_scale_of(c, j) for j in range(n)])
+    # one by one (the lf(**kw) form) ...
+    single = []
+    for j in range(n):
+        ll, st = ctx.eval(c['call_z'][j], rs[j])
+        single.append((ll[0], st[0]))
+    # ... and as one batch (the scan form); both must agree with the reference
+    batch, bst = ctx.eval(c['call_z'], rs)
+    for j in range(n):
+        asserts = ('call_asserts_%d' % j) in c['raw'].files
+        for ll, st in (single[j], (batch[j], bst[j])):
+            if asserts:
+                assert st & (_capi.ST_BB_ROOT1 | _capi.ST_BB_NEG), (name, j, ll, st)
+                continue
+            assert same(ll, c['call_ll'][j], RTOL), (name, j, ll, c['call_ll'][j])
+        assert same(single[j][0], batch[j], 1e-13) or asserts
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_interpolators_and_full_output(ctx, name):
+    """Compatibility mode: the morpher closures and full_output=True."""
+    from oracle import blueice_oracle as orc
+    c = load_case(name)
+    upload_case(ctx, c)
+    f = c['raw']
+    B = int(np.prod(c['bins']))
+    for j in range(min(len(c['call_ll']), 6)):
+        z = c['call_z'][j]
+        if not orc.in_bounds(c['model']['anchor_z'], z):
+            with pytest.raises(ValueError):
+                ctx.interpolate('ps', z)
+            continue
+        # bit-identical: same corner order, separate multiply and add
+        np.testing.assert_array_equal(ctx.interpolate('ps', z),
+                                      orc.interpolate(c['model']['anchor_z'], c['model']['ps'], z).reshape(c['S'], B))
+        np.testing.assert_array_equal(ctx.interpolate('mus', z),
+                                      orc.interpolate(c['model']['anchor_z'], c['model']['mus'], z))
+        if c['bb_source'] >= 0:
+            nm = orc.interpolate(c['model']['anchor_z'], c['model']['n_model'], z)[c['bb_source']]
+            np.testing.assert_array_equal(ctx.interpolate('n_model', z), nm.reshape(B))
+    for key in f.files:
+        if key.startswith('full_') and key.endswith('_mus'):
+            j = int(key.split('_')[1])
+            ll, mus, ps, st = ctx.eval_full(c['call_z'][j], rate_scale_of(c, j))
+            assert same(ll, c['call_ll'][j], RTOL)
+            np.testing.assert_allclose(mus, f['full_%d_mus' % j], rtol=1e-12, atol=0)
+            np.testing.assert_allclose(ps, f['full_%d_ps' % j].reshape(c['S'], B), rtol=1e-12, atol=1e-300)
+
+
+def test_status_bits(ctx):
+    from blueice_amd import _capi
+    c = load_case('d3_small')
+    upload_case(ctx, c)
+    ll, st = ctx.eval(c['call_z'][-1], rate_scale_of(c, len(c['call_ll']) - 1))     # nan z
+    assert ll[0] == -np.inf and st[0] == _capi.ST_OUT_OF_BOUNDS
+    ll, st = ctx.eval([0., 0., 0.], [1., -1., 1., 1.])
+    assert ll[0] == -np.inf and st[0] == _capi.ST_UNPHYSICAL
+    ll, st = ctx.eval([0., 0., 0.], None, dataset=[3])
+    assert st[0] == _capi.ST_BAD_DATASET
+
+
+def test_state_errors():
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.exceptions import NotPreparedException
+    c = DeviceContext(0)
+    with pytest.raises(NotPreparedException):
+        c.d, c.S, c.B = 0, 1, 1
+        c.eval(None, [[1.]])
+    c.close()
