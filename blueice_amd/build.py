@@ -28,7 +28,9 @@ def build(force=False, verbose=False):
         if os.path.getmtime(OUT) >= newest:
             return OUT
     cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-shared', '-fPIC',
-           '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
+           # no implicit FMA contraction: the compatibility morph and the Beeston-Barlow roots follow the
+           # reference's operation order exactly; the hot loop uses explicit fma()
+           '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

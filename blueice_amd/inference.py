@@ -1,0 +1,92 @@
+"""Fit drivers over a likelihood callable: the `bestfit_scipy` path of the reference
+(blueice/inference.py:57-178) plus a batched `best_anchor` (:34-54).
+
+These only need `lf(**kwargs) -> float`, `lf.rate_parameters`, `lf.shape_parameters`,
+`lf.get_bounds`, `lf.pdf_base_config`; scipy.optimize is used as is.  iminuit / emcee drivers,
+intervals and plotting are out of scope.
+"""
+from collections import OrderedDict
+from copy import deepcopy
+
+import numpy as np
+from scipy.optimize import minimize
+
+from .exceptions import NoOpimizationNecessary, OptimizationFailed
+from .utils import is_numeric
+
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy']
+
+
+def best_anchor(lf):
+    """Shape-parameter dict of the anchor model with the highest likelihood -- all anchors in one
+    batched device call when the likelihood offers `eval_points`."""
+    if not len(lf.shape_parameters):
+        return dict()
+    names = list(lf.shape_parameters.keys())
+    anchors = list(lf.anchor_models.keys())
+    if hasattr(lf, 'eval_points'):
+        results = lf.eval_points({n: [a[j] for a in anchors] for j, n in enumerate(names)})
+    else:
+        results = np.array([lf(**dict(zip(names, a))) for a in anchors])
+    return dict(zip(names, anchors[int(np.argmax(results))]))
+
+
+def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, **kwargs):
+    """-> (f(x), names, guesses, bounds) over the parameters not fixed through kwargs.
+    Rate multipliers come first (guess 1, bounds (0, None)), then shape parameters (bounds from the
+    anchors, guess = base setting)."""
+    guess = guess or {}
+    names, guesses, bounds = [], [], []
+    for src in lf.rate_parameters:
+        key = '%s_rate_multiplier' % src
+        if key in kwargs:
+            continue
+        g = guess.get(key, 1)
+        names.append(key)
+        guesses.append(np.log10(g) if rates_in_log_space else g)
+        bounds.append((None, None) if rates_in_log_space else (0, None))
+    for key, (_, _, base_value) in lf.shape_parameters.items():
+        if key in kwargs:
+            continue
+        g = guess.get(key)
+        if g is None:
+            g = lf.pdf_base_config.get(key)
+            if not is_numeric(g):
+                g = base_value
+        names.append(key)
+        guesses.append(g)
+        bounds.append(lf.get_bounds(key))
+    if not names:
+        raise NoOpimizationNecessary("There are no parameters to fit, no optimization is necessary")
+    sign = -1 if minus else 1
+    log_rate = [rates_in_log_space and n.endswith('_rate_multiplier') for n in names]
+
+    def objective(args):
+        call = {n: (10 ** a if lg else a) for n, a, lg in zip(names, args, log_rate)}
+        call.update(kwargs)
+        return lf(**call) * sign
+
+    return objective, names, np.array(guesses), bounds
+
+
+def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bounds_to_minimizer=False, **kwargs):
+    """Maximise lf over its floating parameters -> (OrderedDict name -> value, max log likelihood).
+    scipy's default minimizer first, Nelder-Mead as the fallback, OptimizationFailed after that."""
+    minimize_kwargs = minimize_kwargs or {}
+    try:
+        f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space, **kwargs)
+    except NoOpimizationNecessary:
+        return {}, lf(**kwargs)
+    use_bounds = bounds if pass_bounds_to_minimizer else None
+    res = minimize(f, guess, bounds=use_bounds, **minimize_kwargs)
+    if not res.success:
+        retry = deepcopy(minimize_kwargs)
+        retry.pop('method', None)
+        res = minimize(f, guess, bounds=use_bounds, method='Nelder-Mead', **retry)
+        if not res.success:
+            raise OptimizationFailed("Optimization failure: ", res)
+    x = res.x if len(names) != 1 else [res.x.item()]
+    out = OrderedDict()
+    for n, v in zip(names, x):
+        out[n] = 10 ** v if (rates_in_log_space and n.endswith('_rate_multiplier')) else v
+    return out, -res.fun

@@ -1,0 +1,427 @@
+"""Binned log-likelihood with rate and shape parameters, evaluated on the GPU.
+
+Same surface as the reference's LogLikelihoodBase / BinnedLogLikelihood (blueice/likelihood.py:53-675):
+
+    lf = BinnedLogLikelihood(pdf_base_config, likelihood_config=None, **overrides)
+    lf.add_rate_parameter(name, log_prior) / lf.add_shape_parameter(name, anchors, log_prior, base_value)
+    lf.prepare(); lf.set_data(d); lf(**params) -> float          [full_output=True -> (ll, mus, ps)]
+    lf.bestfit_scipy(...), lf.make_objective(...)                 (inference.py, attached below)
+
+What differs is where the work happens.  `prepare()` streams the anchor models' PMF grids into HBM,
+`set_data()` uploads the binned counts, and every call does only the scalar bookkeeping of
+likelihood.py:328-415 on the host (parameter validation, bounds, priors, rate multipliers) before ONE
+fused device call performs the morph (likelihood.py:355-357), the optional Beeston-Barlow adjustment
+(:618-660) and the Poisson reduction (:662-675).  Batched entry points (`eval_points`, `eval_toys`)
+expose what the reference can only do as Python loops (inference.py:49-50,424-432).
+"""
+from collections import OrderedDict
+from copy import deepcopy
+from functools import wraps
+
+import numpy as np
+from scipy import stats
+
+from . import _capi
+from .device import DeviceContext
+from .exceptions import InvalidParameter, InvalidParameterSpecification, NotPreparedException
+from .histdd import Histdd
+from .model import Model
+from .pdf_morphers import MORPHERS
+from .utils import combine_dicts, is_numeric
+
+__all__ = ['LogLikelihoodBase', 'BinnedLogLikelihood']
+
+_BB_FLAGS = _capi.ST_BB_ROOT1 | _capi.ST_BB_NEG
+
+
+def _needs_preparation(method):
+    @wraps(method)
+    def guarded(self, *args, **kwargs):
+        if not self.is_prepared:
+            if len(self.shape_parameters):
+                raise NotPreparedException("%s requires you to first prepare the likelihood function using prepare()"
+                                           % method.__name__)
+            self.prepare()      # nothing to morph: preparation is trivial
+        return method(self, *args, **kwargs)
+    return guarded
+
+
+def _needs_data(method):
+    @wraps(method)
+    def guarded(self, *args, **kwargs):
+        if not self.is_data_set:
+            raise NotPreparedException("%s requires you to first set the data using set_data()" % method.__name__)
+        return method(self, *args, **kwargs)
+    return guarded
+
+
+class LogLikelihoodBase:
+    """Parameter registry, anchor-model construction and call plumbing shared by likelihoods."""
+
+    def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
+        self.pdf_base_config = combine_dicts(pdf_base_config, kwargs, deep_copy=True)
+        self.config = {} if likelihood_config is None else likelihood_config
+        self.config.setdefault('morpher', 'GridInterpolator')
+        if self.pdf_base_config.get('source_wise_interpolation', False):
+            raise NotImplementedError("Source-wise interpolation not implemented for binned likelihoods")
+
+        self.base_model = Model(self.pdf_base_config)
+        sources = self.base_model.sources
+        self.source_name_list = [s.name for s in sources]
+        self.source_allowed_negative = [s.config.get('allow_negative', False) for s in sources]
+        self.source_apply_efficiency = np.array([s.config.get('apply_efficiency', False) for s in sources])
+        self.source_efficiency_names = np.array([s.config.get('efficiency_name', 'efficiency') for s in sources])
+
+        self.rate_parameters = OrderedDict()     # source name -> log prior (or None)
+        self.shape_parameters = OrderedDict()    # setting name -> (anchors {z: setting}, log prior, base z)
+        self.anchor_models = OrderedDict()       # z tuple -> Model
+        self.is_prepared = False
+        self.is_data_set = False
+        self._has_non_numeric = False
+        self.morpher = None
+
+    # -- parameters ------------------------------------------------------------------------
+    def add_rate_parameter(self, source_name, log_prior=None):
+        """`<source_name>_rate_multiplier` multiplies that source's expected events."""
+        self.rate_parameters[source_name] = log_prior
+
+    def add_shape_parameter(self, setting_name, anchors, log_prior=None, base_value=None):
+        """Vary `setting_name` over `anchors`: a sequence of numeric settings, or a dict z -> setting
+        for non-numeric settings (then `base_value` names the z of the base model's setting)."""
+        numeric = is_numeric(self.pdf_base_config.get(setting_name))
+        if not isinstance(anchors, dict):
+            if not numeric:
+                raise InvalidParameterSpecification("When specifying anchors only by setting values, "
+                                                    "base setting must have a numerical default.")
+            anchors = {z: z for z in anchors}
+        if numeric and base_value is not None:
+            raise InvalidParameterSpecification("For numeric settings, base_value is an unnecessary argument.")
+        if not numeric:
+            if base_value is None:
+                raise InvalidParameterSpecification("For non-numeric settings, you must specify what number will "
+                                                    "represent the default value (the base model setting)")
+            self._has_non_numeric = True
+        self.shape_parameters[setting_name] = (anchors, log_prior, base_value)
+
+    def add_rate_uncertainty(self, source_name, fractional_uncertainty):
+        self.add_rate_parameter(source_name, log_prior=stats.norm(1, fractional_uncertainty).logpdf)
+
+    def add_shape_uncertainty(self, setting_name, fractional_uncertainty, anchor_zs=(-2, -1, 0, 1, 2), base_value=None):
+        self.add_shape_parameter(setting_name, anchor_zs, base_value=base_value)
+        anchors, _, base_value = self.shape_parameters[setting_name]
+        prior = stats.norm(base_value, base_value * fractional_uncertainty).logpdf
+        self.shape_parameters[setting_name] = (anchors, prior, base_value)
+
+    def get_bounds(self, parameter_name=None):
+        if parameter_name is None:
+            return [self.get_bounds(p) for p in self.shape_parameters]
+        if parameter_name in self.shape_parameters:
+            zs = list(self.shape_parameters[parameter_name][0].keys())
+            return min(zs), max(zs)
+        if parameter_name.endswith('_rate_multiplier'):
+            for name, neg in zip(self.source_name_list, self.source_allowed_negative):
+                if parameter_name.startswith(name) and neg:
+                    return float('-inf'), float('inf')
+            return 0, float('inf')
+        raise InvalidParameter("Non-existing parameter %s" % parameter_name)
+
+    def _kwargs_to_settings(self, **kwargs):
+        """-> (rate multipliers [S], {shape setting: z}) with defaults filled in."""
+        for k in kwargs:
+            known = k in self.shape_parameters or (k.endswith('_rate_multiplier')
+                                                   and k[:-len('_rate_multiplier')] in self.source_name_list)
+            if not known:
+                raise InvalidParameter("%s is not a known shape or rate parameter!" % k)
+        settings = {}
+        for name, (_, _, base_value) in self.shape_parameters.items():
+            z = kwargs.get(name)
+            if z is None:
+                base = self.pdf_base_config.get(name)
+                z = base if is_numeric(base) else base_value
+            if not is_numeric(z):
+                raise ValueError("Arguments to likelihood function must be numeric, not %s" % type(z))
+            settings[name] = z
+        multipliers = [kwargs.get(s + '_rate_multiplier', 1) for s in self.source_name_list]
+        return multipliers, settings
+
+    # -- anchor models ---------------------------------------------------------------------
+    def prepare(self, n_cores=1, ipp_client=None):
+        """Compute the model at every anchor point.  (Template building runs serially on the host;
+        the reference's process-pool / ipyparallel farms, likelihood.py:184-208, are out of scope.)"""
+        self.anchor_models = OrderedDict()
+        if len(self.shape_parameters):
+            self.morpher = MORPHERS[self.config['morpher']](self.config.get('morpher_config', {}),
+                                                            self.shape_parameters)
+            for zs in self.morpher.get_anchor_points(bounds=self.get_bounds()):
+                conf = deepcopy(self.pdf_base_config)
+                for z, (name, (anchors, _, _)) in zip(zs, self.shape_parameters.items()):
+                    conf[name] = anchors[z]
+                self.anchor_models[tuple(zs)] = Model(conf)
+        self.is_data_set = False
+        self.is_prepared = True
+
+    @_needs_preparation
+    def set_data(self, d):
+        self._data = d
+        self.is_data_set = True
+
+    def _compute_single_model(self, **kwargs):
+        _, settings = self._kwargs_to_settings(**kwargs)
+        return Model(combine_dicts(self.pdf_base_config, settings, deep_copy=True))
+
+    # -- host half of one evaluation -------------------------------------------------------
+    def _host_terms(self, livetime_days, kwargs):
+        """Everything of likelihood.py:328-393 that is scalar bookkeeping.
+        -> (prior_sum, z vector, rate_scale [S]) or (None, None, None) when z is out of bounds."""
+        multipliers, settings = self._kwargs_to_settings(**kwargs)
+        prior = 0
+        zs = []
+        for name, (_, log_prior, _) in self.shape_parameters.items():
+            z = settings[name]
+            lo, hi = self.get_bounds(name)
+            if not lo <= z <= hi:
+                return None, None, None         # cannot extrapolate: -inf (likelihood.py:345-347)
+            zs.append(z)
+            if log_prior is not None:
+                prior += log_prior(z)
+        scale = np.array(multipliers, dtype=float)
+        for mult, name in zip(multipliers, self.source_name_list):
+            log_prior = self.rate_parameters.get(name)
+            if log_prior is not None:
+                prior += log_prior(mult)
+        if livetime_days is not None:
+            if 'livetime_days' not in self.pdf_base_config:
+                raise ValueError("Cannot scale live-time, base value absent")
+            base = self.pdf_base_config['livetime_days']
+            if base == 0:
+                if livetime_days != 0:
+                    raise ValueError("Cannot scale from 0 to non-0 livetime")
+            else:
+                scale = scale * (livetime_days / base)
+        if True in self.source_apply_efficiency:
+            effs = [settings.get(name, 1) for use, name in
+                    zip(self.source_apply_efficiency, self.source_efficiency_names) if use]
+            scale[self.source_apply_efficiency] *= np.array(effs)
+        return prior, np.asarray(zs, dtype=float), scale
+
+
+class BinnedLogLikelihood(LogLikelihoodBase):
+    """Poisson likelihood over the bins of the analysis space, morph + reduce fused on the GPU."""
+
+    def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
+        super().__init__(pdf_base_config, likelihood_config, **kwargs)
+        pdf_base_config['pdf_interpolation_method'] = 'piecewise'
+        self.model_statistical_uncertainty_handling = self.config.get('model_statistical_uncertainty_handling')
+        self.ps = self.n_model_events = None
+        self.ctx = None
+        self._lazy_nm_interpolator = None
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def _bb_source_index(self):
+        if self.model_statistical_uncertainty_handling is None:
+            return -1
+        if self.model_statistical_uncertainty_handling != 'bb_single':
+            raise NotImplementedError("model_statistical_uncertainty_handling=%r" %
+                                      self.model_statistical_uncertainty_handling)
+        src = self.config.get('bb_single_source')
+        if src is None:
+            raise ValueError("You need to specify bb_single_source to use bb_single_source expectation adjustment")
+        return self.base_model.get_source_i(src)
+
+    def prepare(self, *args, **kwargs):
+        super().prepare(*args, **kwargs)
+        self.ps, self.n_model_events = self.base_model.pmf_grids()
+        self.bin_shape = self.ps.shape[1:]
+        S, B = len(self.source_name_list), int(np.prod(self.bin_shape, dtype=np.int64))
+        bb = self._bb_source_index()
+        if self.ctx is None:
+            self.ctx = DeviceContext(self.config.get('device'))
+        if len(self.shape_parameters):
+            self.morpher.stream_to_device(self.ctx, self.anchor_models, S, B, bb_source=bb)
+        else:
+            self.ctx.begin_model([], S, B, bb_source=bb)
+            self.ctx.set_anchor(0, self.ps, self.base_model.expected_events(),
+                                self.n_model_events[bb] if bb >= 0 else None)
+            self.ctx.end_model()
+        self.ctx.set_allow_negative([1 if x else 0 for x in self.source_allowed_negative])
+        self._lazy_nm_interpolator = None
+
+    # the morpher closures of the reference, served from the same device context
+    def mus_interpolator(self, zs):
+        return self.ctx.interpolate('mus', zs)
+
+    def ps_interpolator(self, zs):
+        return self.ctx.interpolate('ps', zs).reshape((len(self.source_name_list),) + tuple(self.bin_shape))
+
+    def n_model_events_interpolator(self, zs):
+        if self.model_statistical_uncertainty_handling is None or not len(self.shape_parameters):
+            return None
+        if self._lazy_nm_interpolator is None:      # full [S, *bins] tensor only if somebody asks for it
+            self._lazy_nm_interpolator = self.morpher.make_interpolator(
+                f=lambda m: m.pmf_grids()[1], extra_dims=list(self.ps.shape), anchor_models=self.anchor_models)
+        return self._lazy_nm_interpolator(zs)
+
+    @_needs_preparation
+    def set_data(self, d):
+        """Bin the events of `d` in the analysis space and keep the counts in HBM."""
+        LogLikelihoodBase.set_data(self, d)
+        names, edges = zip(*self.base_model.config['analysis_space'])
+        self.data_events_per_bin = Histdd(bins=edges, axis_names=names)
+        self.data_events_per_bin.add(*self.base_model.to_analysis_dimensions(d))
+        self.ctx.upload_counts(self.data_events_per_bin.histogram)
+
+    @_needs_preparation
+    def set_binned_data(self, counts):
+        """Upload already-binned counts: [*bins] or [T, *bins] for T toy datasets.
+        Dataset 0 is what plain `lf(**params)` evaluates."""
+        counts = np.asarray(counts, dtype=float)
+        if counts.shape[-len(self.bin_shape):] != tuple(self.bin_shape):
+            raise ValueError("counts must end in the analysis-space shape %s" % (tuple(self.bin_shape),))
+        self._data = None
+        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
+        self.data_events_per_bin.histogram = counts.reshape((-1,) + tuple(self.bin_shape))[0].copy()
+        self.ctx.upload_counts(counts)
+        self.is_data_set = True
+
+    # -- evaluation ------------------------------------------------------------------------
+    def _interpret(self, ll, status, mus_hint=None):
+        if status & _capi.ST_UNPHYSICAL:
+            if self.config.get('unphysical_behaviour') == 'error':
+                raise ValueError("Unphysical rates: %s" % str(mus_hint))
+            return -float('inf')
+        if status & _capi.ST_BB_ROOT1:
+            raise AssertionError("Beeston-Barlow: first root is not negative everywhere")
+        if status & _capi.ST_BB_NEG:
+            raise AssertionError("Beeston-Barlow: negative adjusted expectation")
+        return ll
+
+    @_needs_data
+    def __call__(self, livetime_days=None, compute_pdf=False, full_output=False, **kwargs):
+        if compute_pdf and len(self.shape_parameters):
+            if self._has_non_numeric:
+                raise NotImplementedError("compute_pdf only works for numerical values")
+            return self._call_with_fresh_pdf(livetime_days, full_output, kwargs)
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is None:
+            return -float('inf')
+        if full_output:
+            ll, mus, ps, st = self.ctx.eval_full(zs, scale)
+            ll = self._interpret(ll, st, mus)
+            if ll == -float('inf') and st:
+                return ll
+            return prior + ll, mus, ps.reshape((len(mus),) + tuple(self.bin_shape))
+        ll, st = self.ctx.eval(zs if len(zs) else None, scale[None, :])
+        st = int(st[0])
+        if st:
+            hint = self.ctx.interpolate('mus', zs) * scale if st & _capi.ST_UNPHYSICAL else None
+            ll0 = self._interpret(float(ll[0]), st, hint)
+            return ll0 if ll0 == -float('inf') else prior + ll0
+        return prior + float(ll[0])
+
+    def _call_with_fresh_pdf(self, livetime_days, full_output, kwargs):
+        """compute_pdf=True: build the model AT the requested settings instead of morphing
+        (likelihood.py:331-335,611-616) and evaluate it through a scratch d=0 device model."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is None:
+            return -float('inf')
+        model = self._compute_single_model(**kwargs)
+        ps, n_mc = model.pmf_grids()
+        bb = self._bb_source_index()
+        scratch = DeviceContext(self.ctx.device)
+        try:
+            scratch.begin_model([], len(ps), int(np.prod(self.bin_shape, dtype=np.int64)), bb_source=bb)
+            scratch.set_anchor(0, ps, model.expected_events(), n_mc[bb] if bb >= 0 else None)
+            scratch.end_model()
+            scratch.set_allow_negative([1 if x else 0 for x in self.source_allowed_negative])
+            scratch.upload_counts(self.data_events_per_bin.histogram)
+            if full_output:
+                ll, mus, ps_out, st = scratch.eval_full(None, scale)
+                ll = self._interpret(ll, st, mus)
+                return prior + ll, mus, ps_out.reshape(ps.shape)
+            ll, st = scratch.eval(None, scale[None, :])
+            return prior + self._interpret(float(ll[0]), int(st[0]), model.expected_events() * scale)
+        finally:
+            scratch.close()
+
+    # -- batched entry points (no counterpart in the reference) --------------------------------
+    def _batch_terms(self, points, livetime_days):
+        names = list(points.keys())
+        cols = [np.atleast_1d(np.asarray(points[n], dtype=float)) for n in names]
+        P = max((len(c) for c in cols), default=1)
+        cols = [np.broadcast_to(c, (P,)) for c in cols]
+        for k in names:
+            self._kwargs_to_settings(**{k: 0.0})       # name validation only
+        _, defaults = self._kwargs_to_settings()
+        z = np.empty((P, len(self.shape_parameters)))
+        prior = np.zeros(P)
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            z[:, i] = cols[names.index(name)] if name in names else defaults[name]
+            if log_prior is not None:
+                prior += np.array([log_prior(v) for v in z[:, i]])
+        scale = np.ones((P, len(self.source_name_list)))
+        for s, name in enumerate(self.source_name_list):
+            key = name + '_rate_multiplier'
+            if key in names:
+                scale[:, s] = cols[names.index(key)]
+            log_prior = self.rate_parameters.get(name)
+            if log_prior is not None:
+                prior += np.array([log_prior(v) for v in scale[:, s]])
+        if livetime_days is not None:
+            if 'livetime_days' not in self.pdf_base_config:
+                raise ValueError("Cannot scale live-time, base value absent")
+            base = self.pdf_base_config['livetime_days']
+            if base == 0:
+                if livetime_days != 0:
+                    raise ValueError("Cannot scale from 0 to non-0 livetime")
+            else:
+                scale = scale * (livetime_days / base)
+        if True in self.source_apply_efficiency:
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                en = self.source_efficiency_names[s]
+                if en in names:
+                    scale[:, s] *= cols[names.index(en)]
+                elif en in defaults:
+                    scale[:, s] *= defaults[en]
+        return z, scale, prior
+
+    @_needs_data
+    def eval_points(self, points, livetime_days=None, dataset=None):
+        """Evaluate many parameter points in one device call.
+
+        points: dict parameter name -> array [P] (scalars broadcast; absent parameters take their
+        defaults) -- the batched form of `[lf(**kw) for kw in ...]` used by likelihood scans,
+        `best_anchor` and profile grids.  Returns ll [P]; out-of-bounds / unphysical points are -inf
+        (or raise, under unphysical_behaviour='error'), exactly as the scalar call."""
+        z, scale, prior = self._batch_terms(points, livetime_days)
+        ll, st = self.ctx.eval(z if z.shape[1] else None, scale, dataset)
+        bad = st & _capi.ST_UNPHYSICAL
+        if np.any(bad) and self.config.get('unphysical_behaviour') == 'error':
+            raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(bad)), len(st)))
+        if np.any(st & _BB_FLAGS):
+            raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
+        out = ll + prior
+        out[(st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0] = -np.inf
+        return out
+
+    @_needs_data
+    def eval_toys(self, livetime_days=None, t0=0, t1=None, **kwargs):
+        """One parameter point against every uploaded dataset (see `set_binned_data`): ll [T]."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        T = (self.ctx.T if t1 is None else t1) - t0
+        if prior is None:
+            return np.full(T, -np.inf)
+        if self.model_statistical_uncertainty_handling is not None:
+            ll, st = self.ctx.eval(np.tile(zs, (T, 1)) if len(zs) else None, np.tile(scale, (T, 1)),
+                                   np.arange(t0, t0 + T))
+            return np.array([prior + self._interpret(a, int(b)) for a, b in zip(ll, st)])
+        ll, st = self.ctx.eval_datasets(zs, scale, t0, t0 + T)
+        if st & _capi.ST_UNPHYSICAL and self.config.get('unphysical_behaviour') == 'error':
+            raise ValueError("Unphysical rates")
+        return ll + prior if not st else ll
+
+
+# inference helpers double as methods, as in the reference (likelihood.py:1004-1007)
+from . import inference  # noqa: E402
+
+for _name in inference.__all__:
+    setattr(LogLikelihoodBase, _name, getattr(inference, _name))

@@ -1,0 +1,152 @@
+"""Deterministic synthetic anchor grids of the shapes BASELINE.json names.
+
+The hot path only ever sees tensors, so benchmarks and full-size parity tests use synthetic ones:
+    anchors per axis (-2,-1,0,1,2)[:n];  ps[a, s, :] = (U[0,1) + 0.05) normalised to sum 1 (strictly
+    positive, so mu > 0);  mus[a, s] = 1000 (s+1) (1 + 0.02 z0 - 0.01 z1 + 0.005 z2 ...);
+    counts ~ Poisson(sum_s mus_s ps_s) at the central anchor (about 1e4 events at C2 -> ~1 % of the
+    bins are non-empty) or a dense variant with ~10 events per bin.
+Every anchor block is generated from its own seed, so the 4 GB C2 tensor (or the 187 GB C5 one) never
+has to exist on the host: blocks are streamed to the device one anchor at a time, and a CPU checker
+can rebuild just the corners it needs.
+"""
+import itertools
+
+import numpy as np
+
+__all__ = ['SyntheticModel', 'CONFIGS']
+
+_MU_SLOPES = (0.02, -0.01, 0.005, 0.0025, -0.00125, 0.0006, 0.0003, 0.0001)
+
+CONFIGS = {
+    # name: (S, n_anchor per axis, bins)
+    'C1': (2, (3,), (40,)),
+    'C2': (4, (5, 5, 5), (100, 100, 100)),
+    'C5': (6, (5, 5, 5, 5), (50, 50, 50, 50)),
+    'C5-3anchor': (6, (3, 3, 3, 3), (50, 50, 50, 50)),
+    'mini3': (4, (3, 3, 3), (20, 17, 13)),       # ragged bin count (4420, not a tile multiple)
+    'mini4bb': (3, (2, 3, 2, 2), (11, 7, 5, 3)),
+}
+
+
+class SyntheticModel:
+    def __init__(self, S, n_anchor, bins, seed=1234, bb_source=-1):
+        self.S, self.n_anchor, self.bins = int(S), tuple(int(n) for n in n_anchor), tuple(int(b) for b in bins)
+        self.d = len(self.n_anchor)
+        self.B = int(np.prod(self.bins, dtype=np.int64))
+        self.A = int(np.prod(self.n_anchor, dtype=np.int64)) if self.d else 1
+        self.seed = int(seed)
+        self.bb_source = int(bb_source)
+        full = np.array([-2., -1., 0., 1., 2.])
+        self.anchor_z = []
+        for n in self.n_anchor:
+            if n <= 5:
+                lo = (5 - n) // 2
+                self.anchor_z.append(full[lo:lo + n].copy())
+            else:
+                self.anchor_z.append(np.linspace(-2., 2., n))
+
+    @classmethod
+    def named(cls, name, **kw):
+        S, na, bins = CONFIGS[name]
+        return cls(S, na, bins, **kw)
+
+    # -- anchors ---------------------------------------------------------------------------
+    def anchor_multi_index(self, a):
+        return np.unravel_index(a, self.n_anchor) if self.d else ()
+
+    def anchor_zs(self, a):
+        return tuple(float(g[i]) for g, i in zip(self.anchor_z, self.anchor_multi_index(a)))
+
+    def anchor_ps(self, a):
+        """[S, B] PMFs of anchor a (C-order anchor index)."""
+        rng = np.random.default_rng([self.seed, 1, int(a)])
+        p = rng.random((self.S, self.B))
+        p += 0.05
+        p /= p.sum(axis=1, keepdims=True)
+        return p
+
+    def anchor_mus(self, a):
+        zs = self.anchor_zs(a)
+        f = 1.0 + sum(sl * z for sl, z in zip(_MU_SLOPES, zs))
+        return np.array([1000. * (s + 1) * f for s in range(self.S)])
+
+    def anchor_n_model(self, a):
+        """[B] Monte-Carlo counts behind the Beeston-Barlow source (>= 1 everywhere)."""
+        rng = np.random.default_rng([self.seed, 2, int(a)])
+        return 1.0 + rng.poisson(30., self.B).astype(float)
+
+    def central_anchor(self):
+        return int(np.ravel_multi_index(tuple(n // 2 for n in self.n_anchor), self.n_anchor)) if self.d else 0
+
+    # -- data ------------------------------------------------------------------------------
+    def counts(self, dense=False, dataset=0, scale=None):
+        """[B] Poisson counts around the central anchor's expectation (integer-valued floats)."""
+        a = self.central_anchor()
+        lam = (self.anchor_mus(a)[:, None] * self.anchor_ps(a)).sum(axis=0)
+        if scale is None:
+            scale = (10.0 * self.B / lam.sum()) if dense else 1.0
+        rng = np.random.default_rng([self.seed, 3, int(dataset), int(bool(dense))])
+        return rng.poisson(lam * scale).astype(float)
+
+    # -- points ----------------------------------------------------------------------------
+    def default_point(self):
+        z = np.array((0.3, -1.7, 1.25, 0.6, -0.4, 0.9, 0.1, -1.1)[:self.d])
+        for i, g in enumerate(self.anchor_z):
+            z[i] = min(max(z[i], g[0]), g[-1])
+        r = np.array((1.1, 1.0, 0.7, 1.0, 1.0, 1.0, 0.9, 1.2)[:self.S])
+        return z, r
+
+    def random_points(self, P, seed=0):
+        rng = np.random.default_rng([self.seed, 4, int(seed)])
+        z = np.stack([rng.uniform(g[0], g[-1], size=P) for g in self.anchor_z], axis=1) if self.d \
+            else np.zeros((P, 0))
+        r = rng.uniform(0.5, 1.5, size=(P, self.S))
+        return z, r
+
+    # -- consumers -------------------------------------------------------------------------
+    def upload(self, ctx):
+        """Stream the model to a DeviceContext one anchor at a time (pdf_morphers.py:62-65 loop)."""
+        ctx.begin_model(self.anchor_z, self.S, self.B, bb_source=self.bb_source)
+        for a in range(self.A):
+            ctx.set_anchor(a, self.anchor_ps(a), self.anchor_mus(a),
+                           self.anchor_n_model(a) if self.bb_source >= 0 else None)
+        ctx.end_model()
+
+    def cell_model(self, z):
+        """Host tensors restricted to the grid cell containing z -- what a CPU checker needs:
+        dict(anchor_z, ps [2.., S, B], mus [2.., S], n_model) with 2 (or 1) anchors per axis.
+        Interpolating it at z is identical to interpolating the full tensor."""
+        ks = []
+        for g, zi in zip(self.anchor_z, z):
+            n = len(g)
+            if n == 1:
+                ks.append((0,))
+                continue
+            k = n - 2 if zi == g[-1] else min(max(int(np.searchsorted(g, zi, side='right')) - 1, 0), n - 2)
+            ks.append((k, k + 1))
+        shape = tuple(len(k) for k in ks)
+        ps = np.empty(shape + (self.S, self.B))
+        mus = np.empty(shape + (self.S,))
+        nm = np.empty(shape + (self.S, self.B)) if self.bb_source >= 0 else None
+        for loc in itertools.product(*[range(n) for n in shape]):
+            a = int(np.ravel_multi_index(tuple(k[i] for k, i in zip(ks, loc)), self.n_anchor)) if self.d else 0
+            ps[loc] = self.anchor_ps(a)
+            mus[loc] = self.anchor_mus(a)
+            if nm is not None:
+                nm[loc] = 1.0
+                nm[loc][self.bb_source] = self.anchor_n_model(a)
+        return dict(anchor_z=[g[list(k)] for g, k in zip(self.anchor_z, ks)], ps=ps, mus=mus, n_model=nm)
+
+    def dense_model(self):
+        """Full host tensors (small configs only)."""
+        shape = self.n_anchor
+        ps = np.empty(shape + (self.S, self.B))
+        mus = np.empty(shape + (self.S,))
+        nm = np.ones(shape + (self.S, self.B)) if self.bb_source >= 0 else None
+        for a in range(self.A):
+            loc = self.anchor_multi_index(a)
+            ps[loc] = self.anchor_ps(a)
+            mus[loc] = self.anchor_mus(a)
+            if nm is not None:
+                nm[loc][self.bb_source] = self.anchor_n_model(a)
+        return dict(anchor_z=self.anchor_z, ps=ps, mus=mus, n_model=nm)

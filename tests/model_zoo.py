@@ -1,0 +1,311 @@
+"""The likelihoods behind the golden fixtures, written once against a *namespace* of classes so the
+very same construction code runs
+  * on the real reference (tests/golden/make_golden.py, development container only) and
+  * on blueice_amd (tests/test_dropin_*.py), whose results are then compared with the goldens.
+
+`ns` must provide: BinnedLogLikelihood, DensityEstimatingSource, FixedSampleSource, GaussianMCSource,
+conf_for_test, make_data.
+"""
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+
+BB_LC = {'model_statistical_uncertainty_handling': 'bb_single', 'bb_single_source': 0}
+
+
+def namespace_of(package):
+    """Namespace for `package` in {'blueice' (the reference), 'blueice_amd'}."""
+    import importlib
+    lk = importlib.import_module(package + '.likelihood')
+    src = importlib.import_module(package + '.source')
+    th = importlib.import_module(package + '.test_helpers')
+    return SimpleNamespace(BinnedLogLikelihood=lk.BinnedLogLikelihood,
+                           DensityEstimatingSource=src.DensityEstimatingSource,
+                           FixedSampleSource=th.FixedSampleSource, GaussianMCSource=th.GaussianMCSource,
+                           conf_for_test=th.conf_for_test, make_data=th.make_data)
+
+
+_morphed_cache = {}
+
+
+def morphed_source_class(ns):
+    """FixedSampleSource whose sample and rate respond to numeric shape settings: events are
+    shifted / stretched / tilted with source-specific strengths."""
+    key = ns.DensityEstimatingSource
+    if key in _morphed_cache:
+        return _morphed_cache[key]
+
+    class MorphedSampleSource(ns.DensityEstimatingSource):
+        def __init__(self, config, *args, **kwargs):
+            super().__init__(config, *args, **kwargs)
+            k = self.config.get('strength', 1.0)
+            self.events_per_day *= (1 + 0.05 * k * self.config.get('shift', 0.)
+                                    - 0.03 * k * self.config.get('stretch', 0.)
+                                    + 0.02 * k * self.config.get('tilt', 0.))
+
+        def get_events_for_density_estimate(self):
+            d = self.config['data'].copy()
+            k = self.config.get('strength', 1.0)
+            names = [n for n, _ in self.config['analysis_space']]
+            d[names[0]] = d[names[0]] + 0.31 * k * self.config.get('shift', 0.)
+            if len(names) > 1:
+                d[names[1]] = d[names[1]] * (1 + 0.11 * k * self.config.get('stretch', 0.))
+            if len(names) > 2:
+                d[names[2]] = d[names[2]] + 0.07 * k * self.config.get('tilt', 0.) * d[names[0]]
+            return d, len(d)
+
+    _morphed_cache[key] = MorphedSampleSource
+    return MorphedSampleSource
+
+
+def sample(rng, n, space):
+    """n events inside the analysis space, clustered so that bins are unevenly filled."""
+    d = np.zeros(n, dtype=[('source', int)] + [(nm, float) for nm, _ in space])
+    for nm, edges in space:
+        lo, hi = edges[0], edges[-1]
+        u = rng.beta(2.0, 3.5, size=n)
+        d[nm] = lo + (hi - lo) * (0.02 + 0.96 * u)
+    return d
+
+
+def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=None, bb_floor=False):
+    strengths = [1.0, -0.6, 0.45, 1.7, -1.2, 0.8]
+    conf = dict(sources=[], default_source_class=morphed_source_class(ns),
+                analysis_space=space, force_recalculation=True, never_save_to_cache=True,
+                shift=0., stretch=0., tilt=0.)
+    if livetime is not None:
+        conf['livetime_days'] = livetime
+    for s in range(S):
+        d = sample(rng, n_mc, space)
+        if bb_floor and s == 0:
+            # >= 1 MC event in every bin for every anchor: add a lattice of bin centres
+            centres = np.meshgrid(*[0.5 * (np.asarray(e)[1:] + np.asarray(e)[:-1]) for _, e in space], indexing='ij')
+            lat = np.zeros(centres[0].size * 3, dtype=d.dtype)
+            for (nm, _), c in zip(space, centres):
+                lat[nm] = np.tile(c.ravel(), 3)
+            d = np.concatenate([d, lat])
+        conf['sources'].append(dict(name='s%d' % s, events_per_day=40. * (s + 1), data=d,
+                                    strength=0.0 if (bb_floor and s == 0) else strengths[s]))
+    lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(lc) if lc else None)
+    for s in range(S):
+        lf.add_rate_parameter('s%d' % s)
+    for nm, anchors in shape_anchors.items():
+        lf.add_shape_parameter(nm, anchors)
+    lf.prepare()
+    lf.set_data(sample(rng, n_data, space))
+    return lf
+
+
+# ---------------------------------------------------------------------------------------------
+# cases: name -> function(ns) -> (lf, calls, full_output call indices)
+# ---------------------------------------------------------------------------------------------
+def ref_single_bin(ns):
+    np.random.seed(1)
+    lf = ns.BinnedLogLikelihood(ns.conf_for_test(mc=True, analysis_space=[['x', [-40, 40]]]))
+    lf.add_rate_parameter('s0')
+    lf.prepare()
+    lf.set_data(np.zeros(1, dtype=[('x', float), ('source', int)]))
+    return lf, [{}, dict(s0_rate_multiplier=5.4), dict(s0_rate_multiplier=0.)], (1,)
+
+
+def ref_zero_bin(ns):
+    np.random.seed(2)
+    lf = ns.BinnedLogLikelihood(ns.conf_for_test(mc=True, analysis_space=[['x', [-40, 40]]]))
+    lf.add_rate_parameter('s0')
+    lf.prepare()
+    lf.set_data(np.zeros(0, dtype=[('x', float), ('source', int)]))
+    return lf, [dict(s0_rate_multiplier=0.), {}, dict(s0_rate_multiplier=2.)], ()
+
+
+def ref_multi_bin_single_dim(ns):
+    data, _ = ns.make_data([dict(n_events=24, x=0.5), dict(n_events=56, x=1.5)])
+    conf = ns.conf_for_test(events_per_day=42, analysis_space=[['x', [0, 1, 5]]],
+                            default_source_class=ns.FixedSampleSource, data=data)
+    lf = ns.BinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    data, _ = ns.make_data([dict(n_events=18, x=0.5), dict(n_events=70, x=1.5)])
+    lf.set_data(data)          # no prepare(): the auto-prepare path
+    return lf, [{}, dict(s0_rate_multiplier=1.7)], ()
+
+
+def ref_multi_bin(ns):
+    data, _ = ns.make_data([dict(n_events=24, x=0.5, y=0.5), dict(n_events=56, x=1.5, y=0.5),
+                            dict(n_events=6, x=0.5, y=2), dict(n_events=14, x=1.5, y=2)])
+    conf = ns.conf_for_test(events_per_day=42, default_source_class=ns.FixedSampleSource, data=data,
+                            analysis_space=[['x', [0, 1, 5]], ['y', [0, 1, 4]]])
+    lf = ns.BinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.add_shape_parameter('strlen_multiplier', {1: 'x', 2: 'hi', 3: 'wha'}, base_value=1)
+    lf.prepare()
+    data, _ = ns.make_data([dict(n_events=18, x=0.5, y=0.5), dict(n_events=70, x=1.5, y=0.5),
+                            dict(n_events=4, x=0.5, y=2), dict(n_events=10, x=1.5, y=2)])
+    lf.set_data(data)
+    calls = [dict(strlen_multiplier=1), dict(strlen_multiplier=2), dict(strlen_multiplier=2.3),
+             dict(strlen_multiplier=3), dict(strlen_multiplier=1.00001, s0_rate_multiplier=0.3),
+             dict(strlen_multiplier=3.5), dict(strlen_multiplier=0.99)]
+    return lf, calls, (2,)
+
+
+def ref_bb_single_bin(ns):
+    data, _ = ns.make_data([dict(n_events=32, x=0.5)])
+    conf = ns.conf_for_test(default_source_class=ns.FixedSampleSource, events_per_day=32 / 5,
+                            analysis_space=[['x', [0, 1]]], data=data)
+    lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(BB_LC))
+    lf.prepare()
+    lf.set_data(np.zeros(2, dtype=[('x', float), ('source', int)]))
+    return lf, [{}], (0,)
+
+
+def ref_bb_multi_bin(ns):
+    data, _ = ns.make_data([dict(n_events=16, x=0.5), dict(n_events=30, x=1.5),
+                            dict(n_events=32, x=2.5), dict(n_events=27, x=3.5)])
+    conf = ns.conf_for_test(default_source_class=ns.FixedSampleSource, events_per_day=105 / 5,
+                            analysis_space=[['x', [0, 1, 2, 3, 4]]], data=data)
+    lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(BB_LC))
+    lf.prepare()
+    data, _ = ns.make_data([dict(n_events=3, x=0.5), dict(n_events=5, x=1.5),
+                            dict(n_events=2, x=2.5), dict(n_events=7, x=3.5)])
+    lf.set_data(data)
+    return lf, [{}], (0,)
+
+
+def _bb_second_source_lf(ns, extra=False):
+    cal, _ = ns.make_data([dict(n_events=16, x=0.5), dict(n_events=30, x=1.5),
+                           dict(n_events=32, x=2.5), dict(n_events=27, x=3.5)])
+    oth, _ = ns.make_data([dict(n_events=5, x=0.5), dict(n_events=7, x=1.5),
+                           dict(n_events=1, x=2.5), dict(n_events=3, x=3.5)])
+    conf = ns.conf_for_test(default_source_class=ns.FixedSampleSource,
+                            analysis_space=[['x', [0, 1, 2, 3, 4]]], dummy=1)
+    conf['sources'] = [{'name': 's0', 'events_per_day': 105 / 5., 'data': cal},
+                       {'name': 's1', 'events_per_day': 16., 'data': oth}]
+    lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(BB_LC))
+    lf.add_shape_parameter('dummy', (0, 1))
+    if extra:
+        lf.add_rate_parameter('s1')
+        lf.add_rate_parameter('s0')
+        lf.add_shape_parameter('strlen_multiplier', {1: 'x', 2: 'hi', 3: 'wha'}, base_value=1)
+    lf.prepare()
+    data, _ = ns.make_data([dict(n_events=3, x=0.5), dict(n_events=5, x=1.5),
+                            dict(n_events=2, x=2.5), dict(n_events=7, x=3.5)])
+    lf.set_data(data)
+    return lf
+
+
+def ref_bb_second_source(ns):
+    return _bb_second_source_lf(ns), [{}, dict(dummy=0.25), dict(dummy=0)], (0,)
+
+
+def bb_two_shape(ns):
+    calls = [{}, dict(strlen_multiplier=1.5, dummy=.25),
+             dict(strlen_multiplier=2.3, dummy=.5, s1_rate_multiplier=.8),
+             dict(strlen_multiplier=3, dummy=1, s0_rate_multiplier=1.3), dict(strlen_multiplier=2, dummy=0.999),
+             dict(s1_rate_multiplier=0.),
+             dict(strlen_multiplier=2.75, dummy=0.1, s0_rate_multiplier=0.4, s1_rate_multiplier=2.2)]
+    return _bb_second_source_lf(ns, extra=True), calls, (2, 5)
+
+
+def c1_like(ns):
+    rng = np.random.default_rng(11)
+    space = [['x', np.linspace(-4, 4, 41)]]
+    lf = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 4000, 300)
+    calls = [{}, dict(shift=-1.), dict(shift=1.), dict(shift=0.37), dict(shift=-0.82, s0_rate_multiplier=1.4),
+             dict(shift=0.999999, s1_rate_multiplier=0.), dict(shift=1.2), dict(shift=-1.0000001),
+             dict(s0_rate_multiplier=-0.1), dict(shift=0.5, s0_rate_multiplier=0., s1_rate_multiplier=0.)]
+    return lf, calls, (3,)
+
+
+def d2_nonuniform(ns):
+    rng = np.random.default_rng(12)
+    space = [['x', np.array([-3., -1.5, -0.5, 0., 0.4, 1.1, 3.])], ['y', np.linspace(0, 5, 6)]]
+    lf = morph_lf(ns, rng, 3, space, OrderedDict(shift=(-1., -0.25, 0.5, 2.), stretch=(0., 1., 4.)),
+                  3000, 500, livetime=2.)
+    calls = [{}]
+    for z0 in (-1., -0.6, -0.25, 0.1, 0.5, 1.3, 2.):
+        for z1 in (0., 0.5, 1., 2.5, 4.):
+            calls.append(dict(shift=z0, stretch=z1))
+    calls += [dict(shift=0.3, stretch=3.3, s0_rate_multiplier=0.5, s1_rate_multiplier=2., s2_rate_multiplier=1.1),
+              dict(shift=0.3, stretch=3.3, livetime_days=5.), dict(shift=2.01, stretch=1.),
+              dict(shift=0., stretch=-0.01), dict(shift=1., stretch=2., s2_rate_multiplier=-1.)]
+    return lf, calls, (9, 36)
+
+
+def d3_small(ns):
+    rng = np.random.default_rng(13)
+    space = [['x', np.linspace(-3, 3, 7)], ['y', np.linspace(0, 5, 6)], ['w', np.linspace(-2, 2, 5)]]
+    lf = morph_lf(ns, rng, 4, space,
+                  OrderedDict(shift=(-1., 0., 1.), stretch=(-1., 0., 1.), tilt=(-1., 0., 1.)), 5000, 800)
+    calls = [{}]
+    pts = rng.uniform(-1, 1, size=(16, 3))
+    special = [(-1, -1, -1), (1, 1, 1), (0, 0, 0), (1, -1, 0), (0.5, 1, -1), (-1, 0.25, 1), (1, 0, 0.75),
+               (0, 0, 1e-9), (-1e-12, 0, 0)]
+    for p in list(pts) + [np.array(s, dtype=float) for s in special]:
+        calls.append(dict(shift=float(p[0]), stretch=float(p[1]), tilt=float(p[2])))
+    calls += [dict(shift=.2, stretch=-.7, tilt=.4, s0_rate_multiplier=1.2, s1_rate_multiplier=0.,
+                   s2_rate_multiplier=0.7, s3_rate_multiplier=3.),
+              dict(shift=1.0000001, stretch=0, tilt=0), dict(shift=float('nan'), stretch=0, tilt=0)]
+    return lf, calls, (5, 26)
+
+
+def d0_multi_source(ns):
+    rng = np.random.default_rng(14)
+    space = [['x', np.linspace(-3, 3, 13)], ['y', np.linspace(0, 5, 4)]]
+    lf = morph_lf(ns, rng, 3, space, OrderedDict(), 2000, 150)
+    return lf, [{}, dict(s0_rate_multiplier=2.), dict(s1_rate_multiplier=0., s2_rate_multiplier=.5)], (1,)
+
+
+def _edge_lf(ns):
+    data, _ = ns.make_data([dict(n_events=10, x=0.5), dict(n_events=30, x=2.5)])
+    conf = ns.conf_for_test(events_per_day=20, analysis_space=[['x', [0, 1, 2, 3]]],
+                            default_source_class=ns.FixedSampleSource, data=data)
+    lf = ns.BinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.add_shape_parameter('strlen_multiplier', {1: 'x', 2: 'hi'}, base_value=1)
+    lf.prepare()
+    return lf
+
+
+_EDGE_CALLS = [{}, dict(strlen_multiplier=1.5), dict(s0_rate_multiplier=0.)]
+
+
+def edge_mu_zero_hit(ns):
+    lf = _edge_lf(ns)
+    lf.set_data(ns.make_data([dict(n_events=3, x=0.5), dict(n_events=1, x=1.5)])[0])
+    return lf, list(_EDGE_CALLS), ()
+
+
+def edge_mu_zero_ok(ns):
+    lf = _edge_lf(ns)
+    lf.set_data(ns.make_data([dict(n_events=3, x=0.5), dict(n_events=11, x=2.5)])[0])
+    return lf, list(_EDGE_CALLS), ()
+
+
+def edge_empty_data(ns):
+    lf = _edge_lf(ns)
+    lf.set_data(ns.make_data([])[0])
+    return lf, [{}, dict(strlen_multiplier=2), dict(s0_rate_multiplier=0.)], ()
+
+
+def bb_d2(ns):
+    rng = np.random.default_rng(15)
+    space = [['x', np.linspace(-3, 3, 7)], ['y', np.linspace(0, 5, 4)]]
+    lf = morph_lf(ns, rng, 3, space, OrderedDict(shift=(-1., 0., 1.), stretch=(0., 1.)), 2500, 400,
+                  lc=BB_LC, bb_floor=True)
+    calls = [{}]
+    for p in rng.uniform(0, 1, size=(10, 2)):
+        calls.append(dict(shift=float(2 * p[0] - 1), stretch=float(p[1])))
+    calls += [dict(shift=-1., stretch=1.), dict(shift=.4, stretch=.6, s0_rate_multiplier=1.5, s1_rate_multiplier=.2),
+              dict(shift=.4, stretch=.6, s1_rate_multiplier=0., s2_rate_multiplier=0.)]
+    return lf, calls, (4, 12)
+
+
+def fit_c1_like(ns):
+    rng = np.random.default_rng(21)
+    space = [['x', np.linspace(-4, 4, 41)]]
+    return morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 4000, 300)
+
+
+CASES = OrderedDict((f.__name__, f) for f in (
+    ref_single_bin, ref_zero_bin, ref_multi_bin_single_dim, ref_multi_bin, ref_bb_single_bin,
+    ref_bb_multi_bin, ref_bb_second_source, bb_two_shape, c1_like, d2_nonuniform, d3_small,
+    d0_multi_source, edge_mu_zero_hit, edge_mu_zero_ok, edge_empty_data, bb_d2))

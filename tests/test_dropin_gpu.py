@@ -1,0 +1,199 @@
+"""The drop-in on the GPU: blueice_amd.BinnedLogLikelihood built from the same configs as the
+reference (tests/model_zoo.py) must return the reference's numbers (tests/golden) through the same
+API -- lf(**kw), full_output, bestfit_scipy -- and its batched entry points must agree with the
+scalar calls.  Tolerance 1e-10 * max(1, |ref|); +-inf / nan / raised errors exact."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import model_zoo
+from golden_util import GOLDEN_DIR, load_case, same
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def ns():
+    return model_zoo.namespace_of('blueice_amd')
+
+
+@pytest.mark.parametrize('name', list(model_zoo.CASES))
+def test_lf_calls_match_reference(ns, name):
+    lf, calls, full = model_zoo.CASES[name](ns)
+    c = load_case(name)
+    scalar = []
+    for j, kw in enumerate(calls):
+        if ('call_asserts_%d' % j) in c['raw'].files:
+            with pytest.raises(AssertionError):
+                lf(**kw)
+            scalar.append(np.nan)
+            continue
+        ll = lf(**kw)
+        assert same(ll, c['call_ll'][j], RTOL), (name, j, kw, ll, c['call_ll'][j])
+        scalar.append(ll)
+    for j in full:
+        if ('full_%d_mus' % j) not in c['raw'].files:
+            continue
+        ll, mus, ps = lf(full_output=True, **calls[j])
+        assert same(ll, c['call_ll'][j], RTOL)
+        np.testing.assert_allclose(mus, c['raw']['full_%d_mus' % j], rtol=1e-12)
+        assert ps.shape == c['raw']['full_%d_ps' % j].shape
+        np.testing.assert_allclose(ps, c['raw']['full_%d_ps' % j], rtol=1e-12, atol=1e-300)
+    # batched form of the same calls (no livetime / asserting calls in the batch)
+    keep = [j for j, kw in enumerate(calls) if 'livetime_days' not in kw and not np.isnan(scalar[j])]
+    names = sorted({k for j in keep for k in calls[j]})
+    if keep and names:
+        _, defaults = lf._kwargs_to_settings()
+        pts = {}
+        for n in names:
+            dflt = defaults.get(n, 1.0)
+            pts[n] = [calls[j].get(n, dflt) for j in keep]
+        batch = lf.eval_points(pts)
+        for b, j in zip(batch, keep):
+            assert same(b, scalar[j], 1e-12), (name, j, b, scalar[j])
+
+
+def test_reference_binned_tests_verbatim(ns):
+    """tests/test_binned_likelihood.py::test_single_bin / test_multi_bin of the reference,
+    with the reference's own assertions (closed-form scipy expectations)."""
+    from blueice_amd import BinnedLogLikelihood
+    from blueice_amd.test_helpers import conf_for_test, make_data, almost_equal, FixedSampleSource
+    lf = BinnedLogLikelihood(conf_for_test(mc=True, analysis_space=[['x', [-40, 40]]]))
+    lf.add_rate_parameter('s0')
+    lf.prepare()
+    lf.set_data(np.zeros(1, dtype=[('x', float), ('source', int)]))
+    assert almost_equal(lf(), stats.poisson(1000).logpmf(1), 1e-12)
+    assert almost_equal(lf(s0_rate_multiplier=5.4), stats.poisson(5400).logpmf(1), 1e-12)
+    lf.set_data(np.zeros(0, dtype=[('x', float), ('source', int)]))
+    assert lf(s0_rate_multiplier=0.) == stats.poisson(0).logpmf(0) == 0         # test_zero_bin
+
+    mc = [dict(n_events=24, x=0.5, y=0.5), dict(n_events=56, x=1.5, y=0.5),
+          dict(n_events=6, x=0.5, y=2), dict(n_events=14, x=1.5, y=2)]
+    data, n_mc = make_data(mc)
+    conf = conf_for_test(events_per_day=42, default_source_class=FixedSampleSource, data=data,
+                         analysis_space=[['x', [0, 1, 5]], ['y', [0, 1, 4]]])
+    lf = BinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.add_shape_parameter('strlen_multiplier', {1: 'x', 2: 'hi', 3: 'wha'}, base_value=1)
+    lf.prepare()
+    obs = [dict(n_events=18, x=0.5, y=0.5), dict(n_events=70, x=1.5, y=0.5),
+           dict(n_events=4, x=0.5, y=2), dict(n_events=10, x=1.5, y=2)]
+    lf.set_data(make_data(obs)[0])
+    mus = [42 / n_mc * m['n_events'] for m in mc]
+    seen = [o['n_events'] for o in obs]
+    for z in (1, 2, 2.3):
+        assert almost_equal(lf(strlen_multiplier=z),
+                            np.sum([stats.poisson(z * mu).logpmf(k) for mu, k in zip(mus, seen)]))
+    with pytest.raises(NotImplementedError):
+        lf(compute_pdf=True, strlen_multiplier=2)
+    assert lf() == lf(strlen_multiplier=1)                                       # base_value default
+
+
+def test_error_handling_and_unphysical(ns):
+    from blueice_amd.exceptions import InvalidParameter, NotPreparedException
+    lf, calls, _ = model_zoo.c1_like(ns)
+    with pytest.raises(InvalidParameter):
+        lf(blargh=41)
+    with pytest.raises(ValueError):
+        lf(shift='hi')
+    assert lf(s0_rate_multiplier=-0.1) == -np.inf
+    lf.config['unphysical_behaviour'] = 'error'
+    with pytest.raises(ValueError):
+        lf(s0_rate_multiplier=-0.1)
+    with pytest.raises(ValueError):
+        lf.eval_points(dict(s0_rate_multiplier=[1., -0.1]))
+    del lf.config['unphysical_behaviour']
+    assert lf(shift=1.2) == -np.inf
+    lf.prepare()                     # re-preparing invalidates the data (likelihood.py:253)
+    with pytest.raises(NotPreparedException):
+        lf()
+
+
+def test_compute_pdf_numeric(ns):
+    """compute_pdf=True builds the model at the requested point; at an anchor it must agree with the
+    interpolated value (same templates), off-anchor it differs."""
+    lf, _, _ = model_zoo.c1_like(ns)
+    a = lf(shift=1.0, s0_rate_multiplier=1.3)
+    b = lf(compute_pdf=True, shift=1.0, s0_rate_multiplier=1.3)
+    assert same(b, a, 1e-12)
+    assert abs(lf(compute_pdf=True, shift=0.5) - lf(shift=0.5)) > 1e-6
+
+
+def test_priors_and_livetime(ns):
+    lf, _, _ = model_zoo.d2_nonuniform(ns)
+    base = lf(shift=0.3, stretch=3.3)
+    lf.add_rate_uncertainty('s1', 0.2)
+    lf.shape_parameters['shift'] = (lf.shape_parameters['shift'][0], stats.norm(0, 1).logpdf, None)
+    got = lf(shift=0.3, stretch=3.3, s1_rate_multiplier=1.1)
+    lf.rate_parameters['s1'] = None
+    lf.shape_parameters['shift'] = (lf.shape_parameters['shift'][0], None, None)
+    bare = lf(shift=0.3, stretch=3.3, s1_rate_multiplier=1.1)
+    assert same(got, bare + stats.norm(1, 0.2).logpdf(1.1) + stats.norm(0, 1).logpdf(0.3), 1e-13)
+    # livetime scaling == scaling every rate (single global factor), likelihood.py:374-382
+    assert same(lf(shift=0.3, stretch=3.3, livetime_days=5.),
+                lf(shift=0.3, stretch=3.3, s0_rate_multiplier=2.5, s1_rate_multiplier=2.5, s2_rate_multiplier=2.5), 1e-13)
+    assert base == lf(shift=0.3, stretch=3.3)
+
+
+def test_bestfit_scipy_matches_reference(ns):
+    f = np.load(GOLDEN_DIR + '/fit_c1_like.npz')
+    lf = model_zoo.fit_c1_like(ns)
+    res, ll = lf.bestfit_scipy()
+    assert list(res.keys()) == [str(x) for x in f['fit_all_names']]
+    assert abs(ll - float(f['fit_all_ll'])) < 1e-6 * abs(ll)
+    np.testing.assert_allclose(list(res.values()), f['fit_all_values'], rtol=2e-3, atol=2e-3)
+    res, ll = lf.bestfit_scipy(shift=0.2)
+    assert list(res.keys()) == [str(x) for x in f['fit_fixshift_names']]
+    assert abs(ll - float(f['fit_fixshift_ll'])) < 1e-6 * abs(ll)
+    # "Don't fit": everything fixed -> ({}, lf(...)) exactly (inference.py:150-151)
+    res, ll = lf.bestfit_scipy(shift=0.2, s0_rate_multiplier=1., s1_rate_multiplier=0.9)
+    assert res == {} and same(ll, float(f['fit_none_ll']), RTOL)
+    objective, names, guess, bounds = lf.make_objective()
+    assert names == ['s0_rate_multiplier', 's1_rate_multiplier', 'shift']
+    assert list(guess) == [1, 1, 0] and bounds == [(0, None), (0, None), (-1.0, 1.0)]
+    assert same(objective(guess), -lf(), 0)
+    best = lf.best_anchor()
+    assert set(best) == {'shift'} and best['shift'] in (-1.0, 0.0, 1.0)
+    assert lf(**best) == max(lf(shift=z) for z in (-1., 0., 1.))
+
+
+def test_morpher_api_contract():
+    """The reference's tests/test_morphers.py::test_morpher_api, for the device-backed morpher."""
+    from collections import OrderedDict
+    from blueice_amd import pdf_morphers
+    from blueice_amd.exceptions import NoShapeParameters
+    for name, cls in pdf_morphers.MORPHERS.items():
+        with pytest.raises(NoShapeParameters):
+            cls(config={}, shape_parameters=OrderedDict())
+        sp = OrderedDict([('bla', ({-1: -1, 0: 0, 1: 1}, None, None))])
+        mr = cls(config={}, shape_parameters=sp)
+        aps = mr.get_anchor_points(bounds=[(-1, 1)], n_models=3)
+        assert isinstance(aps, list) and isinstance(aps[0], tuple)
+        scalar_itp = mr.make_interpolator(lambda _: 0, extra_dims=[], anchor_models={z: None for z in aps})
+        assert scalar_itp([0]) == 0
+        matrix_itp = mr.make_interpolator(lambda _: 0, extra_dims=[2, 2], anchor_models={z: None for z in aps})
+        np.testing.assert_array_equal(matrix_itp([0]), np.zeros((2, 2)))
+        lin = mr.make_interpolator(lambda m: np.array([m, 2. * m]), extra_dims=[2],
+                                   anchor_models={z: float(z[0]) for z in aps})
+        np.testing.assert_allclose(lin([0.25]), [0.25, 0.5], rtol=1e-15)
+        with pytest.raises(ValueError):
+            lin([1.5])
+
+
+def test_toys_match_scalar_calls(ns):
+    lf, _, _ = model_zoo.d3_small(ns)
+    rng = np.random.default_rng(5)
+    base = lf.data_events_per_bin.histogram
+    toys = rng.poisson(base + 0.3, size=(7,) + base.shape).astype(float)
+    want = []
+    for t in toys:
+        lf.set_binned_data(t)
+        want.append(lf(shift=0.2, stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3))
+    lf.set_binned_data(toys)
+    got = lf.eval_toys(shift=0.2, stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3)
+    for g, w in zip(got, want):
+        assert same(g, w, 1e-12)
+    assert same(lf(shift=0.2, stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3), want[0], 0)   # dataset 0
+    both = lf.eval_points(dict(shift=[0.2, 0.2], stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3), dataset=[3, 6])
+    assert same(both[0], want[3], 1e-12) and same(both[1], want[6], 1e-12)

@@ -1,0 +1,181 @@
+"""Host logic of the drop-in (no GPU): the Model / Source / Histdd / morpher / likelihood plumbing must
+hand the device exactly the tensors the reference builds and
+implement the scalar bookkeeping of row a4.  The device is replaced by a recorder -- nothing is
+computed in its place."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+import model_zoo
+from golden_util import load_case
+
+
+class RecordingContext:
+    """Stands where DeviceContext would: records uploads, cannot evaluate."""
+    instances = []
+
+    def __init__(self, device=None):
+        self.device = device
+        self.anchors = {}
+        self.counts = None
+        self.T = 0
+        RecordingContext.instances.append(self)
+
+    def begin_model(self, anchor_z, S, B, bb_source=-1):
+        self.anchor_z, self.S, self.B, self.bb_source = [np.asarray(g, float) for g in anchor_z], S, B, bb_source
+        self.anchors = {}
+
+    def set_anchor(self, idx, ps, mus, n_model_row=None):
+        self.anchors[idx] = (np.array(ps, float).reshape(self.S, self.B), np.array(mus, float),
+                             None if n_model_row is None else np.array(n_model_row, float).reshape(self.B))
+
+    def end_model(self):
+        pass
+
+    def set_allow_negative(self, flags):
+        self.allow_negative = list(flags)
+
+    def upload_counts(self, counts):
+        self.counts = np.array(counts, float)
+        self.T = self.counts.size // self.B
+
+    def close(self):
+        pass
+
+
+@pytest.fixture()
+def ns(monkeypatch):
+    import blueice_amd.likelihood as lk
+    monkeypatch.setattr(lk, 'DeviceContext', RecordingContext)
+    RecordingContext.instances.clear()
+    return model_zoo.namespace_of('blueice_amd')
+
+
+@pytest.mark.parametrize('name', list(model_zoo.CASES))
+def test_uploaded_tensors_equal_reference_tensors(ns, name):
+    lf, calls, _ = model_zoo.CASES[name](ns)
+    c = load_case(name)
+    rec = lf.ctx
+    assert isinstance(rec, RecordingContext)
+    assert rec.S == c['S'] and rec.B == int(np.prod(c['bins'])) and rec.bb_source == c['bb_source']
+    assert len(rec.anchor_z) == c['d']
+    for g, g_ref in zip(rec.anchor_z, c['model']['anchor_z']):
+        np.testing.assert_array_equal(g, g_ref)
+    grid_shape = tuple(len(g) for g in c['model']['anchor_z'])
+    ps_ref = c['model']['ps'].reshape((-1, c['S'], rec.B))
+    mus_ref = c['model']['mus'].reshape((-1, c['S']))
+    assert len(rec.anchors) == int(np.prod(grid_shape)) == len(ps_ref)
+    for idx, (ps, mus, nm) in rec.anchors.items():
+        np.testing.assert_array_equal(ps, ps_ref[idx])
+        np.testing.assert_array_equal(mus, mus_ref[idx])
+        if c['bb_source'] >= 0:
+            nm_ref = c['model']['n_model'].reshape((-1, c['S'], rec.B))[idx, c['bb_source']]
+            np.testing.assert_array_equal(nm, nm_ref)
+    np.testing.assert_array_equal(rec.counts.reshape(c['counts'].shape), c['counts'])
+    # the scalar half of every call (row a4): z vector, rate scale, out-of-bounds exit
+    shape_names = list(lf.shape_parameters)
+    for j, kw in enumerate(calls):
+        kw = dict(kw)
+        lt = kw.pop('livetime_days', None)
+        prior, zs, scale = lf._host_terms(lt, kw)
+        z_ref = c['call_z'][j]
+        in_box = all(g[0] <= z <= g[-1] for g, z in zip(c['model']['anchor_z'], z_ref))
+        if not in_box:
+            assert prior is None
+            continue
+        assert prior == 0
+        np.testing.assert_array_equal(zs, z_ref)
+        want = c['call_mult'][j] * (1.0 if lt is None else lt / c['livetime_base'])
+        np.testing.assert_array_equal(scale, want)
+    assert shape_names == list(lf.shape_parameters)
+
+
+def test_anchor_points_and_grid_order(ns):
+    from blueice_amd.pdf_morphers import GridInterpolator, MORPHERS
+    from blueice_amd.exceptions import NoShapeParameters
+    with pytest.raises(NoShapeParameters):
+        GridInterpolator({}, OrderedDict())
+    sp = OrderedDict([('a', ({2: 'x', -1: 'y', 0.5: 'z'}, None, None)), ('b', ({0: 0, 1: 1}, None, None))])
+    m = MORPHERS['GridInterpolator']({}, sp)
+    pts = m.get_anchor_points(bounds=None)
+    assert isinstance(pts, list) and isinstance(pts[0], tuple)
+    assert pts == [(-1, 0), (-1, 1), (0.5, 0), (0.5, 1), (2, 0), (2, 1)]          # sorted, C order
+    assert [lin for lin, _, _ in m.anchor_items()] == list(range(6))
+
+
+def test_parameter_registry_and_errors(ns):
+    from blueice_amd import BinnedLogLikelihood
+    from blueice_amd.exceptions import (InvalidParameter, InvalidParameterSpecification, NotPreparedException)
+    from blueice_amd.test_helpers import conf_for_test
+    lf = BinnedLogLikelihood(conf_for_test(n_sources=2, mc=True, n_events_for_pdf=500,
+                                           analysis_space=[['x', [-40, 0, 40]]]))
+    lf.add_rate_parameter('s0')
+    with pytest.raises(InvalidParameterSpecification):
+        lf.add_shape_parameter('strlen_multiplier', {1: 'x', 2: 'hi', 3: 'wha'})      # needs base_value
+    with pytest.raises(InvalidParameterSpecification):
+        lf.add_shape_parameter('strlen_multiplier', ['x', 'hi'])                     # list of non-numerics
+    with pytest.raises(InvalidParameterSpecification):
+        lf.add_shape_parameter('some_multiplier', (0.5, 1, 2), base_value=1)         # numeric + base_value
+    lf.add_shape_parameter('strlen_multiplier', {1: 'q', 2: 'hi', 3: 'wha'}, base_value=1)
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 2, 4))
+    assert lf.get_bounds('strlen_multiplier') == (1, 3)
+    assert lf.get_bounds('some_multiplier') == (0.5, 4)
+    assert lf.get_bounds() == [(1, 3), (0.5, 4)]
+    assert lf.get_bounds('s0_rate_multiplier') == (0, float('inf'))
+    with pytest.raises(InvalidParameter):
+        lf.get_bounds('nope')
+    d = np.zeros(3, dtype=[('x', float), ('source', int)])
+    with pytest.raises(NotPreparedException):
+        lf.set_data(d)
+    with pytest.raises(NotPreparedException):
+        lf()
+    lf.prepare()
+    assert len(lf.anchor_models) == 12 and (1, 0.5) in lf.anchor_models
+    with pytest.raises(NotPreparedException):
+        lf()
+    lf.set_data(d)
+    with pytest.raises(InvalidParameter):
+        lf._host_terms(None, dict(blargh=41))
+    with pytest.raises(ValueError):
+        lf._host_terms(None, dict(strlen_multiplier='hi'))
+    mult, settings = lf._kwargs_to_settings(s1_rate_multiplier=3)
+    assert mult == [1, 3] and settings == {'strlen_multiplier': 1, 'some_multiplier': 1}
+    with pytest.raises(ValueError):
+        lf._host_terms(1., {})                      # no base livetime in this config -> cannot scale
+    # priors are added on the host
+    lf.add_rate_uncertainty('s1', 0.1)
+    prior, zs, scale = lf._host_terms(None, dict(s1_rate_multiplier=1.2))
+    from scipy import stats
+    assert prior == stats.norm(1, 0.1).logpdf(1.2)
+
+
+def test_histdd_matches_numpy_semantics():
+    from blueice_amd.histdd import Histdd
+    rng = np.random.default_rng(0)
+    edges = [np.array([0., 1., 2.5, 7.]), np.linspace(-1, 1, 5)]
+    x, y = rng.uniform(-1, 8, 500), rng.uniform(-1.2, 1.2, 500)
+    x[:3] = [7., 0., 2.5]
+    y[:3] = [1., -1., 0.]
+    h = Histdd(x, y, bins=edges, axis_names=['x', 'y'])
+    np.testing.assert_array_equal(h.histogram, np.histogramdd(np.stack([x, y], 1), bins=edges)[0])
+    assert h.n == h.histogram.sum()
+    np.testing.assert_allclose(h.bin_volumes(), np.outer(np.diff(edges[0]), np.diff(edges[1])))
+    assert h.lookup(np.array([0.5]), np.array([-0.9]))[0] == h.histogram[0, 0]
+    assert h.similar_blank_hist().histogram.sum() == 0
+
+
+def test_model_simulate_and_source_rates():
+    from blueice_amd import Model
+    from blueice_amd.test_helpers import conf_for_test, GaussianMCSource
+    np.random.seed(3)
+    m = Model(conf_for_test(n_sources=2, mc=True, n_events_for_pdf=2000, s1_rate_multiplier=2.))
+    assert isinstance(m.sources[0], GaussianMCSource)
+    np.testing.assert_allclose(m.expected_events(), [1000., 2000.])
+    assert m.get_source_i('s1') == 1 and m.get_source_i(0) == 0
+    with pytest.raises(ValueError):
+        m.get_source_i('nope')
+    d = m.simulate()
+    assert 2500 < len(d) < 3500 and set(np.unique(d['source'])) == {0, 1}
+    pmf, n_mc = m.pmf_grids()
+    assert pmf.shape == (2, 99) and abs(pmf[0].sum() - 1) < 1e-12 and n_mc.sum() == 4000
