@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: binned-likelihood evaluations per second on the BASELINE.json model.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1], "C2"): 4 sources, 3 shape parameters with 5 anchors each (125
+anchor models), 100x100x100 analysis bins, one dataset; the anchor tensor (4.0 GB fp64) and the counts
+are resident in HBM before the timed region.  One STEP = one full likelihood evaluation at a fresh
+parameter point: the morph+reduce kernel streams the 2^3 * 4 corner templates of the point's grid cell
+plus the counts (264 MB) and reduces to a scalar.  Successive steps use different
+random points (a pool of 64 spread over the 64 grid cells), so no step finds its templates in the
+256 MiB Infinity Cache -- the number is an HBM-streaming number.
+
+With N > 1 ranks (launched by torch.distributed.run, one process per GPU) every rank holds a replica of
+the tensor and evaluates its own K points (weak scaling, no data-path collective); the per-rank result
+vectors are gathered once at the end with RCCL (all_gather), inside the timed region.
+
+The JSON line also carries
+  roofline      morph+reduce kernel: algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s
+  cpu_baseline  the numpy/scipy oracle (the reference's arithmetic) timed on the host, rank 0, N = 1
+  extras        other call shapes of the same path (same-cell repeat, scan batch, toy-MC, call latency)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+POOL = 64
+
+
+def cpu_baseline(model, counts, points, budget_s=20.0):
+    """Time the oracle (numpy/scipy restatement of the reference path) on this host, one thread."""
+    from oracle import blueice_oracle as orc
+    z, r = points
+    cm = model.cell_model(z[0])
+    c = counts
+    orc.loglikelihood(cm, c, z[0], r[0])            # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.loglikelihood(cm, c, z[0], r[0])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    return dict(value=n / dt, unit='evals/s', cores=1, kind='port',
+                sample='%d single-thread evaluations of the C2 model at one off-grid point (%.1f s); '
+                       'numpy %s oracle = the reference arithmetic' % (n, dt, np.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--config', default='C2')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+
+    K, W = args.steps, args.warmup
+    model = SyntheticModel.named(args.config)
+    ctx = DeviceContext(local_rank)
+    info = ctx.info()
+    model.upload(ctx)
+    counts = model.counts()
+    ctx.upload_counts(counts)
+
+    # a pool of plans: host-side preparation done, descriptors resident on the device
+    z, r = model.random_points(POOL, seed=100 + rank)
+    plans = [ctx.plan(z[i], r[i]) for i in range(POOL)]
+    bytes_per_launch = plans[0].bytes
+
+    if world > 1:
+        out = torch.empty(K, dtype=torch.float64, device='cuda')
+        gathered = [torch.empty(K, dtype=torch.float64, device='cuda') for _ in range(world)]
+        out_ptr = out.data_ptr()
+    else:
+        out_dev = None
+
+    def barrier():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_steps(n, base=0):
+        if world > 1:
+            for i in range(n):
+                plans[i % POOL].run(out_ptr + 8 * ((base + i) % K))
+        else:
+            for i in range(n):
+                plans[i % POOL].run()
+
+    run_steps(W)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(K)
+    ctx.sync()
+    if world > 1:
+        dist.all_gather(gathered, out)         # the final gather: the only collective (RCCL over xGMI)
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel time of the same steps, HIP events on the context stream around every launch
+    ctx.profile(True)
+    n_prof = min(K, 512)
+    run_steps(n_prof)
+    launches, ms = ctx.profile_read()
+    ctx.profile(False)
+    achieved = bytes_per_launch * launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        result = {
+            'metric': 'likelihood evals/sec (and GB/s vs HBM peak), 4-src 5^3-anchor 100^3-bin model',
+            'value': world * K / elapsed, 'unit': 'evals/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C2: 4 sources, 3 shape params (5^3 anchors), 100^3 bins, single dataset; '
+                                   'step = one dense evaluation at a fresh random point (%d-point pool over all '
+                                   'grid cells), tensor replicated per GPU' % POOL,
+                       'sources': model.S, 'anchors': list(model.n_anchor), 'bins': list(model.bins),
+                       'points_per_step': 1, 'device': info['arch']},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'k_morph_reduce<1,false>', 'bytes_per_launch': bytes_per_launch,
+                         'avg_launch_us': ms / max(launches, 1) * 1e3},
+        }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        ex = {}
+        p = ctx.plan(z[0], r[0])                           # same cell every call (a fit's access pattern)
+        for _ in range(50):
+            p.run()
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(1000):
+            p.run()
+        ctx.sync()
+        dt = (time.perf_counter() - t) / 1000
+        ex['same_cell_evals_per_s'] = 1 / dt
+        ex['same_cell_GBps'] = bytes_per_launch / dt / 1e9
+        p.close()
+        t = time.perf_counter()                            # full synchronous call incl. host planning + D2H
+        for i in range(200):
+            ctx.eval(z[i % POOL], r[i % POOL])
+        ex['sync_call_latency_us'] = (time.perf_counter() - t) / 200 * 1e6
+        zz, rr = model.random_points(16384, seed=7)        # scan batch: cell-grouped, templates reused
+        p = ctx.plan(zz, rr)
+        p.run()
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(3):
+            p.run()
+        ctx.sync()
+        ex['scan_batch_16384_evals_per_s'] = 3 * 16384 / (time.perf_counter() - t)
+        p.close()
+        T = 256                                            # toy-MC: one point, T datasets (fp64 counts)
+        ctx.upload_counts(np.stack([model.counts(dataset=i) for i in range(T)]))
+        ctx.eval_datasets(z[0], r[0])
+        ctx.profile(True)
+        ctx.eval_datasets(z[0], r[0])
+        _, tms = ctx.profile_read()
+        ctx.profile(False)
+        ex['toy_mc_256_evals_per_s_kernels'] = T / (tms * 1e-3)
+        ctx.upload_counts(counts)
+        result['extras'] = ex
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(model, counts, (z, r))
+        result['cpu_baseline']['host_cores_available'] = os.cpu_count()
+    elif rank == 0:
+        result['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    for p in plans:
+        p.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
