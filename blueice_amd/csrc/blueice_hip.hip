@@ -229,8 +229,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
 __global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ partial,
                                                      const unsigned* __restrict__ pflags, int nbx, int G, int lanes,
                                                      int64_t n_slots, const int64_t* __restrict__ perm,
-                                                     const int32_t* __restrict__ item_ds,
-                                                     const double* __restrict__ lgsum, double* __restrict__ out,
+                                                     const double* __restrict__ slot_lg, double* __restrict__ out,
                                                      int32_t* __restrict__ status) {
     __shared__ double sh[kThreads / 64];
     __shared__ unsigned shf[kThreads / 64];
@@ -241,6 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ 
     const int64_t item = live ? slot / G : 0;
     const int g = live ? (int)(slot % G) : 0;
     const int64_t p = live ? perm[slot] : -1;
+    const double lg = live ? slot_lg[slot] : 0.0;
     double s = 0.0;
     unsigned f = 0u;
     if (p >= 0) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ 
     f = wave_or(f);
     if (lanes == 64) {
         if ((threadIdx.x & 63) == 0 && p >= 0) {
-            out[p] = s - lgsum[item_ds[item]];
+            out[p] = s - lg;
             if (status) status[p] |= (int32_t)f;
         }
         return;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ 
         double t = sh[0];
         unsigned ff = shf[0];
         for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; ff |= shf[w]; }
-        out[p] = t - lgsum[item_ds[item]];
+        out[p] = t - lg;
         if (status) status[p] |= (int32_t)ff;
     }
 }
@@ -476,7 +476,7 @@ struct bi_plan {
         int G = 0;
         int64_t n_items = 0;
         int nbx = 0;
-        DevBuf rowoff, coef, aux, item_ds, perm, partial, pflags;
+        DevBuf rowoff, coef, aux, item_ds, perm, slot_lg, partial, pflags;
     };
     std::vector<Class> classes;
     DevBuf bad_idx;            // points answered on the host side with -inf
@@ -512,6 +512,7 @@ struct bi_ctx {
     bool data_ready = false;
     int64_t T = 0;
     DevBuf counts, lgsum;
+    std::vector<double> h_lgsum;
 
     // scratch
     DevBuf scratch, scratch2, logmu;
@@ -577,7 +578,7 @@ int dev_upload(bi_ctx* c, DevBuf& b, const std::vector<T>& h) {
 void free_plan_buffers(bi_plan* p) {
     for (auto& k : p->classes) {
         dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_ds);
-        dev_free(k.perm); dev_free(k.partial); dev_free(k.pflags);
+        dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
     }
     dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status);
 }
@@ -948,6 +949,8 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
                            (const double*)c->scratch.p, nblk, (double*)c->lgsum.p + t0, n);
     }
     HIP_TRY(c, hipGetLastError());
+    c->h_lgsum.assign((size_t)T, 0.0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->T = T;
     c->data_ready = true;
@@ -1011,7 +1014,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
 
     // chop every (cell, dataset) group into items of the available G classes
     const int classG[5] = {1, 2, 4, 8, 16};
-    struct HostClass { std::vector<int64_t> rowoff; std::vector<double> coef, aux; std::vector<int32_t> ds; std::vector<int64_t> perm; };
+    struct HostClass { std::vector<int64_t> rowoff; std::vector<double> coef, aux, slot_lg; std::vector<int32_t> ds; std::vector<int64_t> perm; };
     HostClass hc[5];
     const int maxg = (int)c->max_group;
     size_t i = 0;
@@ -1049,6 +1052,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             const size_t po = h.perm.size();
             h.perm.resize(po + G, -1);
             h.ds.push_back((int32_t)(pts[i].key % c->T));
+            h.slot_lg.resize(po + G, c->h_lgsum[(size_t)(pts[i].key % c->T)]);
             for (int g = 0; g < take; ++g) {
                 const int64_t p = pts[i + g].idx;
                 const PointGeom& pg = geom[(size_t)p];
@@ -1095,7 +1099,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
         k.nbx = (int)nbx;
         if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
             (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_ds, h.ds)) ||
-            (rc = dev_upload(c, k.perm, h.perm)) ||
+            (rc = dev_upload(c, k.perm, h.perm)) || (rc = dev_upload(c, k.slot_lg, h.slot_lg)) ||
             (rc = dev_alloc(c, k.partial, (size_t)k.n_items * k.nbx * k.G * sizeof(double))) ||
             (rc = dev_alloc(c, k.pflags, (size_t)k.n_items * k.nbx * k.G * sizeof(unsigned)))) {
             plan->classes.push_back(k);
@@ -1152,7 +1156,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             const int per_block = kThreads / lanes;
             hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0,
                                c->stream, (const double*)b.partial, (const unsigned*)b.pflags, k.nbx, k.G, lanes, n_slots,
-                               (const int64_t*)k.perm.p + i0 * k.G, b.item_ds, (const double*)c->lgsum.p, out,
+                               (const int64_t*)k.perm.p + i0 * k.G, (const double*)k.slot_lg.p + i0 * k.G, out,
                                (int32_t*)plan->status.p);
         }
     }

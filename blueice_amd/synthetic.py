@@ -103,6 +103,35 @@ class SyntheticModel:
         r = rng.uniform(0.5, 1.5, size=(P, self.S))
         return z, r
 
+    def stratified_points(self, seed=0):
+        """One random point strictly inside every grid cell -> (z [n_cells, d], r [n_cells, S])."""
+        rng = np.random.default_rng([self.seed, 5, int(seed)])
+        cells = list(itertools.product(*[range(max(len(g) - 1, 1)) for g in self.anchor_z]))
+        z = np.empty((len(cells), self.d))
+        for j, cell in enumerate(cells):
+            for i, (g, k) in enumerate(zip(self.anchor_z, cell)):
+                z[j, i] = g[k] + rng.uniform(0.05, 0.95) * (g[k + 1] - g[k]) if len(g) > 1 else g[0]
+        r = rng.uniform(0.5, 1.5, size=(len(cells), self.S))
+        return z, r
+
+    def disjoint_cell_points(self, parity=0, seed=0):
+        """One random point in each cell of a set of grid cells that share NO anchor model with each
+        other (per axis cells 0, 2, .. or 1, 3, .. chosen by the bits of `parity`), so a batch of them
+        re-uses no template bytes between evaluations.  -> (z [n, d], r [n, S])."""
+        rng = np.random.default_rng([self.seed, 6, int(seed), int(parity)])
+        per_axis = []
+        for i, g in enumerate(self.anchor_z):
+            n_cells = max(len(g) - 1, 1)
+            start = (parity >> i) & 1 if n_cells > 1 else 0
+            per_axis.append(list(range(start, n_cells, 2)) or [0])
+        cells = list(itertools.product(*per_axis))
+        z = np.empty((len(cells), self.d))
+        for j, cell in enumerate(cells):
+            for i, (g, k) in enumerate(zip(self.anchor_z, cell)):
+                z[j, i] = g[k] + rng.uniform(0.05, 0.95) * (g[k + 1] - g[k]) if len(g) > 1 else g[0]
+        r = rng.uniform(0.5, 1.5, size=(len(cells), self.S))
+        return z, r
+
     # -- consumers -------------------------------------------------------------------------
     def upload(self, ctx):
         """Stream the model to a DeviceContext one anchor at a time (pdf_morphers.py:62-65 loop)."""
