@@ -144,6 +144,17 @@ def main():
     ctx.profile(False)
     achieved = bytes_per_launch * launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
+    # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from the
+    # committed summary of the same command (profiles/), corrected as MI355X_MICROARCH.md prescribes
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            pm = json.load(f)
+        if args.config == 'C2' and pm.get('algorithmic_bytes_per_launch') == bytes_per_launch:
+            traffic = pm['traffic_bytes_per_launch']
+    except Exception:
+        traffic = None
+
     result = None
     if rank == 0:
         result = {
@@ -157,7 +168,9 @@ def main():
                        'sources': model.S, 'anchors': list(model.n_anchor), 'bins': list(model.bins),
                        'evals_per_step': PPS, 'device': info['arch']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                           'bytes per launch)' if traffic else None,
                          'kernel': 'k_morph_reduce<1,false>', 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_us': ms / max(launches, 1) * 1e3},
         }
