@@ -1,0 +1,113 @@
+"""The N > 1 path on CPU: two gloo ranks shard a scan / a toy-MC batch, evaluate their share (with the
+CPU oracle standing in for the device -- tests may use it as the checker) and gather; the result must
+equal the single-process evaluation, and the dealing must keep cells together and balanced."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_range_covers_everything():
+    from blueice_amd.sharding import split_range
+    for n in (0, 1, 7, 8, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [split_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_deal_points_by_cell_balanced_and_cell_local():
+    from blueice_amd.sharding import cell_ids, deal_points_by_cell
+    rng = np.random.default_rng(0)
+    grid = [np.array([-2., -1., 0., 1., 2.])] * 3
+    z = rng.uniform(-2, 2, size=(5000, 3))
+    z[:5] = [[2, 2, 2], [-2, -2, -2], [0, 0, 0], [3, 0, 0], [np.nan, 0, 0]]
+    ids = cell_ids(grid, z)
+    assert ids[0] == 63 and ids[1] == 0 and ids[3] == -1 and ids[4] == -1
+    for world in (1, 2, 8):
+        deal = deal_points_by_cell(grid, z, world)
+        allidx = np.sort(np.concatenate(deal))
+        np.testing.assert_array_equal(allidx, np.arange(len(z)))
+        sizes = [len(d) for d in deal]
+        assert max(sizes) - min(sizes) <= 0.05 * len(z) / world + 1
+        # a cell is split over at most 2 ranks here (groups are far smaller than the fair share)
+        owners = {}
+        for r, d in enumerate(deal):
+            for c in np.unique(ids[d]):
+                owners.setdefault(int(c), set()).add(r)
+        assert max(len(v) for v in owners.values()) <= 2
+    one = deal_points_by_cell(grid, np.tile([[0.5, 0.5, 0.5]], (100, 1)), 4)    # one hot cell is split
+    assert sorted(len(d) for d in one) == [25, 25, 25, 25]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from blueice_amd.sharding import sharded_eval_points, sharded_eval_toys
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        m = SyntheticModel.named('mini3')
+        dense = m.dense_model()
+        counts = m.counts(dense=True)
+        z, r = m.random_points(37, seed=2)
+        calls = []
+
+        def eval_fn(zz, rr):
+            calls.append(len(zz))
+            return orc.loglikelihood_batch(dense, counts, zz, rr)
+
+        ll = sharded_eval_points(eval_fn, m.anchor_z, z, r, dist)
+        toys = np.stack([m.counts(dense=True, dataset=t) for t in range(5)])
+        z0, r0 = m.default_point()
+        lt = sharded_eval_toys(lambda a, b: orc.loglikelihood_batch(dense, toys, np.tile(z0, (b - a, 1)),
+                                                                     np.tile(r0, (b - a, 1)), dataset=np.arange(a, b)),
+                               5, dist)
+        q.put((rank, ll, lt, sum(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_equal_single_process():
+    import torch.multiprocessing as mp
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = SyntheticModel.named('mini3')
+    dense, counts = m.dense_model(), m.counts(dense=True)
+    z, r = m.random_points(37, seed=2)
+    want = orc.loglikelihood_batch(dense, counts, z, r)
+    toys = np.stack([m.counts(dense=True, dataset=t) for t in range(5)])
+    z0, r0 = m.default_point()
+    want_t = orc.loglikelihood_batch(dense, toys, np.tile(z0, (5, 1)), np.tile(r0, (5, 1)), dataset=np.arange(5))
+    assert sorted(g[0] for g in got) == [0, 1]
+    for rank, ll, lt, n_eval in got:
+        np.testing.assert_array_equal(ll, want)            # every rank holds the full gathered vector
+        np.testing.assert_array_equal(lt, want_t)
+        assert 17 <= n_eval <= 20                          # each rank evaluated about half of the 37 points

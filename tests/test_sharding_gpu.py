@@ -1,0 +1,74 @@
+"""Two ranks on the GPU box (both on device 0, gloo for the gather -- the box has one GPU): the sharded
+scan through the real HIP path equals the single-process device result and the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.sharding import sharded_eval_points, sharded_eval_toys
+    from blueice_amd.synthetic import SyntheticModel
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        m = SyntheticModel.named('mini3')
+        ctx = DeviceContext(0)
+        m.upload(ctx)
+        ctx.upload_counts(m.counts(dense=True))
+        z, r = m.random_points(301, seed=4)
+        ll = sharded_eval_points(lambda zz, rr: ctx.eval(zz, rr)[0], m.anchor_z, z, r, dist)
+        toys = np.stack([m.counts(dense=True, dataset=t) for t in range(9)])
+        ctx.upload_counts(toys)          # every rank holds all toys here; it evaluates only its range
+        z0, r0 = m.default_point()
+        lt = sharded_eval_toys(lambda a, b: ctx.eval_datasets(z0, r0, a, b)[0], 9, dist)
+        ctx.close()
+        q.put((rank, ll, lt))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_gpu_equal_single_process():
+    import torch.multiprocessing as mp
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    counts = m.counts(dense=True)
+    ctx.upload_counts(counts)
+    z, r = m.random_points(301, seed=4)
+    single = ctx.eval(z, r)[0]
+    dense = m.dense_model()
+    want = orc.loglikelihood_batch(dense, counts, z[:12], r[:12])
+    toys = np.stack([m.counts(dense=True, dataset=t) for t in range(9)])
+    ctx.upload_counts(toys)
+    z0, r0 = m.default_point()
+    single_t = ctx.eval_datasets(z0, r0)[0]
+    ctx.close()
+    for rank, ll, lt in got:
+        np.testing.assert_allclose(ll, single, rtol=1e-13)
+        np.testing.assert_allclose(ll[:12], want, rtol=1e-10)
+        np.testing.assert_allclose(lt, single_t, rtol=1e-13)
