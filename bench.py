@@ -91,6 +91,7 @@ def main():
     info = ctx.info()
     model.upload(ctx)
     counts = model.counts()
+    ctx.set_param('sparse', 0)          # headline = the dense kernel: every evaluation visits every bin
     ctx.upload_counts(counts)
 
     # a pool of plans: host-side preparation done, descriptors resident on the device
@@ -227,13 +228,35 @@ def main():
         ex['scan_batch_16384_evals_per_s'] = 3 * 16384 / (time.perf_counter() - t)
         p.close()
         T = 256                                            # toy-MC: one point, T datasets (fp64 counts)
-        ctx.upload_counts(np.stack([model.counts(dataset=i) for i in range(T)]))
-        ctx.eval_datasets(z[0], r[0])
-        ctx.profile(True)
-        ctx.eval_datasets(z[0], r[0])
-        _, tms = ctx.profile_read()
-        ctx.profile(False)
-        ex['toy_mc_256_evals_per_s_kernels'] = T / (tms * 1e-3)
+        toys = np.stack([model.counts(dataset=i) for i in range(T)])
+        for mode, key in ((0, 'toy_mc_256_dense_counts_evals_per_s_kernels'), (1, 'toy_mc_256_csr_evals_per_s_kernels')):
+            ctx.set_param('sparse', mode)
+            ctx.upload_counts(toys)
+            ctx.eval_datasets(z[0], r[0])
+            ctx.profile(True)
+            ctx.eval_datasets(z[0], r[0])
+            _, tms = ctx.profile_read()
+            ctx.profile(False)
+            ex[key] = T / (tms * 1e-3)
+        # non-empty-bin form (exact: templates >= 0): only the ~1e4 bins with data are visited per evaluation
+        ctx.set_param('sparse', 1)
+        ctx.upload_counts(counts)
+        zz, rr = model.random_points(131072, seed=11)
+        t = time.perf_counter()
+        p = ctx.plan(zz, rr)
+        t_plan = time.perf_counter() - t
+        p.run()
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(3):
+            p.run()
+        ctx.sync()
+        dt = (time.perf_counter() - t) / 3
+        ex['sparse_scan_131072_evals_per_s_device'] = len(zz) / dt
+        ex['sparse_scan_131072_evals_per_s_incl_host_planning'] = len(zz) / (dt + t_plan)
+        ex['sparse_nonempty_bins'] = ctx.get_param('nnz_total')
+        p.close()
+        ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
         result['extras'] = ex
 

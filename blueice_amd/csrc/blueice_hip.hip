@@ -106,7 +106,8 @@ struct LaunchArgs {
     const int64_t* rowoff;  // [items][NS]  element offsets of the stream rows
     const double* coef;     // [items][NS][G]
     const double* aux;      // [items][G][2]  (p_cal, N) for BB
-    const int32_t* item_ds; // [items] dataset index
+    const int64_t* item_cnt; // [items] element offset of the item's counts row
+    const int32_t* item_tiles; // [items] 512-bin tiles of the item's rows (NULL: n_tiles)
     double* partial;        // [items][nbx][G]
     unsigned* pflags;       // [items][nbx][G]
     int64_t B, Bp;
@@ -122,14 +123,15 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
     const int NS = a.n0 + a.n1 + a.n2;
     const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
     const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
-    const double* __restrict__ cnt = a.counts + (int64_t)a.item_ds[item] * a.Bp;
+    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
+    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
 
     double sum[G];
     unsigned flg[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
         double acc[G][2];
 #pragma unroll
@@ -380,6 +382,132 @@ __global__ void k_bb_normalise(const double* __restrict__ aw, const double* __re
     if (b < B) row[b] = aw[b] / tot[0];
 }
 
+// per padded row: sum over bins, minimum, and a "has non-finite" flag -> out[row*3 + {0,1,2}]
+__global__ __launch_bounds__(kThreads) void k_row_stats(const double* __restrict__ rows, int64_t B, int64_t Bp,
+                                                        double* __restrict__ out) {
+    const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
+    double s = 0.0, mn = __builtin_inf(), bad = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += kThreads) {
+        const double v = r[b];
+        s += v;
+        mn = fmin(mn, v);
+        if (!(fabs(v) < __builtin_inf())) bad = 1.0;
+    }
+    __shared__ double sh[3][kThreads / 64];
+    s = wave_sum(s);
+    bad = wave_sum(bad);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = mn; sh[2][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0][0], m = sh[1][0], f = sh[2][0];
+        for (int w = 1; w < kThreads / 64; ++w) { t += sh[0][w]; m = fmin(m, sh[1][w]); f += sh[2][w]; }
+        out[(int64_t)blockIdx.x * 3 + 0] = t;
+        out[(int64_t)blockIdx.x * 3 + 1] = m;
+        out[(int64_t)blockIdx.x * 3 + 2] = f;
+    }
+}
+
+// ---- non-empty-bin lists (CSR) of the datasets, built in bin order (deterministic) -----------
+constexpr int kNzPerThread = 8;
+constexpr int kNzChunk = kThreads * kNzPerThread;  // 2048 bins per block
+
+__device__ __forceinline__ bool is_nz(double n) { return n != 0.0; }  // true for nan as well
+
+__global__ __launch_bounds__(kThreads) void k_nz_count(const double* __restrict__ counts, int64_t B, int64_t Bp,
+                                                       int32_t* __restrict__ cnt, int nchunks) {
+    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (b0 + j < B && is_nz(c[b0 + j])) ++k;
+    __shared__ int sh[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(kThreads) void k_nz_scatter(const double* __restrict__ counts, int64_t B, int64_t Bp,
+                                                         const int64_t* __restrict__ chunk_off, int nchunks,
+                                                         int32_t* __restrict__ nz_idx, double* __restrict__ nz_n) {
+    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    double v[kNzPerThread];
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j) {
+        v[j] = (b0 + j < B) ? c[b0 + j] : 0.0;
+        if (is_nz(v[j])) ++k;
+    }
+    // exclusive prefix of k over the block, in thread order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __shared__ int sh[kThreads / 64];
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (is_nz(v[j])) {
+            nz_idx[pos] = (int32_t)(b0 + j);
+            nz_n[pos] = v[j];
+            ++pos;
+        }
+}
+
+// compacted templates of one dataset: out[row][j] = rows[row][idx[j]] (0 beyond nnz)
+__global__ __launch_bounds__(kThreads) void k_gather_rows(const double* __restrict__ rows, int64_t Bp,
+                                                          const int32_t* __restrict__ idx, int64_t nnz, int64_t np,
+                                                          double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (j >= np) return;
+    const int64_t row = blockIdx.y;
+    out[row * np + j] = j < nnz ? rows[row * Bp + idx[j]] : 0.0;
+}
+
+__global__ void k_pad_copy(const double* __restrict__ src, int64_t n, int64_t np, double* __restrict__ dst) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < np) dst[j] = j < n ? src[j] : 0.0;
+}
+
+// toy-MC, CSR form: for dataset t: sum_j xlogy(n_j, mu[idx_j]); one block per dataset
+__global__ __launch_bounds__(kThreads) void k_dataset_dot_csr(const int32_t* __restrict__ nz_idx,
+                                                              const double* __restrict__ nz_n,
+                                                              const int64_t* __restrict__ nz_off,
+                                                              const double* __restrict__ logmu, int64_t t0,
+                                                              double* __restrict__ partial) {
+    const int64_t t = t0 + blockIdx.x;
+    const int64_t lo = nz_off[t], hi = nz_off[t + 1];
+    double s = 0.0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += kThreads) {
+        const double n = nz_n[j];
+        double term = n * logmu[nz_idx[j]];
+        if (n != n) term = __builtin_nan("");
+        else if (n < 0.0 || n != floor(n)) term = -__builtin_inf();
+        s += term;
+    }
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) r += sh[w];
+        partial[blockIdx.x] = r;
+    }
+}
+
 // ---- toy-MC form: one parameter point, many datasets --------------------------------------
 // pass 1: mu_b -> logmu[b] (log mu, or -inf for mu == 0, or nan for invalid mu), partial sum mu
 __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu) {
@@ -476,13 +604,15 @@ struct bi_plan {
         int G = 0;
         int64_t n_items = 0;
         int nbx = 0;
-        DevBuf rowoff, coef, aux, item_ds, perm, slot_lg, partial, pflags;
+        DevBuf rowoff, coef, aux, item_cnt, item_tiles, perm, slot_lg, partial, pflags;
     };
     std::vector<Class> classes;
     DevBuf bad_idx;            // points answered on the host side with -inf
     int64_t n_bad = 0;
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
+    int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
     int64_t bytes = 0;         // algorithmic HBM bytes per run
     int64_t launches = 0;
 };
@@ -514,12 +644,28 @@ struct bi_ctx {
     DevBuf counts, lgsum;
     std::vector<double> h_lgsum;
 
+    // model statistics (for the sparse forms)
+    std::vector<double> h_rowsum;  // [A*S] sum over bins of every ps row
+    bool ps_nonneg = false;        // every ps entry is finite and >= 0
+
+    // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
+    bool csr_ready = false, compact_ready = false;
+    DevBuf nz_idx, nz_n, nz_off, ps_c, cnt_c;
+    std::vector<int64_t> h_nz_off;            // [T+1]
+    std::vector<int64_t> h_c_off, h_cnt_off;  // [T] element offsets into ps_c / cnt_c
+    std::vector<int64_t> h_c_np;              // [T] padded non-empty bins per dataset
+    std::vector<double> h_Tz;                 // [T][A*S] sum of every ps row over the EMPTY bins of the dataset
+
     // scratch
     DevBuf scratch, scratch2, logmu;
+
+    int64_t epoch = 0;  // bumped by every model / data upload
 
     // tunables
     int64_t blocks_per_cu = 8;
     int64_t max_group = kMaxG;
+    int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent
+    int64_t compact_budget = (int64_t)16 << 30;  // bytes of HBM the compacted templates may take
 
     // profiling
     bool profiling = false;
@@ -577,7 +723,7 @@ int dev_upload(bi_ctx* c, DevBuf& b, const std::vector<T>& h) {
 
 void free_plan_buffers(bi_plan* p) {
     for (auto& k : p->classes) {
-        dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_ds);
+        dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
     }
     dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status);
@@ -726,6 +872,99 @@ int check_ready(bi_ctx* c, bool need_data) {
 
 int n_tiles_of(const bi_ctx* c) { return (int)(c->Bp / kTile); }
 
+// CSR lists of the non-empty bins of every dataset (always, unless the data are dense), and -- when the
+// templates are non-negative and the budget allows -- per-dataset compacted copies of all template rows,
+// so that an evaluation only touches non-empty bins:
+//   sum_b [n log mu - mu - lgamma(n+1)] = sum_{b: n_b != 0} [n log mu - mu] - sum_k coef_k Tz_k - sum lgamma
+// with Tz_k = sum of row k over the EMPTY bins.  Exact (to rounding) because mu_b >= 0 is then guaranteed,
+// so the only per-bin terms that are not linear in the templates are those of the non-empty bins.
+int build_sparse_forms(bi_ctx* c) {
+    c->csr_ready = c->compact_ready = false;
+    const int64_t T = c->T, B = c->B, Bp = c->Bp;
+    const int nchunks = (int)((B + kNzChunk - 1) / kNzChunk);
+    int rc;
+    DevBuf d_cnt, d_off;
+    auto cleanup = [&]() { dev_free(d_cnt); dev_free(d_off); };
+    if ((rc = dev_alloc(c, d_cnt, (size_t)T * nchunks * sizeof(int32_t)))) return rc;
+    const int64_t tchunk = 32768;
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+        const int64_t n = std::min(tchunk, T - t0);
+        hipLaunchKernelGGL(k_nz_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream,
+                           (const double*)c->counts.p + t0 * Bp, B, Bp, (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
+    }
+    std::vector<int32_t> h_cnt((size_t)T * nchunks);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt.p, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, BI_ERR_HIP, "non-empty-bin count: %s", hipGetErrorString(e)); }
+    std::vector<int64_t> h_off(h_cnt.size());
+    c->h_nz_off.assign((size_t)T + 1, 0);
+    int64_t run = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        c->h_nz_off[(size_t)t] = run;
+        for (int k = 0; k < nchunks; ++k) { h_off[(size_t)t * nchunks + k] = run; run += h_cnt[(size_t)t * nchunks + k]; }
+    }
+    c->h_nz_off[(size_t)T] = run;
+    if (c->sparse == 0 || (c->sparse == 1 && run > T * B / 4)) { cleanup(); return BI_OK; }  // dense data: dense forms
+    if ((rc = dev_upload(c, d_off, h_off)) || (rc = dev_alloc(c, c->nz_idx, (size_t)std::max<int64_t>(run, 1) * sizeof(int32_t))) ||
+        (rc = dev_alloc(c, c->nz_n, (size_t)std::max<int64_t>(run, 1) * sizeof(double))) || (rc = dev_upload(c, c->nz_off, c->h_nz_off))) {
+        cleanup();
+        return rc;
+    }
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+        const int64_t n = std::min(tchunk, T - t0);
+        hipLaunchKernelGGL(k_nz_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream,
+                           (const double*)c->counts.p + t0 * Bp, B, Bp, (const int64_t*)d_off.p + t0 * nchunks, nchunks,
+                           (int32_t*)c->nz_idx.p, (double*)c->nz_n.p);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "non-empty-bin scatter: %s", hipGetErrorString(e));
+    c->csr_ready = true;
+
+    // compacted templates per dataset
+    if (!c->ps_nonneg || c->bb_source >= 0) return BI_OK;
+    const int64_t rows = c->A * c->S;
+    c->h_c_np.assign((size_t)T, 0);
+    c->h_c_off.assign((size_t)T, 0);
+    c->h_cnt_off.assign((size_t)T, 0);
+    int64_t tot_ps = 0, tot_cnt = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t nnz = c->h_nz_off[(size_t)t + 1] - c->h_nz_off[(size_t)t];
+        const int64_t np = std::max<int64_t>(kTile, (nnz + kTile - 1) / kTile * kTile);
+        c->h_c_np[(size_t)t] = np;
+        c->h_c_off[(size_t)t] = tot_ps;
+        c->h_cnt_off[(size_t)t] = tot_cnt;
+        tot_ps += rows * np;
+        tot_cnt += np;
+    }
+    if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
+    if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
+        (rc = dev_alloc(c, c->scratch, (size_t)rows * sizeof(double))))
+        return rc;
+    c->h_Tz.assign((size_t)T * rows, 0.0);
+    std::vector<double> tnz((size_t)rows);
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo, np = c->h_c_np[(size_t)t];
+        double* dst = (double*)c->ps_c.p + c->h_c_off[(size_t)t];
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((np + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0,
+                           c->stream, (const double*)c->ps.p, Bp, (const int32_t*)c->nz_idx.p + lo, nnz, np, dst);
+        hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)c->nz_n.p + lo, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
+        hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
+                           (double*)c->scratch.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
+        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
+    }
+    c->compact_ready = true;
+    return BI_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -761,6 +1000,7 @@ void bi_destroy(bi_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
+    dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -791,6 +1031,12 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
         c->max_group = v;
         return BI_OK;
     }
+    if (!strcmp(name, "sparse")) {
+        if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "sparse: 0 = off, 1 = auto, 2 = whenever exact");
+        c->sparse = v;
+        return BI_OK;
+    }
+    if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
     return fail(c, BI_ERR_INVALID, "unknown parameter %s", name);
 }
 
@@ -800,6 +1046,12 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "max_group")) return c->max_group;
     if (!strcmp(name, "tile_bins")) return kTile;
     if (!strcmp(name, "padded_bins")) return c->Bp;
+    if (!strcmp(name, "sparse")) return c->sparse;
+    if (!strcmp(name, "compact_budget")) return c->compact_budget;
+    if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
+    if (!strcmp(name, "compact_ready")) return c->compact_ready ? 1 : 0;
+    if (!strcmp(name, "ps_nonneg")) return c->ps_nonneg ? 1 : 0;
+    if (!strcmp(name, "nnz_total")) return c->csr_ready ? c->h_nz_off.back() : -1;
     return -1;
 }
 
@@ -815,6 +1067,7 @@ int bi_model_begin(bi_ctx* c, int d, const int32_t* n_anchor, const double* anch
     if (d > 0 && (!n_anchor || !anchor_z)) return fail(c, BI_ERR_INVALID, "anchor arrays are NULL");
     c->model_ready = false;
     c->data_ready = false;  // a new model invalidates the data (likelihood.py:253)
+    ++c->epoch;
     c->d = d; c->S = S; c->B = B; c->bb_source = bb_source;
     c->Bp = (B + kTile - 1) / kTile * kTile;
     c->n_anchor.assign(d, 0);
@@ -887,6 +1140,24 @@ int bi_model_end(bi_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->h_nm_tot.data(), c->nm_tot.p, (size_t)c->A * sizeof(double), hipMemcpyDeviceToHost,
                                   c->stream));
     }
+    {
+        // row sums T_k and non-negativity of the templates: preconditions / constants of the sparse forms
+        const int64_t rows = c->A * c->S;
+        int rc = dev_alloc(c, c->scratch, (size_t)rows * 3 * sizeof(double));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_row_stats, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->B,
+                           c->Bp, (double*)c->scratch.p);
+        HIP_TRY(c, hipGetLastError());
+        std::vector<double> st((size_t)rows * 3);
+        HIP_TRY(c, hipMemcpyAsync(st.data(), c->scratch.p, st.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->h_rowsum.assign((size_t)rows, 0.0);
+        c->ps_nonneg = true;
+        for (int64_t r = 0; r < rows; ++r) {
+            c->h_rowsum[(size_t)r] = st[(size_t)r * 3];
+            if (!(st[(size_t)r * 3 + 1] >= 0.0) || st[(size_t)r * 3 + 2] != 0.0) c->ps_nonneg = false;
+        }
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->model_open = false;
     c->model_ready = true;
@@ -931,6 +1202,7 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
     if (T < 1 || !counts) return fail(c, BI_ERR_INVALID, "need T >= 1 datasets and a counts pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     c->data_ready = false;
+    ++c->epoch;
     const size_t bytes = (size_t)T * c->Bp * sizeof(double);
     if ((rc = dev_alloc(c, c->counts, bytes))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->counts.p, 0, bytes, c->stream));
@@ -953,6 +1225,7 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
     HIP_TRY(c, hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->T = T;
+    if ((rc = build_sparse_forms(c))) return rc;
     c->data_ready = true;
     return BI_OK;
 }
@@ -986,8 +1259,15 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     const int n1 = bb ? nc : 0, n2 = bb ? nc : 0;
     const int NS = n0 + n1 + n2;
 
+    bool any_neg = false;
+    for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
+    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg;
+    const int64_t n_rows = c->A * S;
+
     bi_plan* plan = new bi_plan();
     plan->P = P;
+    plan->sparse = sparse;
+    plan->epoch = c->epoch;
     plan->h_status.assign((size_t)P, 0);
 
     struct Pt { int64_t key; int64_t idx; };
@@ -1014,7 +1294,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
 
     // chop every (cell, dataset) group into items of the available G classes
     const int classG[5] = {1, 2, 4, 8, 16};
-    struct HostClass { std::vector<int64_t> rowoff; std::vector<double> coef, aux, slot_lg; std::vector<int32_t> ds; std::vector<int64_t> perm; };
+    struct HostClass { std::vector<int64_t> rowoff, cnt_off; std::vector<double> coef, aux, slot_lg; std::vector<int32_t> tiles; std::vector<int64_t> perm; int64_t bytes = 0; };
     HostClass hc[5];
     const int maxg = (int)c->max_group;
     size_t i = 0;
@@ -1032,6 +1312,9 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             HostClass& h = hc[ci];
             const int64_t p0 = pts[i].idx;
             const int64_t cell = geom[(size_t)p0].cell_anchor;
+            const int64_t ds = pts[i].key % c->T;
+            const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
+            const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
             const size_t ro = h.rowoff.size();
             h.rowoff.resize(ro + NS);
             // stream rows: [n0] (corner, source != bb) ; [n1] (corner, bb source) ; [n2] n_model corner rows
@@ -1039,7 +1322,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             for (int corner = 0; corner < nc; ++corner)
                 for (int s = 0; s < S; ++s) {
                     if (bb && s == c->bb_source) continue;
-                    h.rowoff[ro + k0++] = ((cell + corner_off[(size_t)corner]) * S + s) * c->Bp;
+                    h.rowoff[ro + k0++] = row_base + ((cell + corner_off[(size_t)corner]) * S + s) * row_stride;
                 }
             for (int corner = 0; corner < n1; ++corner)
                 h.rowoff[ro + n0 + corner] = ((cell + corner_off[(size_t)corner]) * S + c->bb_source) * c->Bp;
@@ -1051,8 +1334,10 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             h.aux.resize(ao + (size_t)G * 2, 1.0);
             const size_t po = h.perm.size();
             h.perm.resize(po + G, -1);
-            h.ds.push_back((int32_t)(pts[i].key % c->T));
-            h.slot_lg.resize(po + G, c->h_lgsum[(size_t)(pts[i].key % c->T)]);
+            h.cnt_off.push_back(sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp);
+            h.tiles.push_back((int32_t)(row_stride / kTile));
+            h.bytes += (int64_t)sizeof(double) * ((int64_t)NS + 1) * (sparse ? row_stride : c->B);
+            h.slot_lg.resize(po + G, c->h_lgsum[(size_t)ds]);
             for (int g = 0; g < take; ++g) {
                 const int64_t p = pts[i + g].idx;
                 const PointGeom& pg = geom[(size_t)p];
@@ -1075,6 +1360,17 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
                     h.aux[ao + (size_t)g * 2 + 1] = Ntot;
                 }
                 h.perm[po + g] = p;
+                if (sparse) {
+                    // minus sum_k coef_k * (sum of row k over the empty bins of this dataset)
+                    double zsum = 0.0;
+                    int kk = 0;
+                    for (int corner = 0; corner < nc; ++corner)
+                        for (int s = 0; s < S; ++s) {
+                            const int64_t row = (cell + corner_off[(size_t)corner]) * S + s;
+                            zsum += h.coef[co + (size_t)(kk++) * G + g] * c->h_Tz[(size_t)(ds * n_rows + row)];
+                        }
+                    h.slot_lg[po + g] += zsum;
+                }
             }
             i += take;
             n -= take;
@@ -1085,20 +1381,21 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     const int n_tiles = n_tiles_of(c);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     int64_t total_items = 0;
-    for (auto& h : hc) total_items += (int64_t)h.ds.size();
-    const int64_t bytes_per_pass = (int64_t)sizeof(double) * ((int64_t)NS + 1) * c->B;
+    for (auto& h : hc) total_items += (int64_t)h.tiles.size();
 
     for (int ci = 0; ci < 5; ++ci) {
         HostClass& h = hc[ci];
-        if (h.ds.empty()) continue;
+        if (h.tiles.empty()) continue;
         bi_plan::Class k;
         k.G = classG[ci];
-        k.n_items = (int64_t)h.ds.size();
-        int64_t nbx = std::min<int64_t>(n_tiles, std::max<int64_t>(1, (4 * slots + total_items - 1) / total_items));
-        if (total_items == 1) nbx = std::min<int64_t>(n_tiles, slots);
+        k.n_items = (int64_t)h.tiles.size();
+        const int64_t max_tiles = sparse ? *std::max_element(h.tiles.begin(), h.tiles.end()) : n_tiles;
+        int64_t nbx = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + total_items - 1) / total_items));
+        if (total_items == 1) nbx = std::min<int64_t>(max_tiles, slots);
         k.nbx = (int)nbx;
         if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
-            (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_ds, h.ds)) ||
+            (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_cnt, h.cnt_off)) ||
+            (rc = dev_upload(c, k.item_tiles, h.tiles)) ||
             (rc = dev_upload(c, k.perm, h.perm)) || (rc = dev_upload(c, k.slot_lg, h.slot_lg)) ||
             (rc = dev_alloc(c, k.partial, (size_t)k.n_items * k.nbx * k.G * sizeof(double))) ||
             (rc = dev_alloc(c, k.pflags, (size_t)k.n_items * k.nbx * k.G * sizeof(unsigned)))) {
@@ -1107,7 +1404,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             delete plan;
             return rc;
         }
-        plan->bytes += k.n_items * bytes_per_pass;
+        plan->bytes += h.bytes;
         plan->launches += (k.n_items + 65534) / 65535;
         plan->classes.push_back(k);
     }
@@ -1127,14 +1424,15 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!plan) return fail(c, BI_ERR_INVALID, "plan is NULL");
+    if (plan->epoch != c->epoch) return fail(c, BI_ERR_STATE, "plan is stale: model or data were uploaded after it was made");
     HIP_TRY(c, hipSetDevice(c->device));
     double* out = out_dev ? out_dev : (double*)plan->out.p;
     const bool bb = c->bb_source >= 0;
     const int nc = 1 << (int)c->eff_axes.size();
     LaunchArgs a{};
-    a.ps = (const double*)c->ps.p;
+    a.ps = plan->sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
     a.nm = (const double*)c->nm.p;
-    a.counts = (const double*)c->counts.p;
+    a.counts = plan->sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
     a.B = c->B; a.Bp = c->Bp;
     a.n0 = bb ? nc * (c->S - 1) : nc * c->S;
     a.n1 = bb ? nc : 0; a.n2 = bb ? nc : 0;
@@ -1147,7 +1445,8 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             b.rowoff = (const int64_t*)k.rowoff.p + i0 * NS;
             b.coef = (const double*)k.coef.p + i0 * NS * k.G;
             b.aux = (const double*)k.aux.p + i0 * k.G * 2;
-            b.item_ds = (const int32_t*)k.item_ds.p + i0;
+            b.item_cnt = (const int64_t*)k.item_cnt.p + i0;
+            b.item_tiles = (const int32_t*)k.item_tiles.p + i0;
             b.partial = (double*)k.partial.p + i0 * k.nbx * k.G;
             b.pflags = (unsigned*)k.pflags.p + i0 * k.nbx * k.G;
             launch_morph_g(c, k.G, b, dim3((unsigned)k.nbx, (unsigned)ni), bb);
@@ -1234,8 +1533,9 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int nmu = (int)std::min<int64_t>(n_tiles, slots);
     DevBuf d_row, d_coef, d_out;
     auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_out); };
-    const int64_t chunk = 16384;
-    const int nbx = (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, std::min(n, chunk))));
+    const bool csr = c->sparse && c->csr_ready;
+    const int64_t chunk = csr ? 1048576 : 16384;
+    const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, std::min(n, chunk))));
     if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
         (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
@@ -1259,9 +1559,14 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
         const int64_t ni = std::min(chunk, n - s0);
         {
             EventScope ev(c);
-            hipLaunchKernelGGL(k_dataset_dot, dim3((unsigned)nbx, (unsigned)ni), dim3(kThreads), 0, c->stream,
-                               (const double*)c->counts.p, (const double*)c->logmu.p, c->Bp, n_tiles, t0 + s0,
-                               (double*)c->scratch2.p);
+            if (csr)
+                hipLaunchKernelGGL(k_dataset_dot_csr, dim3((unsigned)ni), dim3(kThreads), 0, c->stream,
+                                   (const int32_t*)c->nz_idx.p, (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p,
+                                   (const double*)c->logmu.p, t0 + s0, (double*)c->scratch2.p);
+            else
+                hipLaunchKernelGGL(k_dataset_dot, dim3((unsigned)nbx, (unsigned)ni), dim3(kThreads), 0, c->stream,
+                                   (const double*)c->counts.p, (const double*)c->logmu.p, c->Bp, n_tiles, t0 + s0,
+                                   (double*)c->scratch2.p);
         }
         hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
                            (const double*)c->scratch2.p, nbx, (const double*)a.partial, (const unsigned*)a.pflags, nmu,

@@ -23,20 +23,27 @@ def test_c2_matches_oracle(c2):
     m, ctx = c2
     for dense in (False, True):
         counts = m.counts(dense=dense)
-        ctx.upload_counts(counts)
         z0, r0 = m.default_point()
         zs, rs = m.random_points(2, seed=3)
         pts = [(z0, r0), (zs[0], rs[0]), (np.array([-2., 2., 0.]), rs[1])]     # off-grid, random, on-anchor corner
-        for z, r in pts:
-            want = orc.loglikelihood(m.cell_model(z), counts, z, r)
-            got, st = ctx.eval(z, r)
-            assert st[0] == 0
-            assert abs(got[0] - want) <= 1e-10 * max(1.0, abs(want)), (dense, z, got[0], want)
+        want = [orc.loglikelihood(m.cell_model(z), counts, z, r) for z, r in pts]
+        for sparse in (0, 1):
+            ctx.set_param('sparse', sparse)
+            ctx.upload_counts(counts)
+            # ~1e4 events in 1e6 bins -> the non-empty-bin form is active; 10 events per bin -> it is not
+            assert ctx.get_param('compact_ready') == (1 if (sparse and not dense) else 0)
+            for (z, r), w in zip(pts, want):
+                got, st = ctx.eval(z, r)
+                assert st[0] == 0
+                assert abs(got[0] - w) <= 1e-10 * max(1.0, abs(w)), (dense, sparse, z, got[0], w)
+            toys, tst = ctx.eval_datasets(z0, r0)
+            assert abs(toys[0] - want[0]) <= 1e-10 * abs(want[0])
 
 
 def test_c2_properties(c2):
     m, ctx = c2
     counts = m.counts()
+    ctx.set_param('sparse', 0)
     ctx.upload_counts(counts)
     z, r = m.random_points(48, seed=9)
     single = np.array([ctx.eval(z[i], r[i])[0][0] for i in range(8)])
@@ -74,3 +81,16 @@ def test_c2_properties(c2):
     y, _ = ctx.eval(np.array(m.anchor_zs(a_idx)), r[0])
     assert abs(x[0] - y[0]) <= 1e-12 * abs(x[0])
     solo.close()
+    # non-empty-bin (sparse) form == dense form on the same batch, and the plan goes stale on re-upload
+    ctx.set_param('sparse', 1)
+    ctx.upload_counts(counts)
+    assert ctx.get_param('compact_ready') == 1
+    plan = ctx.plan(z, r)
+    assert plan.bytes < 0.05 * 48 * 264e6
+    plan.run()
+    sp, st = plan.read()
+    np.testing.assert_allclose(sp, batch, rtol=1e-12)
+    from blueice_amd.exceptions import NotPreparedException
+    ctx.upload_counts(counts)
+    with pytest.raises(NotPreparedException):
+        plan.run()

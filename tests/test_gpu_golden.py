@@ -27,11 +27,19 @@ def upload_case(ctx, c):
     ctx.upload_counts(c['counts'])
 
 
+@pytest.mark.parametrize('sparse', [0, 2])
 @pytest.mark.parametrize('name', case_names())
-def test_eval_matches_reference_goldens(ctx, name):
+def test_eval_matches_reference_goldens(ctx, name, sparse):
+    """sparse=0: every bin is visited (the dense morph+reduce kernel).  sparse=2: whenever it is exact
+    (non-negative templates, no Beeston-Barlow) only the non-empty bins are visited, the empty ones enter
+    through precomputed row sums -- same numbers required."""
     from blueice_amd import _capi
     c = load_case(name)
+    ctx.set_param('sparse', sparse)
     upload_case(ctx, c)
+    if sparse:
+        assert ctx.get_param('csr_ready') == 1
+        assert ctx.get_param('compact_ready') == (1 if c['bb_source'] < 0 else 0)
     n = len(c['call_ll'])
     rs = np.array([rate_scale_of(c, j) for j in range(n)])
     # one by one (the lf(**kw) form) ...
@@ -49,6 +57,7 @@ def test_eval_matches_reference_goldens(ctx, name):
                 continue
             assert same(ll, c['call_ll'][j], RTOL), (name, j, ll, c['call_ll'][j])
         assert same(single[j][0], batch[j], 1e-13) or asserts
+    ctx.set_param('sparse', 1)
 
 
 @pytest.mark.parametrize('name', case_names())
