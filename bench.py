@@ -172,7 +172,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                            'bytes per launch)' if traffic else None,
-                         'kernel': 'k_morph_reduce<1,false>', 'bytes_per_launch': bytes_per_launch,
+                         'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads)', 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_us': ms / max(launches, 1) * 1e3},
         }
 

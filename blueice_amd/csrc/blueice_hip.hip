@@ -117,7 +117,20 @@ struct LaunchArgs {
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
 // blockIdx.x strides over 512-bin tiles.
-template <int G, bool BB>
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double* p) {
+    if constexpr (NT) {
+        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
+        double2 v;
+        v.x = __builtin_nontemporal_load(p);
+        v.y = __builtin_nontemporal_load(p + 1);
+        return v;
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+
+template <int G, bool BB, bool NT>
 __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
     const int item = blockIdx.y;
     const int NS = a.n0 + a.n1 + a.n2;
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
 
 #pragma unroll 8
         for (int k = 0; k < a.n0; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(a.ps + rowoff[k] + bin0);
+            const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const double c = coef[k * G + g];
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
             for (int g = 0; g < G; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
 #pragma unroll 4
             for (int k = 0; k < a.n1; ++k) {
-                const double2 v = *reinterpret_cast<const double2*>(a.ps + rowoff[a.n0 + k] + bin0);
+                const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const double c = coef[(a.n0 + k) * G + g];
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
             }
 #pragma unroll 4
             for (int k = 0; k < a.n2; ++k) {
-                const double2 v = *reinterpret_cast<const double2*>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
+                const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const double c = coef[(a.n0 + a.n1 + k) * G + g];
@@ -612,6 +625,7 @@ struct bi_plan {
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
     int64_t bytes = 0;         // algorithmic HBM bytes per run
     int64_t launches = 0;
@@ -669,6 +683,7 @@ struct bi_ctx {
     // tunables
     int64_t blocks_per_cu = 8;
     int64_t max_group = kMaxG;
+    int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse
     int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent
     int64_t compact_budget = (int64_t)16 << 30;  // bytes of HBM the compacted templates may take
 
@@ -852,19 +867,23 @@ struct EventScope {
 };
 
 template <int G>
-void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb) {
-    if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true>), grid, dim3(kThreads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_morph_reduce<G, false>), grid, dim3(kThreads), 0, c->stream, a);
+void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
+    if (bb && nt) hipLaunchKernelGGL((k_morph_reduce<G, true, true>), grid, dim3(kThreads), 0, c->stream, a);
+    else if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true, false>), grid, dim3(kThreads), 0, c->stream, a);
+    else if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true>), grid, dim3(kThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_morph_reduce<G, false, false>), grid, dim3(kThreads), 0, c->stream, a);
 }
 
-void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb) {
+// nt: the launch streams its template rows exactly once (no two items touch the same anchor), so the loads
+// carry the nontemporal hint: +8 % HBM rate on gfx950; with shared rows the default policy (L2 / MALL) wins.
+void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
     EventScope ev(c);
     switch (G) {
-        case 1: launch_morph<1>(c, a, grid, bb); break;
-        case 2: launch_morph<2>(c, a, grid, bb); break;
-        case 4: launch_morph<4>(c, a, grid, bb); break;
-        case 8: launch_morph<8>(c, a, grid, bb); break;
-        default: launch_morph<16>(c, a, grid, bb); break;
+        case 1: launch_morph<1>(c, a, grid, bb, nt); break;
+        case 2: launch_morph<2>(c, a, grid, bb, nt); break;
+        case 4: launch_morph<4>(c, a, grid, bb, nt); break;
+        case 8: launch_morph<8>(c, a, grid, bb, nt); break;
+        default: launch_morph<16>(c, a, grid, bb, nt); break;
     }
 }
 
@@ -1071,7 +1090,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     a.partial = (double*)c->slot_partial.p;
     a.pflags = (unsigned*)c->slot_pflags.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
-    launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb);
+    launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
     const int lanes = nbx > 64 ? kThreads : 64;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kThreads), 0, c->stream, (const double*)a.partial,
                        (const unsigned*)a.pflags, nbx, 1, lanes, (int64_t)1, (const int64_t*)(dev + (o + 2) * 8),
@@ -1157,6 +1176,11 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
         return BI_OK;
     }
     if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
+    if (!strcmp(name, "nt_loads")) {
+        if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
+        c->nt_loads = v;
+        return BI_OK;
+    }
     return fail(c, BI_ERR_INVALID, "unknown parameter %s", name);
 }
 
@@ -1167,6 +1191,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "tile_bins")) return kTile;
     if (!strcmp(name, "padded_bins")) return c->Bp;
     if (!strcmp(name, "sparse")) return c->sparse;
+    if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
     if (!strcmp(name, "compact_ready")) return c->compact_ready ? 1 : 0;
@@ -1416,10 +1441,12 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     const int classG[5] = {1, 2, 4, 8, 16};
     struct HostClass { std::vector<int64_t> rowoff, cnt_off; std::vector<double> coef, aux, slot_lg; std::vector<int32_t> tiles; std::vector<int64_t> perm; int64_t bytes = 0; };
     HostClass hc[5];
-    const int maxg = (int)c->max_group;
+    const int maxg = bb ? (int)std::min<int64_t>(c->max_group, 8) : (int)c->max_group;  // G=16 with BB spills past 256 VGPRs
     size_t i = 0;
     std::vector<int64_t> corner_off((size_t)nc);
     for (int k = 0; k < nc; ++k) corner_off[(size_t)k] = corner_offset(c, k);
+    std::vector<char> anchor_used((size_t)c->A, 0);
+    bool reuse = false;
     while (i < pts.size()) {
         size_t j = i;
         while (j < pts.size() && pts[j].key == pts[i].key) ++j;
@@ -1433,6 +1460,11 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
             const int64_t p0 = pts[i].idx;
             const int64_t cell = geom[(size_t)p0].cell_anchor;
             const int64_t ds = pts[i].key % c->T;
+            for (int corner = 0; corner < nc; ++corner) {
+                char& u = anchor_used[(size_t)(cell + corner_off[(size_t)corner])];
+                if (u) reuse = true;
+                u = 1;
+            }
             const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
             const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
             const size_t ro = h.rowoff.size();
@@ -1528,6 +1560,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
         plan->launches += (k.n_items + 65534) / 65535;
         plan->classes.push_back(k);
     }
+    plan->no_reuse = !reuse;
     plan->n_bad = (int64_t)bad.size();
     if ((rc = dev_upload(c, plan->bad_idx, bad)) || (rc = dev_alloc(c, plan->out, (size_t)std::max<int64_t>(P, 1) * sizeof(double))) ||
         (rc = dev_upload(c, plan->status, plan->h_status))) {
@@ -1569,7 +1602,8 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             b.item_tiles = (const int32_t*)k.item_tiles.p + i0;
             b.partial = (double*)k.partial.p + i0 * k.nbx * k.G;
             b.pflags = (unsigned*)k.pflags.p + i0 * k.nbx * k.G;
-            launch_morph_g(c, k.G, b, dim3((unsigned)k.nbx, (unsigned)ni), bb);
+            const bool nt = !plan->sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && plan->no_reuse));
+            launch_morph_g(c, k.G, b, dim3((unsigned)k.nbx, (unsigned)ni), bb, nt);
             const int64_t n_slots = ni * k.G;
             const int lanes = k.nbx > 64 ? kThreads : 64;
             const int per_block = kThreads / lanes;

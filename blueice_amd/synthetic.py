@@ -23,6 +23,7 @@ CONFIGS = {
     'C2': (4, (5, 5, 5), (100, 100, 100)),
     'C5': (6, (5, 5, 5, 5), (50, 50, 50, 50)),
     'C5-3anchor': (6, (3, 3, 3, 3), (50, 50, 50, 50)),
+    'C5-2anchor': (6, (2, 2, 2, 2), (50, 50, 50, 50)),   # one grid cell of C5: full bin count, 4.8 GB
     'mini3': (4, (3, 3, 3), (20, 17, 13)),       # ragged bin count (4420, not a tile multiple)
     'mini4bb': (3, (2, 3, 2, 2), (11, 7, 5, 3)),
 }

@@ -94,3 +94,27 @@ def test_c2_properties(c2):
     ctx.upload_counts(counts)
     with pytest.raises(NotPreparedException):
         plan.run()
+
+
+def test_c5_beeston_barlow_full_bins():
+    """BASELINE.json configs[4] at full bin count: Beeston-Barlow, 6 sources, 4 shape parameters, 50^4 bins.
+    One grid cell of the anchor grid (2 anchors per axis, 4.8 GB) is enough to exercise every stream of an
+    evaluation (16 corners x 5 plain sources + 16 BB-source rows + 16 MC-count rows = 112 rows, 5.65 GB)."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    m = SyntheticModel.named('C5-2anchor', bb_source=0)
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    counts = m.counts(dense=True)           # ~10 events per bin
+    ctx.upload_counts(counts)
+    z, r = m.random_points(3, seed=2)
+    got, st = ctx.eval(z, r)
+    assert not st.any()
+    want = orc.loglikelihood(m.cell_model(z[0]), counts, z[0], r[0], bb_source=0)
+    assert abs(got[0] - want) <= 1e-10 * max(1.0, abs(want)), (got[0], want)
+    one, st1 = ctx.eval(z[1], r[1])
+    assert abs(one[0] - got[1]) <= 1e-13 * abs(one[0])
+    plan = ctx.plan(z, r)
+    assert plan.bytes == 8 * (16 * 6 + 16 + 1) * m.B          # three points of one cell share one pass (G=4)
+    ctx.close()
