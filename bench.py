@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--config', default='C2')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo for\n'
+                    'rehearsals on a box with fewer GPUs than ranks)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -75,19 +77,26 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     dist = None
     torch = None
+    n_dev = 1
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29500')
+        n_dev = max(torch.cuda.device_count(), 1)
+        if args.backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    use_cuda_tensors = world > 1 and args.backend == 'nccl'
 
     from blueice_amd.device import DeviceContext
     from blueice_amd.synthetic import SyntheticModel
 
     K, W = args.steps, args.warmup
     model = SyntheticModel.named(args.config)
-    ctx = DeviceContext(local_rank)
+    ctx = DeviceContext(local_rank % n_dev if world > 1 else local_rank)
     info = ctx.info()
     model.upload(ctx)
     counts = model.counts()
@@ -102,20 +111,27 @@ def main():
     bytes_per_launch = plans[0].bytes
     assert plans[0].launches == 1 and bytes_per_launch == PPS * 8 * (8 * model.S + 1) * model.B
 
-    if world > 1:
+    out_ptr = None
+    if use_cuda_tensors:
+        # results land directly in a torch (RCCL-visible) device tensor: no host round trip before the gather
         out = torch.empty(K * PPS, dtype=torch.float64, device='cuda')
         gathered = [torch.empty(K * PPS, dtype=torch.float64, device='cuda') for _ in range(world)]
         out_ptr = out.data_ptr()
+    elif world > 1:
+        out = torch.empty(K * PPS, dtype=torch.float64)
+        gathered = [torch.empty(K * PPS, dtype=torch.float64) for _ in range(world)]
 
     def barrier():
         ctx.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if use_cuda_tensors:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_cuda_tensors:
+                torch.cuda.synchronize()
 
     def run_steps(n, base=0):
-        if world > 1:
+        if out_ptr is not None:
             for i in range(n):
                 plans[i % POOL].run(out_ptr + 8 * PPS * ((base + i) % K))
         else:
@@ -128,14 +144,21 @@ def main():
     run_steps(K)
     ctx.sync()
     if world > 1:
+        if not use_cuda_tensors:               # rehearsal backend: last step's results via the host
+            last, _ = plans[(K - 1) % POOL].read()
+            out[-PPS:] = torch.from_numpy(last)
         dist.all_gather(gathered, out)         # the final gather: the only collective (RCCL over xGMI)
-        torch.cuda.synchronize()
+        if use_cuda_tensors:
+            torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if use_cuda_tensors else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank evaluated different points: the gathered vector must be finite everywhere
+        tail = torch.stack([g[-PPS:] for g in gathered]).cpu().numpy()
+        assert np.all(np.isfinite(tail)), 'gathered results contain non-finite values'
 
     # kernel time of the same steps, HIP events on the context stream around every launch
     ctx.profile(True)
