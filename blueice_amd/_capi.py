@@ -36,6 +36,7 @@ SIGNATURES = {
     'bi_set_allow_negative': (C.c_int, [_p, _p]),
     'bi_upload_counts': (C.c_int, [_p, _i64, _p]),
     'bi_eval': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p]),
+    'bi_eval_grad': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p]),
     'bi_eval_datasets': (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     'bi_interpolate': (C.c_int, [_p, C.c_int, _p, _p]),
     'bi_eval_full': (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),

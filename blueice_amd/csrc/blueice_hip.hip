@@ -130,7 +130,10 @@ __device__ __forceinline__ double2 stream_load(const double* p) {
     }
 }
 
-template <int G, bool BB, bool NT>
+// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
+// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
+// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
+template <int G, bool BB, bool NT, int MODE = 0>
 __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
     const int item = blockIdx.y;
     const int NS = a.n0 + a.n1 + a.n2;
@@ -162,7 +165,13 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
         }
         const double2 nv = *reinterpret_cast<const double2*>(cnt + bin0);
 
-        if constexpr (!BB) {
+        if constexpr (MODE == 1) {
+            sum[0] += poisson_term(nv.x, acc[0][0]) + poisson_term(nv.y, acc[0][1]);
+            const double f0 = (nv.x != 0.0 ? nv.x / acc[0][0] : 0.0) - 1.0;
+            const double f1 = (nv.y != 0.0 ? nv.y / acc[0][1] : 0.0) - 1.0;
+#pragma unroll
+            for (int g = 1; g < G; ++g) sum[g] += f0 * acc[g][0] + f1 * acc[g][1];
+        } else if constexpr (!BB) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 sum[g] += poisson_term(nv.x, acc[g][0]) + poisson_term(nv.y, acc[g][1]);
@@ -766,6 +775,8 @@ inline void find_cell(const std::vector<double>& g, double z, int& k, double& t)
 struct PointGeom {
     int64_t cell_anchor;          // linear anchor index of the lower corner
     std::vector<double> w;        // [2^deff] corner weights, reference order
+    double t[kMaxDim];            // per axis: normalised distance in the cell
+    double inv_delta[kMaxDim];    // per axis: 1 / (g[k+1] - g[k])  (0 for single-anchor axes)
 };
 
 // corner c (bit i from the most significant = effective axis 0) -> anchor offset
@@ -792,6 +803,8 @@ bool point_geometry(const bi_ctx* c, const double* z, PointGeom& g) {
         find_cell(c->grid[i], z[i], k, t);
         base += (int64_t)k * c->astride[i];
         kk[i] = k; tt[i] = t;
+        g.t[i] = t;
+        g.inv_delta[i] = c->grid[i].size() > 1 ? 1.0 / (c->grid[i][(size_t)k + 1] - c->grid[i][(size_t)k]) : 0.0;
     }
     (void)kk;
     g.cell_anchor = base;
@@ -872,6 +885,23 @@ void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
     else if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true, false>), grid, dim3(kThreads), 0, c->stream, a);
     else if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true>), grid, dim3(kThreads), 0, c->stream, a);
     else hipLaunchKernelGGL((k_morph_reduce<G, false, false>), grid, dim3(kThreads), 0, c->stream, a);
+}
+
+void launch_morph_grad(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool nt) {
+    EventScope ev(c);
+#define BI_GRAD_CASE(GG)                                                                                          \
+    case GG:                                                                                                      \
+        if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 1>), grid, dim3(kThreads), 0, c->stream, a); \
+        else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 1>), grid, dim3(kThreads), 0, c->stream, a);   \
+        break;
+    switch (G) {
+        BI_GRAD_CASE(2)
+        BI_GRAD_CASE(4)
+        BI_GRAD_CASE(8)
+        default:
+            BI_GRAD_CASE(16)
+    }
+#undef BI_GRAD_CASE
 }
 
 // nt: the launch streams its template rows exactly once (no two items touch the same anchor), so the loads
@@ -1650,6 +1680,157 @@ int bi_eval(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, con
     if (!rc) rc = bi_plan_read(c, plan, out, status);
     bi_plan_destroy(c, plan);
     return rc;
+}
+
+
+// ---- value + analytic gradient in one pass ----------------------------------------------------
+
+int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
+                 double* grad, int32_t* status) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "bi_eval_grad is not available with Beeston-Barlow");
+    if (P < 0 || (P > 0 && (!ll || !grad))) return fail(c, BI_ERR_INVALID, "bad P / output pointers");
+    if (c->d > 0 && P > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
+    const int S = c->S, d = c->d;
+    const int W = 1 + d + S;
+    if (W > kMaxG) return fail(c, BI_ERR_INVALID, "1 + d + S = %d exceeds %d gradient columns", W, kMaxG);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int G = std::max(2, pick_class(W, kMaxG));
+    const int de = (int)c->eff_axes.size();
+    const int nc = 1 << de, NS = nc * S;
+    bool any_neg = false;
+    for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
+    const bool sparse = c->sparse && c->compact_ready && !any_neg;
+    const int64_t n_rows = c->A * S;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+
+    std::vector<int64_t> rowoff, cnt_off, perm;
+    std::vector<double> coef, slot_lg;
+    std::vector<int32_t> tiles;
+    std::vector<int64_t> live;  // point index of every item
+    std::vector<double> ones((size_t)S, 1.0), mus((size_t)S), dmus((size_t)S * std::max(d, 1));
+    std::vector<double> dw((size_t)nc * std::max(de, 1));
+    std::vector<int64_t> corner_off((size_t)nc);
+    for (int k = 0; k < nc; ++k) corner_off[(size_t)k] = corner_offset(c, k);
+    int max_tiles = 1;
+    int64_t bytes = 0;
+    for (int64_t p = 0; p < P; ++p) {
+        if (status) status[p] = 0;
+        ll[p] = ninf;
+        for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = qnan;
+        const int64_t ds = dataset ? dataset[p] : 0;
+        if (ds < 0 || ds >= c->T) { if (status) status[p] = BI_ST_BAD_DATASET; continue; }
+        PointGeom g;
+        if (!point_geometry(c, z ? z + p * d : nullptr, g)) { if (status) status[p] = BI_ST_OUT_OF_BOUNDS; continue; }
+        interp_mus(c, g, mus.data());
+        const double* rs = rate_scale ? rate_scale + p * S : ones.data();
+        std::vector<double> r((size_t)S);
+        for (int s = 0; s < S; ++s) r[(size_t)s] = mus[(size_t)s] * rs[s];
+        if (!rates_physical(c, r.data())) { if (status) status[p] = BI_ST_UNPHYSICAL; continue; }
+        // d w_c / d z_i for the effective axes: (+-1/delta_i) * prod_{j != i} w^(j)
+        for (int corner = 0; corner < nc; ++corner)
+            for (int i = 0; i < de; ++i) {
+                const int ax = c->eff_axes[(size_t)i];
+                double v = (((corner >> (de - 1 - i)) & 1) ? 1.0 : -1.0) * g.inv_delta[ax];
+                for (int j = 0; j < de; ++j) {
+                    if (j == i) continue;
+                    const double t = g.t[c->eff_axes[(size_t)j]];
+                    v *= ((corner >> (de - 1 - j)) & 1) ? t : (1 - t);
+                }
+                dw[(size_t)corner * de + i] = v;
+            }
+        // d mus_s / d z_i
+        for (int i = 0; i < de; ++i)
+            for (int s = 0; s < S; ++s) {
+                double v = 0.0;
+                for (int corner = 0; corner < nc; ++corner)
+                    v += dw[(size_t)corner * de + i] * c->h_mus[(size_t)((g.cell_anchor + corner_off[(size_t)corner]) * S + s)];
+                dmus[(size_t)i * S + s] = v;
+            }
+        const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
+        const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
+        const size_t ro = rowoff.size(), co = coef.size(), po = perm.size();
+        rowoff.resize(ro + NS);
+        coef.resize(co + (size_t)NS * G, 0.0);
+        perm.resize(po + G, -1);
+        slot_lg.resize(po + G, 0.0);
+        int k = 0;
+        for (int corner = 0; corner < nc; ++corner)
+            for (int s = 0; s < S; ++s, ++k) {
+                const int64_t row = (g.cell_anchor + corner_off[(size_t)corner]) * S + s;
+                rowoff[ro + k] = row_base + row * row_stride;
+                double* col = &coef[co + (size_t)k * G];
+                const double w = g.w[(size_t)corner];
+                col[0] = w * r[(size_t)s];
+                for (int i = 0; i < de; ++i)   // total derivative w.r.t. z: through the weights and through mus(z)
+                    col[1 + c->eff_axes[(size_t)i]] = dw[(size_t)corner * de + i] * r[(size_t)s] + w * dmus[(size_t)i * S + s] * rs[s];
+                col[1 + d + s] = w * mus[(size_t)s];
+                if (sparse) {
+                    const double tz = c->h_Tz[(size_t)(ds * n_rows + row)];
+                    for (int q = 0; q < W; ++q) slot_lg[po + q] += col[q] * tz;
+                }
+            }
+        slot_lg[po] += c->h_lgsum[(size_t)ds];
+        for (int q = 0; q < W; ++q) perm[po + q] = (int64_t)live.size() * W + q;
+        cnt_off.push_back(sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp);
+        tiles.push_back((int32_t)(row_stride / kTile));
+        max_tiles = std::max(max_tiles, tiles.back());
+        bytes += (int64_t)sizeof(double) * ((int64_t)NS + 1) * (sparse ? row_stride : c->B);
+        live.push_back(p);
+    }
+    const int64_t n_items = (int64_t)live.size();
+    if (n_items == 0) return BI_OK;
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
+    const int nbx = (int)std::min<int64_t>(max_tiles, n_items == 1 ? slots : std::max<int64_t>(1, (4 * slots + n_items - 1) / n_items));
+    DevBuf d_row, d_coef, d_cnt, d_tiles, d_perm, d_lg, d_part, d_flag, d_out;
+    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_tiles); dev_free(d_perm);
+                           dev_free(d_lg); dev_free(d_part); dev_free(d_flag); dev_free(d_out); };
+    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) || (rc = dev_upload(c, d_cnt, cnt_off)) ||
+        (rc = dev_upload(c, d_tiles, tiles)) || (rc = dev_upload(c, d_perm, perm)) || (rc = dev_upload(c, d_lg, slot_lg)) ||
+        (rc = dev_alloc(c, d_part, (size_t)n_items * nbx * G * sizeof(double))) ||
+        (rc = dev_alloc(c, d_flag, (size_t)n_items * nbx * G * sizeof(unsigned))) ||
+        (rc = dev_alloc(c, d_out, (size_t)n_items * W * sizeof(double)))) {
+        cleanup();
+        return rc;
+    }
+    LaunchArgs a{};
+    a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
+    a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = max_tiles;
+    const bool nt = !sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && n_items == 1));
+    for (int64_t i0 = 0; i0 < n_items; i0 += 65535) {
+        const int64_t ni = std::min<int64_t>(65535, n_items - i0);
+        LaunchArgs b = a;
+        b.rowoff = (const int64_t*)d_row.p + i0 * NS;
+        b.coef = (const double*)d_coef.p + i0 * NS * G;
+        b.item_cnt = (const int64_t*)d_cnt.p + i0;
+        b.item_tiles = (const int32_t*)d_tiles.p + i0;
+        b.partial = (double*)d_part.p + i0 * nbx * G;
+        b.pflags = (unsigned*)d_flag.p + i0 * nbx * G;
+        launch_morph_grad(c, G, b, dim3((unsigned)nbx, (unsigned)ni), nt);
+        const int64_t n_slots = ni * G;
+        const int lanes = nbx > 64 ? kThreads : 64;
+        const int per_block = kThreads / lanes;
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
+                           (const double*)b.partial, (const unsigned*)b.pflags, nbx, G, lanes, n_slots,
+                           (const int64_t*)d_perm.p + i0 * G, (const double*)d_lg.p + i0 * G, (double*)d_out.p,
+                           (int32_t*)nullptr);
+    }
+    std::vector<double> h_out((size_t)n_items * W);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_grad: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < n_items; ++i) {
+        const int64_t p = live[(size_t)i];
+        ll[p] = h_out[(size_t)i * W];
+        for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = h_out[(size_t)i * W + 1 + j];
+    }
+    (void)bytes;
+    return BI_OK;
 }
 
 // ---- toy-MC form ---------------------------------------------------------------------------

@@ -162,6 +162,16 @@ class DeviceContext:
         self._check(self._lib.bi_eval(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), ptr(out), ptr(status)))
         return out, status
 
+    def eval_grad(self, z, rate_scale=None, dataset=None):
+        """Value and analytic gradient in one pass -> (ll [P], dll/dz [P, d], dll/drate_scale [P, S], status)."""
+        P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)
+        ll = np.empty(P, dtype=np.float64)
+        grad = np.empty((P, self.d + self.S), dtype=np.float64)
+        status = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.bi_eval_grad(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), ptr(ll), ptr(grad),
+                                           ptr(status)))
+        return ll, grad[:, :self.d], grad[:, self.d:], status
+
     def eval_datasets(self, z, rate_scale=None, t0=0, t1=None):
         """One parameter point against datasets [t0, t1) -> (ll [t1-t0], status)."""
         t1 = self.T if t1 is None else int(t1)

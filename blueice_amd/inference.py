@@ -31,10 +31,11 @@ def best_anchor(lf):
     return dict(zip(names, anchors[int(np.argmax(results))]))
 
 
-def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, **kwargs):
+def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, with_gradient=False, **kwargs):
     """-> (f(x), names, guesses, bounds) over the parameters not fixed through kwargs.
     Rate multipliers come first (guess 1, bounds (0, None)), then shape parameters (bounds from the
-    anchors, guess = base setting)."""
+    anchors, guess = base setting).  with_gradient=True (extension): f returns (value, gradient) from one
+    device pass (`lf.value_and_gradient`), for `scipy.optimize.minimize(..., jac=True)`."""
     guess = guess or {}
     names, guesses, bounds = [], [], []
     for src in lf.rate_parameters:
@@ -66,22 +67,38 @@ def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, **kwarg
         call.update(kwargs)
         return lf(**call) * sign
 
-    return objective, names, np.array(guesses), bounds
+    def objective_with_gradient(args):
+        call = {n: (10 ** a if lg else a) for n, a, lg in zip(names, args, log_rate)}
+        call.update(kwargs)
+        value, grads = lf.value_and_gradient(**call)
+        g = np.array([grads[n] * (np.log(10.) * call[n] if lg else 1.0) for n, lg in zip(names, log_rate)])
+        if not np.isfinite(value):
+            g = np.zeros(len(names))
+        return value * sign, g * sign
+
+    return (objective_with_gradient if with_gradient else objective), names, np.array(guesses), bounds
 
 
-def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bounds_to_minimizer=False, **kwargs):
+def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bounds_to_minimizer=False,
+                  use_gradient=False, **kwargs):
     """Maximise lf over its floating parameters -> (OrderedDict name -> value, max log likelihood).
-    scipy's default minimizer first, Nelder-Mead as the fallback, OptimizationFailed after that."""
+    scipy's default minimizer first, Nelder-Mead as the fallback, OptimizationFailed after that.
+    use_gradient=True (extension): hand scipy the analytic gradient computed in the same device pass as
+    the value instead of letting it difference the objective numerically (n_parameters + 1 calls per step)."""
     minimize_kwargs = minimize_kwargs or {}
+    use_gradient = use_gradient and hasattr(lf, 'value_and_gradient')
     try:
-        f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space, **kwargs)
+        f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space,
+                                                    **(dict(kwargs, with_gradient=True) if use_gradient else kwargs))
     except NoOpimizationNecessary:
         return {}, lf(**kwargs)
     use_bounds = bounds if pass_bounds_to_minimizer else None
-    res = minimize(f, guess, bounds=use_bounds, **minimize_kwargs)
+    res = minimize(f, guess, bounds=use_bounds, **(dict(minimize_kwargs, jac=True) if use_gradient else minimize_kwargs))
     if not res.success:
         retry = deepcopy(minimize_kwargs)
         retry.pop('method', None)
+        if use_gradient:
+            f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space, **kwargs)
         res = minimize(f, guess, bounds=use_bounds, method='Nelder-Mead', **retry)
         if not res.success:
             raise OptimizationFailed("Optimization failure: ", res)

@@ -343,6 +343,49 @@ class BinnedLogLikelihood(LogLikelihoodBase):
         finally:
             scratch.close()
 
+    # -- analytic gradient (one device pass; the reference differentiates numerically) ----------
+    @staticmethod
+    def _prior_slope(log_prior, x):
+        if log_prior is None:
+            return 0.0
+        h = 1e-6 * max(1.0, abs(x))
+        return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
+
+    @_needs_data
+    def value_and_gradient(self, livetime_days=None, **kwargs):
+        """-> (ll, OrderedDict parameter name -> d ll / d parameter) for every registered rate and shape
+        parameter, from ONE pass over the templates (`bi_eval_grad`).  Inside a grid cell ll is smooth in
+        the shape parameters; exactly on an anchor the slope of the cell the point is assigned to is
+        returned.  Prior terms are differentiated numerically on the host (they are Python callables)."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        grads = OrderedDict()
+        names = ['%s_rate_multiplier' % s for s in self.rate_parameters] + list(self.shape_parameters)
+        if prior is None:
+            return -float('inf'), OrderedDict((n, float('nan')) for n in names)
+        multipliers, settings = self._kwargs_to_settings(**kwargs)
+        ll, gz, gs, st = self.ctx.eval_grad(zs if len(zs) else None, scale[None, :])
+        ll = self._interpret(float(ll[0]), int(st[0]))
+        gz, gs = gz[0], gs[0]
+        mult = np.array(multipliers, dtype=float)
+        with np.errstate(all='ignore'):
+            per_mult = np.where(mult != 0, scale / np.where(mult != 0, mult, 1.0), 0.0)
+        if np.any(mult == 0):          # d scale / d multiplier does not depend on the multiplier itself
+            _, _, unit = self._host_terms(livetime_days, {k: v for k, v in kwargs.items()
+                                                          if not k.endswith('_rate_multiplier')})
+            per_mult = np.where(mult != 0, per_mult, unit)
+        for s, name in enumerate(self.source_name_list):
+            if name in self.rate_parameters:
+                grads['%s_rate_multiplier' % name] = gs[s] * per_mult[s] + \
+                    self._prior_slope(self.rate_parameters[name], multipliers[s])
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            g = gz[i] + self._prior_slope(log_prior, settings[name])
+            # a shape parameter that doubles as the efficiency of some sources also scales their rates
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                if self.source_efficiency_names[s] == name and settings[name] != 0:
+                    g += gs[s] * scale[s] / settings[name]
+            grads[name] = g
+        return prior + ll, grads
+
     # -- batched entry points (no counterpart in the reference) --------------------------------
     def _batch_terms(self, points, livetime_days):
         names = list(points.keys())

@@ -107,6 +107,16 @@ int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
 int bi_eval(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
             double* out, int32_t* status);
 
+/* Value and analytic gradient in ONE pass over the templates (no counterpart in the reference, whose
+ * fits differentiate `make_objective`'s f numerically: blueice/inference.py:111-124,153-155).
+ *   ll   [P]          as bi_eval
+ *   grad [P][d + S]   d ll / d z_i (i < d; through the morph weights AND through mus(z)), then
+ *                     d ll / d rate_scale_s.  Inside a grid cell ll is smooth; on an anchor the
+ *                     derivative is the one of the cell the point is assigned to.  NaN where ll = -inf.
+ * Needs 1 + d + S <= 16; not available with Beeston-Barlow. */
+int bi_eval_grad(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
+                 double* grad, int32_t* status);
+
 /* One parameter point against datasets [t0, t1): the toy-MC form.  mu_b / log mu_b are computed
  * once and every dataset reduces sum_b xlogy(n, mu) against them.  Not available with
  * Beeston-Barlow (mu then depends on the data).  out [t1 - t0]. */

@@ -1,0 +1,95 @@
+"""Analytic gradient (bi_eval_grad / value_and_gradient): against central finite differences of the CPU
+oracle on the same inputs, in both the dense and the non-empty-bin form, and through bestfit_scipy."""
+import numpy as np
+import pytest
+
+import model_zoo
+from golden_util import GOLDEN_DIR, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def fd_oracle(model, counts, z, r, h=1e-6):
+    from oracle import blueice_oracle as orc
+    gz = np.zeros(len(z))
+    for i in range(len(z)):
+        zp, zm = np.array(z, float), np.array(z, float)
+        zp[i] += h
+        zm[i] -= h
+        gz[i] = (orc.loglikelihood(model, counts, zp, r) - orc.loglikelihood(model, counts, zm, r)) / (2 * h)
+    gr = np.zeros(len(r))
+    for s in range(len(r)):
+        hs = h * max(1.0, abs(r[s]))
+        rp, rm = np.array(r, float), np.array(r, float)
+        rp[s] += hs
+        rm[s] -= hs
+        gr[s] = (orc.loglikelihood(model, counts, z, rp) - orc.loglikelihood(model, counts, z, rm)) / (2 * hs)
+    return gz, gr
+
+
+@pytest.mark.parametrize('sparse', [0, 2])
+@pytest.mark.parametrize('name', ['c1_like', 'd2_nonuniform', 'd3_small', 'd0_multi_source'])
+def test_gradient_matches_finite_differences(name, sparse):
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    c = load_case(name)
+    ctx = DeviceContext(0)
+    ctx.set_param('sparse', sparse)
+    ctx.upload_model(c['model']['anchor_z'], c['model']['ps'], c['model']['mus'])
+    ctx.upload_counts(c['counts'])
+    rng = np.random.default_rng(3)
+    zs = np.array([[rng.uniform(g[0], g[-1]) for g in c['model']['anchor_z']] for _ in range(6)]).reshape(6, c['d'])
+    rs = rng.uniform(0.4, 1.6, size=(6, c['S']))
+    ll, gz, gs, st = ctx.eval_grad(zs if c['d'] else None, rs)
+    ref, _ = ctx.eval(zs if c['d'] else None, rs)
+    assert not st.any()
+    np.testing.assert_allclose(ll, ref, rtol=1e-12)
+    for i in range(6):
+        fz, fr = fd_oracle(c['model'], c['counts'], zs[i], rs[i])
+        scale = max(1.0, np.abs(np.concatenate([fz, fr])).max())
+        np.testing.assert_allclose(gz[i], fz, atol=2e-5 * scale, rtol=1e-6)
+        np.testing.assert_allclose(gs[i], fr, atol=2e-5 * scale, rtol=1e-6)
+    # status / edge: out of the box -> -inf with NaN gradient
+    if c['d']:
+        zz = zs[0].copy()
+        zz[0] = c['model']['anchor_z'][0][-1] + 1.0
+        ll, gz, gs, st = ctx.eval_grad(zz, rs[0])
+        assert ll[0] == -np.inf and st[0] == 1 and np.isnan(gz[0]).all()
+    ctx.close()
+
+
+def test_value_and_gradient_through_the_likelihood_class():
+    from scipy import stats
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf, _, _ = model_zoo.d2_nonuniform(ns)
+    lf.add_rate_uncertainty('s1', 0.3)
+    kw = dict(shift=0.3, stretch=2.2, s0_rate_multiplier=0.8, s1_rate_multiplier=1.2, s2_rate_multiplier=1.1,
+              livetime_days=3.)
+    ll, grads = lf.value_and_gradient(**kw)
+    assert abs(ll - lf(**kw)) <= 1e-12 * abs(ll)
+    assert list(grads) == ['s0_rate_multiplier', 's1_rate_multiplier', 's2_rate_multiplier', 'shift', 'stretch']
+    for name, g in grads.items():
+        h = 1e-6
+        up, dn = dict(kw), dict(kw)
+        up[name] += h
+        dn[name] -= h
+        fd = (lf(**up) - lf(**dn)) / (2 * h)
+        assert abs(g - fd) <= 1e-5 * max(1.0, abs(fd)), (name, g, fd)
+
+
+def test_bestfit_with_gradient_reaches_the_reference_optimum():
+    f = np.load(GOLDEN_DIR + '/fit_c1_like.npz')
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf = model_zoo.fit_c1_like(ns)
+    calls = {'n': 0}
+    orig = lf.ctx.eval_grad
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    lf.ctx.eval_grad = counting
+    res, ll = lf.bestfit_scipy(use_gradient=True)
+    assert list(res.keys()) == [str(x) for x in f['fit_all_names']]
+    assert ll >= float(f['fit_all_ll']) - 1e-6 * abs(ll)           # at least as good as the reference's optimum
+    assert abs(ll - float(f['fit_all_ll'])) < 1e-4 * abs(ll)
+    assert 0 < calls['n'] < 200                                      # vs ~500 objective calls by differencing
