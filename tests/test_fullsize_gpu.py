@@ -118,3 +118,29 @@ def test_c5_beeston_barlow_full_bins():
     plan = ctx.plan(z, r)
     assert plan.bytes == 8 * (16 * 6 + 16 + 1) * m.B          # three points of one cell share one pass (G=4)
     ctx.close()
+
+
+def test_c3_toy_batch(c2):
+    """BASELINE.json configs[2] (toy-MC datasets batched per call) at full bin count with a reduced number
+    of toys: the dense-count form, the CSR form and the per-dataset point form agree, and one toy is checked
+    against the oracle."""
+    from oracle import blueice_oracle as orc
+    m, ctx = c2
+    T = 48
+    toys = np.stack([m.counts(dataset=100 + t) for t in range(T)])
+    z, r = m.default_point()
+    res = {}
+    for sparse in (0, 1):
+        ctx.set_param('sparse', sparse)
+        ctx.upload_counts(toys)
+        assert ctx.get_param('csr_ready') == sparse
+        res[sparse], st = ctx.eval_datasets(z, r)
+        assert st == 0
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-13)
+    pts, _ = ctx.eval(np.tile(z, (T, 1)), np.tile(r, (T, 1)), dataset=np.arange(T))     # compacted templates
+    np.testing.assert_allclose(pts, res[0], rtol=1e-12)
+    part, _ = ctx.eval_datasets(z, r, 7, 19)
+    np.testing.assert_array_equal(part, res[1][7:19])
+    want = orc.loglikelihood(m.cell_model(z), toys[5], z, r)
+    assert abs(res[0][5] - want) <= 1e-10 * abs(want)
+    ctx.set_param('sparse', 1)
