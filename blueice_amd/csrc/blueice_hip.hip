@@ -530,9 +530,128 @@ __global__ __launch_bounds__(kThreads) void k_dataset_dot_csr(const int32_t* __r
     }
 }
 
+// ---- toy-MC generation on the device ---------------------------------------------------------
+// n_{t,b} ~ Poisson(mu_b): the binned equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of
+// events per source, each drawn from the source's pdf) followed by set_data's binning (likelihood.py:603-609).
+// Counter-based Philox4x32-10 keyed by the seed, counter = (bin, dataset, attempt): every (dataset, bin) draw
+// is independent of launch geometry and can be regenerated, which is what lets the two-pass CSR build
+// (count, then scatter) see the same numbers twice.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // uniform on [0, 1) with 53 random bits
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__device__ double poisson_draw(double lam, uint64_t seed, int64_t t, int64_t b) {
+    if (!(lam > 0.0)) return 0.0;  // mu = 0 (or invalid) -> no events
+    uint32_t r[4];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (lam < 10.0) {
+        // inversion by sequential search (one uniform)
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, k0, k1, r);
+        const double u = u53(r[0], r[1]);
+        double p = exp(-lam), F = p;
+        double n = 0.0;
+        while (u > F && n < 1000.0) {
+            n += 1.0;
+            p *= lam / n;
+            F += p;
+        }
+        return n;
+    }
+    // PTRS, Hoermann (1993): transformed rejection with squeeze, as in numpy's random_poisson_ptrs
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb;
+    const double invalpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
+    for (uint32_t attempt = 0; attempt < 4096u; ++attempt) {
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, ((uint32_t)(t >> 32) & 0xFFFFu) | ((attempt + 1u) << 16), k0, k1, r);
+        const double U = u53(r[0], r[1]) - 0.5, V = u53(r[2], r[3]);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * aa / us + bb) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(aa / (us * us) + bb) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam);  // unreachable in practice (acceptance > 0.9 per attempt)
+}
+
+__global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
+                                                        int32_t* __restrict__ cnt, int nchunks) {
+    const int64_t t = t0 + blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    int k = 0;
+#pragma unroll 1
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (b0 + j < B && poisson_draw(mu[b0 + j], seed, t, b0 + j) != 0.0) ++k;
+    __shared__ int sh[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
+                                                          const int64_t* __restrict__ chunk_off, int nchunks,
+                                                          int32_t* __restrict__ nz_idx, double* __restrict__ nz_n,
+                                                          double* __restrict__ lg_partial) {
+    const int64_t t = t0 + blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    double v[kNzPerThread];
+    int k = 0;
+    double lg = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < kNzPerThread; ++j) {
+        v[j] = (b0 + j < B) ? poisson_draw(mu[b0 + j], seed, t, b0 + j) : 0.0;
+        if (v[j] != 0.0) { ++k; if (v[j] > 1.0) lg += lgamma(v[j] + 1.0); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int q = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += q;
+    }
+    __shared__ int sh[kThreads / 64];
+    __shared__ double shl[kThreads / 64];
+    lg = wave_sum(lg);
+    if (lane == 63) sh[wave] = incl;
+    if (lane == 0) shl[wave] = lg;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (v[j] != 0.0) {
+            nz_idx[pos] = (int32_t)(b0 + j);
+            nz_n[pos] = v[j];
+            ++pos;
+        }
+    if (threadIdx.x == 0) lg_partial[(int64_t)blockIdx.y * nchunks + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
+}
+
+// densify one dataset from its non-empty-bin list
+__global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __restrict__ n, int64_t nnz,
+                               double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) out[idx[j]] = n[j];
+}
+
 // ---- toy-MC form: one parameter point, many datasets --------------------------------------
 // pass 1: mu_b -> logmu[b] (log mu, or -inf for mu == 0, or nan for invalid mu), partial sum mu
-__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu) {
+__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu, int store_mu) {
     const int64_t* __restrict__ rowoff = a.rowoff;
     const double* __restrict__ coef = a.coef;
     double sum = 0.0;
@@ -548,8 +667,13 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* 
             m1 = fma(c, v.y, m1);
         }
         double2 l;
-        l.x = (m0 >= 0.0) ? log(m0) : __builtin_nan("");
-        l.y = (m1 >= 0.0) ? log(m1) : __builtin_nan("");
+        if (store_mu) {  // toy generation wants the expectation itself
+            l.x = m0;
+            l.y = m1;
+        } else {
+            l.x = (m0 >= 0.0) ? log(m0) : __builtin_nan("");
+            l.y = (m1 >= 0.0) ? log(m1) : __builtin_nan("");
+        }
         if (!(m0 >= 0.0) || !(m1 >= 0.0)) bad = 1u;
         *reinterpret_cast<double2*>(logmu + bin0) = l;
         sum += m0 + m1;
@@ -663,6 +787,7 @@ struct bi_ctx {
 
     // data
     bool data_ready = false;
+    bool dense_counts = false;  // counts [T][Bp] resident (false for device-generated toys: CSR lists only)
     int64_t T = 0;
     DevBuf counts, lgsum;
     std::vector<double> h_lgsum;
@@ -926,6 +1051,52 @@ int check_ready(bi_ctx* c, bool need_data) {
 
 int n_tiles_of(const bi_ctx* c) { return (int)(c->Bp / kTile); }
 
+// per-dataset compacted copies of all template rows over the non-empty bins (needs the CSR lists)
+int build_compact_templates(bi_ctx* c) {
+    c->compact_ready = false;
+    const int64_t T = c->T, Bp = c->Bp;
+    int rc;
+    hipError_t e;
+    if (!c->ps_nonneg || c->bb_source >= 0) return BI_OK;
+    const int64_t rows = c->A * c->S;
+    c->h_c_np.assign((size_t)T, 0);
+    c->h_c_off.assign((size_t)T, 0);
+    c->h_cnt_off.assign((size_t)T, 0);
+    int64_t tot_ps = 0, tot_cnt = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t nnz = c->h_nz_off[(size_t)t + 1] - c->h_nz_off[(size_t)t];
+        const int64_t np = std::max<int64_t>(kTile, (nnz + kTile - 1) / kTile * kTile);
+        c->h_c_np[(size_t)t] = np;
+        c->h_c_off[(size_t)t] = tot_ps;
+        c->h_cnt_off[(size_t)t] = tot_cnt;
+        tot_ps += rows * np;
+        tot_cnt += np;
+    }
+    if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
+    if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
+        (rc = dev_alloc(c, c->scratch, (size_t)rows * sizeof(double))))
+        return rc;
+    c->h_Tz.assign((size_t)T * rows, 0.0);
+    std::vector<double> tnz((size_t)rows);
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo, np = c->h_c_np[(size_t)t];
+        double* dst = (double*)c->ps_c.p + c->h_c_off[(size_t)t];
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((np + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0,
+                           c->stream, (const double*)c->ps.p, Bp, (const int32_t*)c->nz_idx.p + lo, nnz, np, dst);
+        hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)c->nz_n.p + lo, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
+        hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
+                           (double*)c->scratch.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
+        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
+    }
+    c->compact_ready = true;
+    return BI_OK;
+}
+
 // CSR lists of the non-empty bins of every dataset (always, unless the data are dense), and -- when the
 // templates are non-negative and the budget allows -- per-dataset compacted copies of all template rows,
 // so that an evaluation only touches non-empty bins:
@@ -977,45 +1148,7 @@ int build_sparse_forms(bi_ctx* c) {
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "non-empty-bin scatter: %s", hipGetErrorString(e));
     c->csr_ready = true;
 
-    // compacted templates per dataset
-    if (!c->ps_nonneg || c->bb_source >= 0) return BI_OK;
-    const int64_t rows = c->A * c->S;
-    c->h_c_np.assign((size_t)T, 0);
-    c->h_c_off.assign((size_t)T, 0);
-    c->h_cnt_off.assign((size_t)T, 0);
-    int64_t tot_ps = 0, tot_cnt = 0;
-    for (int64_t t = 0; t < T; ++t) {
-        const int64_t nnz = c->h_nz_off[(size_t)t + 1] - c->h_nz_off[(size_t)t];
-        const int64_t np = std::max<int64_t>(kTile, (nnz + kTile - 1) / kTile * kTile);
-        c->h_c_np[(size_t)t] = np;
-        c->h_c_off[(size_t)t] = tot_ps;
-        c->h_cnt_off[(size_t)t] = tot_cnt;
-        tot_ps += rows * np;
-        tot_cnt += np;
-    }
-    if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
-    if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
-        (rc = dev_alloc(c, c->scratch, (size_t)rows * sizeof(double))))
-        return rc;
-    c->h_Tz.assign((size_t)T * rows, 0.0);
-    std::vector<double> tnz((size_t)rows);
-    for (int64_t t = 0; t < T; ++t) {
-        const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo, np = c->h_c_np[(size_t)t];
-        double* dst = (double*)c->ps_c.p + c->h_c_off[(size_t)t];
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((np + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0,
-                           c->stream, (const double*)c->ps.p, Bp, (const int32_t*)c->nz_idx.p + lo, nnz, np, dst);
-        hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->nz_n.p + lo, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
-        hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
-                           (double*)c->scratch.p);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
-        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
-    }
-    c->compact_ready = true;
-    return BI_OK;
+    return build_compact_templates(c);
 }
 
 
@@ -1043,6 +1176,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
     const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg;
+    if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
     const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
     const int tiles = (int)(row_stride / kTile);
@@ -1400,6 +1534,7 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
     HIP_TRY(c, hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->T = T;
+    c->dense_counts = true;
     if ((rc = build_sparse_forms(c))) return rc;
     c->data_ready = true;
     return BI_OK;
@@ -1438,6 +1573,9 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
     const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg;
     const int64_t n_rows = c->A * S;
+    if (!sparse && !c->dense_counts)
+        return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
+                                     "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
 
     bi_plan* plan = new bi_plan();
     plan->P = P;
@@ -1702,6 +1840,7 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
     const bool sparse = c->sparse && c->compact_ready && !any_neg;
+    if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t n_rows = c->A * S;
     const double ninf = -std::numeric_limits<double>::infinity();
     const double qnan = std::numeric_limits<double>::quiet_NaN();
@@ -1876,7 +2015,8 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int nmu = (int)std::min<int64_t>(n_tiles, slots);
     DevBuf d_row, d_coef, d_out;
     auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_out); };
-    const bool csr = c->sparse && c->csr_ready;
+    const bool csr = (c->sparse && c->csr_ready) || !c->dense_counts;
+    if (csr && !c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
     const int64_t chunk = csr ? 1048576 : 16384;
     const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, std::min(n, chunk))));
     if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
@@ -1896,7 +2036,7 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles;
     {
         EventScope ev(c);
-        hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p);
+        hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p, 0);
     }
     for (int64_t s0 = 0; s0 < n; s0 += chunk) {
         const int64_t ni = std::min(chunk, n - s0);
@@ -1920,6 +2060,129 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets: %s", hipGetErrorString(e));
+    return BI_OK;
+}
+
+
+// ---- toy-MC generation -------------------------------------------------------------------------
+
+int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64_t T, uint64_t seed) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (T < 1) return fail(c, BI_ERR_INVALID, "need T >= 1 toys");
+    if (c->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PointGeom g;
+    if (!point_geometry(c, z, g)) return fail(c, BI_ERR_INVALID, "toy generation point is outside the anchor box");
+    std::vector<double> r((size_t)c->S);
+    interp_mus(c, g, r.data());
+    if (rate_scale) for (int s = 0; s < c->S; ++s) r[(size_t)s] *= rate_scale[s];
+    for (int s = 0; s < c->S; ++s)
+        if (!(r[(size_t)s] >= 0.0 && r[(size_t)s] < std::numeric_limits<double>::infinity()))
+            return fail(c, BI_ERR_INVALID, "toy generation needs rates in [0, inf)");
+    c->data_ready = false;
+    c->dense_counts = false;
+    c->csr_ready = c->compact_ready = false;
+    ++c->epoch;
+    dev_free(c->counts);  // the toys exist as non-empty-bin lists only
+    const int nc = (int)g.w.size(), NS = nc * c->S;
+    std::vector<int64_t> rowoff((size_t)NS);
+    std::vector<double> coef((size_t)NS);
+    int k = 0;
+    for (int corner = 0; corner < nc; ++corner)
+        for (int s = 0; s < c->S; ++s) {
+            rowoff[(size_t)k] = ((g.cell_anchor + corner_offset(c, corner)) * c->S + s) * c->Bp;
+            coef[(size_t)k++] = g.w[(size_t)corner] * r[(size_t)s];
+        }
+    const int n_tiles = n_tiles_of(c);
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
+    const int nmu = (int)std::min<int64_t>(n_tiles, slots);
+    const int64_t B = c->B;
+    const int nchunks = (int)((B + kNzChunk - 1) / kNzChunk);
+    DevBuf d_row, d_coef, d_cnt, d_off, d_lgp;
+    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_off); dev_free(d_lgp); };
+    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
+        (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
+        (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
+        (rc = dev_alloc(c, d_cnt, (size_t)T * nchunks * sizeof(int32_t))) ||
+        (rc = dev_alloc(c, d_lgp, (size_t)T * nchunks * sizeof(double))) || (rc = dev_alloc(c, c->lgsum, (size_t)T * sizeof(double)))) {
+        cleanup();
+        return rc;
+    }
+    LaunchArgs a{};
+    a.ps = (const double*)c->ps.p;
+    a.rowoff = (const int64_t*)d_row.p;
+    a.coef = (const double*)d_coef.p;
+    a.partial = (double*)c->scratch.p;
+    a.pflags = (unsigned*)((char*)c->scratch.p + (((size_t)nmu * sizeof(double) + 63) / 64) * 64);
+    a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles;
+    hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p, 1);
+    const double* mu = (const double*)c->logmu.p;
+    const int64_t tchunk = 32768;
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+        const int64_t n = std::min(tchunk, T - t0);
+        hipLaunchKernelGGL(k_toy_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, B, seed, t0,
+                           (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
+    }
+    std::vector<int32_t> h_cnt((size_t)T * nchunks);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt.p, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, BI_ERR_HIP, "toy count: %s", hipGetErrorString(e)); }
+    std::vector<int64_t> h_off(h_cnt.size());
+    c->h_nz_off.assign((size_t)T + 1, 0);
+    int64_t run = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        c->h_nz_off[(size_t)t] = run;
+        for (int q = 0; q < nchunks; ++q) { h_off[(size_t)t * nchunks + q] = run; run += h_cnt[(size_t)t * nchunks + q]; }
+    }
+    c->h_nz_off[(size_t)T] = run;
+    if ((rc = dev_upload(c, d_off, h_off)) || (rc = dev_alloc(c, c->nz_idx, (size_t)std::max<int64_t>(run, 1) * sizeof(int32_t))) ||
+        (rc = dev_alloc(c, c->nz_n, (size_t)std::max<int64_t>(run, 1) * sizeof(double))) || (rc = dev_upload(c, c->nz_off, c->h_nz_off))) {
+        cleanup();
+        return rc;
+    }
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+        const int64_t n = std::min(tchunk, T - t0);
+        hipLaunchKernelGGL(k_toy_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, B, seed, t0,
+                           (const int64_t*)d_off.p + t0 * nchunks, nchunks, (int32_t*)c->nz_idx.p, (double*)c->nz_n.p,
+                           (double*)d_lgp.p + t0 * nchunks);
+        hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)d_lgp.p + t0 * nchunks, nchunks, (double*)c->lgsum.p + t0, n);
+    }
+    c->h_lgsum.assign((size_t)T, 0.0);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "toy scatter: %s", hipGetErrorString(e));
+    c->T = T;
+    c->csr_ready = true;
+    if ((rc = build_compact_templates(c))) return rc;   // per-toy point evaluations, when the budget allows
+    c->data_ready = true;
+    return BI_OK;
+}
+
+int bi_download_counts(bi_ctx* c, int64_t t, double* out) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (t < 0 || t >= c->T || !out) return fail(c, BI_ERR_INVALID, "dataset %lld outside [0,%lld) or out is NULL", (long long)t, (long long)c->T);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->dense_counts) {
+        HIP_TRY(c, hipMemcpyAsync(out, (const double*)c->counts.p + t * c->Bp, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return BI_OK;
+    }
+    if (!c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
+    if ((rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double)))) return rc;
+    const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo;
+    HIP_TRY(c, hipMemsetAsync(c->logmu.p, 0, (size_t)c->B * sizeof(double), c->stream));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_csr_to_dense, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t*)c->nz_idx.p + lo, (const double*)c->nz_n.p + lo, nnz, (double*)c->logmu.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->logmu.p, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BI_OK;
 }
 
@@ -1965,6 +2228,7 @@ int bi_eval_full(bi_ctx* c, const double* z, const double* rate_scale, int64_t d
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!ll || !mus_out || !ps_out) return fail(c, BI_ERR_INVALID, "output pointers are NULL");
+    if (c->bb_source >= 0 && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     int32_t st = 0;
     rc = bi_eval(c, 1, z, rate_scale, &dataset, ll, &st);
     if (rc) return rc;

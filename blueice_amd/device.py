@@ -140,6 +140,19 @@ class DeviceContext:
         self._check(self._lib.bi_upload_counts(self._h, T, ptr(c)))
         self.T = T
 
+    def generate_toys(self, z, rate_scale=None, T=1, seed=0):
+        """Replace the data by T Poisson toy datasets drawn on the device at parameter point (z, rate_scale)."""
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        self._check(self._lib.bi_generate_toys(self._h, ptr(z), ptr(rate_scale), int(T), int(seed) & (2**64 - 1)))
+        self.T = int(T)
+
+    def download_counts(self, t=0):
+        out = np.empty(self.B, dtype=np.float64)
+        self._check(self._lib.bi_download_counts(self._h, int(t), ptr(out)))
+        return out
+
     # -- evaluation ------------------------------------------------------------------------
     def _point_args(self, z, rate_scale, dataset):
         if self.d:

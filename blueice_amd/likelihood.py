@@ -283,6 +283,21 @@ class BinnedLogLikelihood(LogLikelihoodBase):
         self.ctx.upload_counts(counts)
         self.is_data_set = True
 
+    @_needs_preparation
+    def simulate_toys(self, n_toys, seed=0, livetime_days=None, **kwargs):
+        """Draw `n_toys` binned toy datasets ON THE DEVICE at the given parameter values and make them the
+        likelihood's data (dataset 0 is what plain `lf(**params)` sees; `eval_toys` evaluates them all).
+        Per bin n ~ Poisson(mu_b): the distribution that `base_model.simulate()` + `set_data()` produces
+        (model.py:69-91, likelihood.py:603-609), without events or host transfers."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is None:
+            raise ValueError("cannot simulate outside the anchor box")
+        self.ctx.generate_toys(zs, scale, n_toys, seed)
+        self._data = None
+        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
+        self.data_events_per_bin.histogram = self.ctx.download_counts(0).reshape(self.bin_shape)
+        self.is_data_set = True
+
     # -- evaluation ------------------------------------------------------------------------
     def _interpret(self, ll, status, mus_hint=None):
         if status & _capi.ST_UNPHYSICAL:

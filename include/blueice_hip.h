@@ -87,6 +87,16 @@ int bi_set_allow_negative(bi_ctx* ctx, const int32_t* allow /*[S]*/);
  * (blueice/likelihood.py:603-609).  T datasets of B float64 counts each (toy MC: T > 1). */
 int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
 
+/* Toy-MC datasets generated on the device: n_{t,b} ~ Poisson(mu_b), mu_b = sum_s r_s p_{s,b}(z) -- the binned
+ * equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of events per source, each drawn from
+ * the source's pdf) followed by set_data's binning (blueice/likelihood.py:603-609).  Philox4x32-10 keyed by
+ * (seed; dataset, bin): reproducible and independent of launch geometry.  The T datasets REPLACE the
+ * context's data and are stored as non-empty-bin lists only (no [T][B] array, no host transfer);
+ * bi_eval_datasets works on them directly, point evaluations when the compacted templates fit the budget. */
+int bi_generate_toys(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t T, uint64_t seed);
+/* dense counts [B] of dataset t, from whatever form is resident */
+int bi_download_counts(bi_ctx* ctx, int64_t t, double* out);
+
 /* ---- the hot path -----------------------------------------------------------------------
  * P independent evaluations of LogLikelihoodBase.__call__ (blueice/likelihood.py:318-427)
  * without the Python-callable priors:

@@ -74,25 +74,38 @@ def test_two_ranks_on_gpu_equal_single_process():
         np.testing.assert_allclose(lt, single_t, rtol=1e-13)
 
 
-def test_results_land_in_a_torch_device_tensor():
+_TORCH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.set_device(0)                      # bench.py's order: torch initialises the GPU first
+buf = torch.full((300,), float('nan'), dtype=torch.float64, device='cuda:0')
+torch.cuda.synchronize()
+sys.path.insert(0, sys.argv[1])
+from blueice_amd.device import DeviceContext
+from blueice_amd.synthetic import SyntheticModel
+m = SyntheticModel.named('mini3')
+ctx = DeviceContext(0)
+m.upload(ctx)
+ctx.upload_counts(m.counts(dense=True))
+z, r = m.random_points(100, seed=8)
+want, _ = ctx.eval(z, r)
+plan = ctx.plan(z, r)
+plan.run(buf.data_ptr() + 8 * 100)            # middle third of the torch tensor
+ctx.sync()
+got = buf.cpu().numpy()
+assert np.all(np.isnan(got[:100])) and np.all(np.isnan(got[200:]))
+np.testing.assert_array_equal(got[100:200], want)
+print('TORCH_TENSOR_OK')
+"""
+
+
+def test_results_land_in_a_torch_device_tensor(tmp_path):
     """bench.py's N > 1 path hands `bi_run_plan` the data pointer of a torch CUDA tensor so that RCCL can
     gather the results without a host round trip: the library must write straight into foreign device
-    memory (same HIP runtime, another allocator)."""
-    import torch
-    from blueice_amd.device import DeviceContext
-    from blueice_amd.synthetic import SyntheticModel
-    m = SyntheticModel.named('mini3')
-    ctx = DeviceContext(0)
-    m.upload(ctx)
-    ctx.upload_counts(m.counts(dense=True))
-    z, r = m.random_points(100, seed=8)
-    want, _ = ctx.eval(z, r)
-    plan = ctx.plan(z, r)
-    buf = torch.full((3 * 100,), float('nan'), dtype=torch.float64, device='cuda:0')
-    torch.cuda.synchronize()
-    plan.run(buf.data_ptr() + 8 * 100)          # middle third
-    ctx.sync()
-    got = buf.cpu().numpy()
-    assert np.all(np.isnan(got[:100])) and np.all(np.isnan(got[200:]))
-    np.testing.assert_array_equal(got[100:200], want)
-    ctx.close()
+    memory.  Run in a fresh process, torch first -- exactly bench.py's order of initialisation."""
+    import subprocess
+    script = tmp_path / 'torch_tensor.py'
+    script.write_text(_TORCH_SCRIPT)
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'TORCH_TENSOR_OK' in res.stdout, res.stdout + res.stderr

@@ -1,0 +1,100 @@
+"""Device-side toy-MC generation (bi_generate_toys): statistical equivalence with Poisson(mu_b) per bin,
+reproducibility, and consistency of the likelihood of generated toys with the uploaded-counts path."""
+import numpy as np
+import pytest
+from scipy import stats
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(mu):
+    """d = 0, one source whose expected counts per bin are exactly `mu`."""
+    from blueice_amd.device import DeviceContext
+    ctx = DeviceContext(0)
+    tot = mu.sum()
+    ctx.upload_model([], (mu / tot)[None, :], np.array([tot]))
+    return ctx
+
+
+def test_poisson_statistics_small_and_large_means():
+    mu = np.concatenate([np.geomspace(0.004, 9.5, 40), np.linspace(10., 80., 24), [0.0, 250.0]])
+    ctx = make_ctx(mu)
+    T = 6000
+    ctx.generate_toys(None, None, T, seed=12345)
+    toys = np.stack([ctx.download_counts(t) for t in range(T)])
+    assert np.all(toys == np.floor(toys)) and np.all(toys >= 0)
+    assert np.all(toys[:, -2] == 0)                              # mu = 0 -> never an event
+    mean, var = toys.mean(axis=0), toys.var(axis=0, ddof=1)
+    se = np.sqrt(np.maximum(mu, 1e-12) / T)
+    assert np.all(np.abs(mean - mu) <= 5 * se + 1e-12), np.max(np.abs(mean - mu) / (se + 1e-12))
+    ok = mu > 0.5
+    assert np.all(np.abs(var[ok] / mu[ok] - 1) < 6 * np.sqrt(2.0 / T) + 3.0 / (mu[ok] * np.sqrt(T)))
+    # frequencies of n = 0, 1, 2 against the pmf (both sampler branches)
+    for b in (5, 25, 39, 45, 60):
+        for k in (0, 1, 2, int(mu[b])):
+            p = stats.poisson(mu[b]).pmf(k)
+            f = np.mean(toys[:, b] == k)
+            assert abs(f - p) <= 5 * np.sqrt(p * (1 - p) / T) + 1e-4, (b, k, f, p)
+    # neighbouring bins / datasets are uncorrelated
+    c = np.corrcoef(toys[:, 50], toys[:, 51])[0, 1]
+    assert abs(c) < 5 / np.sqrt(T)
+    # chi-square of the totals: sum over bins ~ Poisson(sum mu)
+    tot = toys.sum(axis=1)
+    assert abs(tot.mean() - mu.sum()) < 5 * np.sqrt(mu.sum() / T)
+    # reproducible, seed-dependent
+    ctx.generate_toys(None, None, 50, seed=12345)
+    again = np.stack([ctx.download_counts(t) for t in range(50)])
+    np.testing.assert_array_equal(again, toys[:50])
+    ctx.generate_toys(None, None, 50, seed=12346)
+    other = np.stack([ctx.download_counts(t) for t in range(50)])
+    assert not np.array_equal(other, toys[:50])
+    ctx.close()
+
+
+def test_generated_toys_evaluate_like_uploaded_counts():
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    z, r = m.default_point()
+    T = 40
+    ctx.generate_toys(z, 0.02 * r, T, seed=7)          # ~200 events in 4420 bins
+    assert ctx.get_param('csr_ready') == 1 and ctx.get_param('compact_ready') == 1
+    gen, st = ctx.eval_datasets(z, 0.02 * r)
+    pts, _ = ctx.eval(np.tile(z, (T, 1)), np.tile(0.02 * r, (T, 1)), dataset=np.arange(T))
+    np.testing.assert_allclose(pts, gen, rtol=1e-12)
+    dense = np.stack([ctx.download_counts(t) for t in range(T)])
+    assert 100 < dense.sum(axis=1).mean() < 400
+    want = orc.loglikelihood(m.dense_model(), dense[3], z, 0.02 * r)
+    assert abs(gen[3] - want) <= 1e-10 * abs(want)
+    ctx.upload_counts(dense)
+    up, _ = ctx.eval_datasets(z, 0.02 * r)
+    np.testing.assert_allclose(up, gen, rtol=1e-13)
+    # a toy set too big for the compaction budget still serves the toy-MC form; point calls say why not
+    ctx.set_param('compact_budget', 1024)
+    ctx.generate_toys(z, 0.02 * r, T, seed=7)
+    assert ctx.get_param('compact_ready') == 0
+    again, _ = ctx.eval_datasets(z, 0.02 * r)
+    np.testing.assert_array_equal(again, gen)
+    from blueice_amd.exceptions import NotPreparedException
+    with pytest.raises(NotPreparedException):
+        ctx.eval(z, r)
+    ctx.close()
+
+
+def test_simulate_toys_through_the_likelihood_class():
+    import model_zoo
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf, _, _ = model_zoo.d3_small(ns)
+    lf.simulate_toys(300, seed=5, shift=0.2, stretch=-0.3, tilt=0.5, s1_rate_multiplier=2.0)
+    ll = lf.eval_toys(shift=0.2, stretch=-0.3, tilt=0.5, s1_rate_multiplier=2.0)
+    assert ll.shape == (300,) and np.all(np.isfinite(ll))
+    assert abs(lf(shift=0.2, stretch=-0.3, tilt=0.5, s1_rate_multiplier=2.0) - ll[0]) <= 1e-13 * abs(ll[0])
+    mus = lf.ctx.interpolate('mus', [0.2, -0.3, 0.5]) * np.array([1., 2., 1., 1.])
+    n_tot = np.array([lf.ctx.download_counts(t).sum() for t in range(300)])
+    assert abs(n_tot.mean() - mus.sum()) < 5 * np.sqrt(mus.sum() / 300)
+    # the truth should, on average, be favoured over a displaced hypothesis
+    other = lf.eval_toys(shift=-0.8, stretch=0.7, tilt=-0.5, s1_rate_multiplier=0.5)
+    assert np.mean(ll - other) > 0
