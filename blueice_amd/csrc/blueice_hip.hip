@@ -111,6 +111,7 @@ struct LaunchArgs {
     double* partial;        // [items][nbx][G]
     unsigned* pflags;       // [items][nbx][G]
     int64_t B, Bp;
+    double outlier;         // MODE 2: likelihood given to events with a non-positive density (0 = none)
     int n0, n1, n2;         // streams into U (or mu), into P_i, into a
     int n_tiles;
 };
@@ -130,6 +131,7 @@ __device__ __forceinline__ double2 stream_load(const double* p) {
     }
 }
 
+// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
 // MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
 // gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
 // chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
@@ -163,9 +165,24 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
                 acc[g][1] = fma(c, v.y, acc[g][1]);
             }
         }
-        const double2 nv = *reinterpret_cast<const double2*>(cnt + bin0);
+        double2 nv;
+        if constexpr (MODE == 2) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
 
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 2) {
+            // extended unbinned likelihood (blueice/likelihood.py:678-690): the "bins" are the events,
+            // the term is log(sum_s mu_s p_s(x_e)) with the outlier clamp; -sum_s mu_s is added by the host
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (bin0 + j < a.B) {
+                        double lam = acc[g][j];
+                        if (a.outlier != 0.0 && !(lam > 0.0)) lam = a.outlier;
+                        sum[g] += log(lam);
+                    }
+                }
+            }
+        } else if constexpr (MODE == 1) {
             sum[0] += poisson_term(nv.x, acc[0][0]) + poisson_term(nv.y, acc[0][1]);
             const double f0 = (nv.x != 0.0 ? nv.x / acc[0][0] : 0.0) - 1.0;
             const double f1 = (nv.y != 0.0 ? nv.y / acc[0][1] : 0.0) - 1.0;
@@ -786,6 +803,9 @@ struct bi_ctx {
     std::vector<char> anchor_set;
 
     // data
+    bool unbinned = false;      // extended unbinned likelihood: rows are pdf values at the events
+    double outlier = 0.0;
+    bool ps_finite = true;
     bool data_ready = false;
     bool dense_counts = false;  // counts [T][Bp] resident (false for device-generated toys: CSR lists only)
     int64_t T = 0;
@@ -1006,6 +1026,11 @@ struct EventScope {
 
 template <int G>
 void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
+    if (c->unbinned) {
+        if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true, 2>), grid, dim3(kThreads), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_morph_reduce<G, false, false, 2>), grid, dim3(kThreads), 0, c->stream, a);
+        return;
+    }
     if (bb && nt) hipLaunchKernelGGL((k_morph_reduce<G, true, true>), grid, dim3(kThreads), 0, c->stream, a);
     else if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true, false>), grid, dim3(kThreads), 0, c->stream, a);
     else if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true>), grid, dim3(kThreads), 0, c->stream, a);
@@ -1175,7 +1200,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     const int n0 = bb ? nc * (S - 1) : nc * S, n1 = bb ? nc : 0, n2 = bb ? nc : 0, NS = n0 + n1 + n2;
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg;
+    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
     if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
     const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
@@ -1235,6 +1260,11 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     ((int32_t*)(w64 + o + 1))[1] = 0;
     w64[o + 2] = 0;                                                  // perm -> out[0]
     wd[o + 3] = c->h_lgsum[(size_t)ds] + zsum;                       // slot_lg
+    if (c->unbinned) {
+        double rsum = 0.0;
+        for (int s = 0; s < S; ++s) rsum += rates[s];
+        wd[o + 3] = rsum;
+    }
     // the result {ll, status} is written by k_finish straight into the pinned host block (second half)
     char* res = (char*)c->slot_host + bytes;
     *(double*)res = 0.0;
@@ -1254,6 +1284,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     a.partial = (double*)c->slot_partial.p;
     a.pflags = (unsigned*)c->slot_pflags.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
+    a.outlier = c->outlier;
     launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
     const int lanes = nbx > 64 ? kThreads : 64;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kThreads), 0, c->stream, (const double*)a.partial,
@@ -1371,14 +1402,15 @@ int bi_model_begin(bi_ctx* c, int d, const int32_t* n_anchor, const double* anch
     if (!c) return BI_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     if (d < 0 || d > kMaxDim) return fail(c, BI_ERR_INVALID, "d=%d outside [0,%d]", d, kMaxDim);
-    if (S < 1 || B < 1) return fail(c, BI_ERR_INVALID, "need S >= 1 and B >= 1 (got S=%d B=%lld)", S, (long long)B);
+    if (S < 1 || B < 0) return fail(c, BI_ERR_INVALID, "need S >= 1 and B >= 0 (got S=%d B=%lld)", S, (long long)B);
     if (bb_source < -1 || bb_source >= S) return fail(c, BI_ERR_INVALID, "bb_source %d outside [-1,%d)", bb_source, S);
     if (d > 0 && (!n_anchor || !anchor_z)) return fail(c, BI_ERR_INVALID, "anchor arrays are NULL");
     c->model_ready = false;
     c->data_ready = false;  // a new model invalidates the data (likelihood.py:253)
     ++c->epoch;
     c->d = d; c->S = S; c->B = B; c->bb_source = bb_source;
-    c->Bp = (B + kTile - 1) / kTile * kTile;
+    c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile);
+    c->unbinned = false;
     c->n_anchor.assign(d, 0);
     c->grid.assign(d, {});
     c->A = 1;
@@ -1423,10 +1455,10 @@ int bi_model_set_anchor(bi_ctx* c, int64_t ai, const double* ps, const double* m
     if (c->bb_source >= 0 && !nm_row) return fail(c, BI_ERR_INVALID, "Beeston-Barlow model needs the n_model row");
     HIP_TRY(c, hipSetDevice(c->device));
     double* dst = (double*)c->ps.p + (size_t)ai * c->S * c->Bp;
-    HIP_TRY(c, hipMemcpy2DAsync(dst, c->Bp * sizeof(double), ps, c->B * sizeof(double), c->B * sizeof(double), c->S,
+    if (c->B > 0) HIP_TRY(c, hipMemcpy2DAsync(dst, c->Bp * sizeof(double), ps, c->B * sizeof(double), c->B * sizeof(double), c->S,
                                 hipMemcpyHostToDevice, c->stream));
     for (int s = 0; s < c->S; ++s) c->h_mus[(size_t)ai * c->S + s] = mus[s];
-    if (c->bb_source >= 0) {
+    if (c->bb_source >= 0 && c->B > 0) {
         double* nd = (double*)c->nm.p + (size_t)ai * c->Bp;
         HIP_TRY(c, hipMemcpyAsync(nd, nm_row, c->B * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
@@ -1462,9 +1494,11 @@ int bi_model_end(bi_ctx* c) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->h_rowsum.assign((size_t)rows, 0.0);
         c->ps_nonneg = true;
+        c->ps_finite = true;
         for (int64_t r = 0; r < rows; ++r) {
             c->h_rowsum[(size_t)r] = st[(size_t)r * 3];
             if (!(st[(size_t)r * 3 + 1] >= 0.0) || st[(size_t)r * 3 + 2] != 0.0) c->ps_nonneg = false;
+            if (st[(size_t)r * 3 + 2] != 0.0) c->ps_finite = false;
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1481,12 +1515,12 @@ int bi_upload_model(bi_ctx* c, int d, const int32_t* n_anchor, const double* anc
     int rc = bi_model_begin(c, d, n_anchor, anchor_z, S, B, bb_source);
     if (rc) return rc;
     // one strided copy for the whole tensor: rows are (anchor, source)
-    HIP_TRY(c, hipMemcpy2DAsync(c->ps.p, c->Bp * sizeof(double), ps, B * sizeof(double), B * sizeof(double),
+    if (B > 0) HIP_TRY(c, hipMemcpy2DAsync(c->ps.p, c->Bp * sizeof(double), ps, B * sizeof(double), B * sizeof(double),
                                 (size_t)c->A * S, hipMemcpyHostToDevice, c->stream));
     std::copy(mus, mus + (size_t)c->A * S, c->h_mus.begin());
     if (bb_source >= 0) {
         // only row bb_source of every anchor is ever used (likelihood.py:643)
-        HIP_TRY(c, hipMemcpy2DAsync(c->nm.p, c->Bp * sizeof(double), n_model + (size_t)bb_source * B,
+        if (B > 0) HIP_TRY(c, hipMemcpy2DAsync(c->nm.p, c->Bp * sizeof(double), n_model + (size_t)bb_source * B,
                                     (size_t)S * B * sizeof(double), B * sizeof(double), (size_t)c->A,
                                     hipMemcpyHostToDevice, c->stream));
     }
@@ -1509,6 +1543,8 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (T < 1 || !counts) return fail(c, BI_ERR_INVALID, "need T >= 1 datasets and a counts pointer");
+    if (c->unbinned) return fail(c, BI_ERR_STATE, "the context holds an unbinned likelihood: it has no binned counts");
+    if (c->B < 1) return fail(c, BI_ERR_INVALID, "a binned likelihood needs at least one bin");
     HIP_TRY(c, hipSetDevice(c->device));
     c->data_ready = false;
     ++c->epoch;
@@ -1571,7 +1607,7 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
 
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg;
+    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
     const int64_t n_rows = c->A * S;
     if (!sparse && !c->dense_counts)
         return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
@@ -1680,6 +1716,11 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
                     h.aux[ao + (size_t)g * 2 + 1] = Ntot;
                 }
                 h.perm[po + g] = p;
+                if (c->unbinned) {   // ll = -sum_s mu_s + sum_e log(...)   (likelihood.py:690)
+                    double rsum = 0.0;
+                    for (int s = 0; s < S; ++s) rsum += r[s];
+                    h.slot_lg[po + g] = rsum;
+                }
                 if (sparse) {
                     // minus sum_k coef_k * (sum of row k over the empty bins of this dataset)
                     double zsum = 0.0;
@@ -1755,6 +1796,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     a.nm = (const double*)c->nm.p;
     a.counts = plan->sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
     a.B = c->B; a.Bp = c->Bp;
+    a.outlier = c->outlier;
     a.n0 = bb ? nc * (c->S - 1) : nc * c->S;
     a.n1 = bb ? nc : 0; a.n2 = bb ? nc : 0;
     a.n_tiles = n_tiles_of(c);
@@ -1828,6 +1870,7 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "bi_eval_grad is not available with Beeston-Barlow");
+    if (c->unbinned) return fail(c, BI_ERR_INVALID, "bi_eval_grad is implemented for binned likelihoods only");
     if (P < 0 || (P > 0 && (!ll || !grad))) return fail(c, BI_ERR_INVALID, "bad P / output pointers");
     if (c->d > 0 && P > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
     const int S = c->S, d = c->d;
@@ -1979,6 +2022,7 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "bi_eval_datasets is not available with Beeston-Barlow");
+    if (c->unbinned) return fail(c, BI_ERR_INVALID, "bi_eval_datasets needs a binned likelihood");
     if (t0 < 0 || t1 > c->T || t0 > t1) return fail(c, BI_ERR_INVALID, "dataset range [%lld,%lld) outside [0,%lld)", (long long)t0, (long long)t1, (long long)c->T);
     if (c->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
     if (t1 > t0 && !out) return fail(c, BI_ERR_INVALID, "out is NULL");
@@ -2070,6 +2114,7 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (T < 1) return fail(c, BI_ERR_INVALID, "need T >= 1 toys");
+    if (c->B < 1) return fail(c, BI_ERR_INVALID, "a binned likelihood needs at least one bin");
     if (c->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     PointGeom g;
@@ -2183,6 +2228,32 @@ int bi_download_counts(bi_ctx* c, int64_t t, double* out) {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, c->logmu.p, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BI_OK;
+}
+
+
+// ---- extended unbinned likelihood -----------------------------------------------------------------
+
+int bi_set_unbinned(bi_ctx* c, double outlier_likelihood) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "Beeston-Barlow applies to binned likelihoods only");
+    if (!c->ps_finite)
+        return fail(c, BI_ERR_INVALID, "pdf values at the events must be finite (the reference's nansum over sources, "
+                                       "likelihood.py:686, is not reproduced)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ++c->epoch;
+    c->unbinned = true;
+    c->outlier = outlier_likelihood;
+    c->csr_ready = c->compact_ready = false;
+    // one pseudo dataset with zero lgamma sum; the counts row is never read in this mode
+    if ((rc = dev_alloc(c, c->counts, (size_t)c->Bp * sizeof(double)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counts.p, 0, (size_t)c->Bp * sizeof(double), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->T = 1;
+    c->h_lgsum.assign(1, 0.0);
+    c->dense_counts = true;
+    c->data_ready = true;
     return BI_OK;
 }
 

@@ -140,6 +140,11 @@ class DeviceContext:
         self._check(self._lib.bi_upload_counts(self._h, T, ptr(c)))
         self.T = T
 
+    def set_unbinned(self, outlier_likelihood=1e-12):
+        """Treat the uploaded rows as pdf values at the events: extended unbinned likelihood."""
+        self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))
+        self.T = 1
+
     def generate_toys(self, z, rate_scale=None, T=1, seed=0):
         """Replace the data by T Poisson toy datasets drawn on the device at parameter point (z, rate_scale)."""
         z = as_f64(z).reshape(self.d) if self.d else None

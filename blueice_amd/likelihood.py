@@ -29,7 +29,7 @@ from .model import Model
 from .pdf_morphers import MORPHERS
 from .utils import combine_dicts, is_numeric
 
-__all__ = ['LogLikelihoodBase', 'BinnedLogLikelihood']
+__all__ = ['LogLikelihoodBase', 'BinnedLogLikelihood', 'UnbinnedLogLikelihood', 'LogLikelihoodSum']
 
 _BB_FLAGS = _capi.ST_BB_ROOT1 | _capi.ST_BB_NEG
 
@@ -205,46 +205,36 @@ class LogLikelihoodBase:
         return prior, np.asarray(zs, dtype=float), scale
 
 
-class BinnedLogLikelihood(LogLikelihoodBase):
-    """Poisson likelihood over the bins of the analysis space, morph + reduce fused on the GPU."""
+class DeviceLogLikelihood(LogLikelihoodBase):
+    """What the binned and the unbinned likelihood share: one DeviceContext holding the anchor tensor, and
+    evaluation = host bookkeeping + one fused device call."""
+
+    model_statistical_uncertainty_handling = None
 
     def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
         super().__init__(pdf_base_config, likelihood_config, **kwargs)
-        pdf_base_config['pdf_interpolation_method'] = 'piecewise'
-        self.model_statistical_uncertainty_handling = self.config.get('model_statistical_uncertainty_handling')
         self.ps = self.n_model_events = None
         self.ctx = None
-        self._lazy_nm_interpolator = None
+        self.bin_shape = ()
 
-    # -- lifecycle -------------------------------------------------------------------------
     def _bb_source_index(self):
-        if self.model_statistical_uncertainty_handling is None:
-            return -1
-        if self.model_statistical_uncertainty_handling != 'bb_single':
-            raise NotImplementedError("model_statistical_uncertainty_handling=%r" %
-                                      self.model_statistical_uncertainty_handling)
-        src = self.config.get('bb_single_source')
-        if src is None:
-            raise ValueError("You need to specify bb_single_source to use bb_single_source expectation adjustment")
-        return self.base_model.get_source_i(src)
+        return -1
 
-    def prepare(self, *args, **kwargs):
-        super().prepare(*args, **kwargs)
-        self.ps, self.n_model_events = self.base_model.pmf_grids()
-        self.bin_shape = self.ps.shape[1:]
-        S, B = len(self.source_name_list), int(np.prod(self.bin_shape, dtype=np.int64))
+    def _stream_models(self, pmf_of, n_bins):
+        """Fill the device context from the anchor models (or the base model when nothing morphs).
+        pmf_of(model) -> (rows [S, n_bins], MC counts [S, n_bins] or None)."""
+        S = len(self.source_name_list)
         bb = self._bb_source_index()
         if self.ctx is None:
             self.ctx = DeviceContext(self.config.get('device'))
         if len(self.shape_parameters):
-            self.morpher.stream_to_device(self.ctx, self.anchor_models, S, B, bb_source=bb)
+            self.morpher.stream_to_device(self.ctx, self.anchor_models, S, n_bins, bb_source=bb, rows_of=pmf_of)
         else:
-            self.ctx.begin_model([], S, B, bb_source=bb)
-            self.ctx.set_anchor(0, self.ps, self.base_model.expected_events(),
-                                self.n_model_events[bb] if bb >= 0 else None)
+            rows, n_mc = pmf_of(self.base_model)
+            self.ctx.begin_model([], S, n_bins, bb_source=bb)
+            self.ctx.set_anchor(0, rows, self.base_model.expected_events(), n_mc[bb] if bb >= 0 else None)
             self.ctx.end_model()
         self.ctx.set_allow_negative([1 if x else 0 for x in self.source_allowed_negative])
-        self._lazy_nm_interpolator = None
 
     # the morpher closures of the reference, served from the same device context
     def mus_interpolator(self, zs):
@@ -253,50 +243,14 @@ class BinnedLogLikelihood(LogLikelihoodBase):
     def ps_interpolator(self, zs):
         return self.ctx.interpolate('ps', zs).reshape((len(self.source_name_list),) + tuple(self.bin_shape))
 
-    def n_model_events_interpolator(self, zs):
-        if self.model_statistical_uncertainty_handling is None or not len(self.shape_parameters):
-            return None
-        if self._lazy_nm_interpolator is None:      # full [S, *bins] tensor only if somebody asks for it
-            self._lazy_nm_interpolator = self.morpher.make_interpolator(
-                f=lambda m: m.pmf_grids()[1], extra_dims=list(self.ps.shape), anchor_models=self.anchor_models)
-        return self._lazy_nm_interpolator(zs)
+    # hooks of the two concrete likelihoods
+    def _rows_of(self, model):
+        """-> (template rows [S, *bin_shape] of `model`, MC counts or None)."""
+        raise NotImplementedError
 
-    @_needs_preparation
-    def set_data(self, d):
-        """Bin the events of `d` in the analysis space and keep the counts in HBM."""
-        LogLikelihoodBase.set_data(self, d)
-        names, edges = zip(*self.base_model.config['analysis_space'])
-        self.data_events_per_bin = Histdd(bins=edges, axis_names=names)
-        self.data_events_per_bin.add(*self.base_model.to_analysis_dimensions(d))
-        self.ctx.upload_counts(self.data_events_per_bin.histogram)
-
-    @_needs_preparation
-    def set_binned_data(self, counts):
-        """Upload already-binned counts: [*bins] or [T, *bins] for T toy datasets.
-        Dataset 0 is what plain `lf(**params)` evaluates."""
-        counts = np.asarray(counts, dtype=float)
-        if counts.shape[-len(self.bin_shape):] != tuple(self.bin_shape):
-            raise ValueError("counts must end in the analysis-space shape %s" % (tuple(self.bin_shape),))
-        self._data = None
-        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
-        self.data_events_per_bin.histogram = counts.reshape((-1,) + tuple(self.bin_shape))[0].copy()
-        self.ctx.upload_counts(counts)
-        self.is_data_set = True
-
-    @_needs_preparation
-    def simulate_toys(self, n_toys, seed=0, livetime_days=None, **kwargs):
-        """Draw `n_toys` binned toy datasets ON THE DEVICE at the given parameter values and make them the
-        likelihood's data (dataset 0 is what plain `lf(**params)` sees; `eval_toys` evaluates them all).
-        Per bin n ~ Poisson(mu_b): the distribution that `base_model.simulate()` + `set_data()` produces
-        (model.py:69-91, likelihood.py:603-609), without events or host transfers."""
-        prior, zs, scale = self._host_terms(livetime_days, kwargs)
-        if prior is None:
-            raise ValueError("cannot simulate outside the anchor box")
-        self.ctx.generate_toys(zs, scale, n_toys, seed)
-        self._data = None
-        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
-        self.data_events_per_bin.histogram = self.ctx.download_counts(0).reshape(self.bin_shape)
-        self.is_data_set = True
+    def _attach_data(self, ctx):
+        """Give a scratch context the same data this likelihood holds."""
+        raise NotImplementedError
 
     # -- evaluation ------------------------------------------------------------------------
     def _interpret(self, ll, status, mus_hint=None):
@@ -340,7 +294,7 @@ class BinnedLogLikelihood(LogLikelihoodBase):
         if prior is None:
             return -float('inf')
         model = self._compute_single_model(**kwargs)
-        ps, n_mc = model.pmf_grids()
+        ps, n_mc = self._rows_of(model)
         bb = self._bb_source_index()
         scratch = DeviceContext(self.ctx.device)
         try:
@@ -348,7 +302,7 @@ class BinnedLogLikelihood(LogLikelihoodBase):
             scratch.set_anchor(0, ps, model.expected_events(), n_mc[bb] if bb >= 0 else None)
             scratch.end_model()
             scratch.set_allow_negative([1 if x else 0 for x in self.source_allowed_negative])
-            scratch.upload_counts(self.data_events_per_bin.histogram)
+            self._attach_data(scratch)
             if full_output:
                 ll, mus, ps_out, st = scratch.eval_full(None, scale)
                 ll = self._interpret(ll, st, mus)
@@ -357,49 +311,6 @@ class BinnedLogLikelihood(LogLikelihoodBase):
             return prior + self._interpret(float(ll[0]), int(st[0]), model.expected_events() * scale)
         finally:
             scratch.close()
-
-    # -- analytic gradient (one device pass; the reference differentiates numerically) ----------
-    @staticmethod
-    def _prior_slope(log_prior, x):
-        if log_prior is None:
-            return 0.0
-        h = 1e-6 * max(1.0, abs(x))
-        return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
-
-    @_needs_data
-    def value_and_gradient(self, livetime_days=None, **kwargs):
-        """-> (ll, OrderedDict parameter name -> d ll / d parameter) for every registered rate and shape
-        parameter, from ONE pass over the templates (`bi_eval_grad`).  Inside a grid cell ll is smooth in
-        the shape parameters; exactly on an anchor the slope of the cell the point is assigned to is
-        returned.  Prior terms are differentiated numerically on the host (they are Python callables)."""
-        prior, zs, scale = self._host_terms(livetime_days, kwargs)
-        grads = OrderedDict()
-        names = ['%s_rate_multiplier' % s for s in self.rate_parameters] + list(self.shape_parameters)
-        if prior is None:
-            return -float('inf'), OrderedDict((n, float('nan')) for n in names)
-        multipliers, settings = self._kwargs_to_settings(**kwargs)
-        ll, gz, gs, st = self.ctx.eval_grad(zs if len(zs) else None, scale[None, :])
-        ll = self._interpret(float(ll[0]), int(st[0]))
-        gz, gs = gz[0], gs[0]
-        mult = np.array(multipliers, dtype=float)
-        with np.errstate(all='ignore'):
-            per_mult = np.where(mult != 0, scale / np.where(mult != 0, mult, 1.0), 0.0)
-        if np.any(mult == 0):          # d scale / d multiplier does not depend on the multiplier itself
-            _, _, unit = self._host_terms(livetime_days, {k: v for k, v in kwargs.items()
-                                                          if not k.endswith('_rate_multiplier')})
-            per_mult = np.where(mult != 0, per_mult, unit)
-        for s, name in enumerate(self.source_name_list):
-            if name in self.rate_parameters:
-                grads['%s_rate_multiplier' % name] = gs[s] * per_mult[s] + \
-                    self._prior_slope(self.rate_parameters[name], multipliers[s])
-        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
-            g = gz[i] + self._prior_slope(log_prior, settings[name])
-            # a shape parameter that doubles as the efficiency of some sources also scales their rates
-            for s in np.flatnonzero(self.source_apply_efficiency):
-                if self.source_efficiency_names[s] == name and settings[name] != 0:
-                    g += gs[s] * scale[s] / settings[name]
-            grads[name] = g
-        return prior + ll, grads
 
     # -- batched entry points (no counterpart in the reference) --------------------------------
     def _batch_terms(self, points, livetime_days):
@@ -461,6 +372,131 @@ class BinnedLogLikelihood(LogLikelihoodBase):
         out[(st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0] = -np.inf
         return out
 
+
+
+class BinnedLogLikelihood(DeviceLogLikelihood):
+    """Poisson likelihood over the bins of the analysis space, morph + reduce fused on the GPU."""
+
+    def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
+        super().__init__(pdf_base_config, likelihood_config, **kwargs)
+        pdf_base_config['pdf_interpolation_method'] = 'piecewise'
+        self.model_statistical_uncertainty_handling = self.config.get('model_statistical_uncertainty_handling')
+        self._lazy_nm_interpolator = None
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def _bb_source_index(self):
+        if self.model_statistical_uncertainty_handling is None:
+            return -1
+        if self.model_statistical_uncertainty_handling != 'bb_single':
+            raise NotImplementedError("model_statistical_uncertainty_handling=%r" %
+                                      self.model_statistical_uncertainty_handling)
+        src = self.config.get('bb_single_source')
+        if src is None:
+            raise ValueError("You need to specify bb_single_source to use bb_single_source expectation adjustment")
+        return self.base_model.get_source_i(src)
+
+    def prepare(self, *args, **kwargs):
+        super().prepare(*args, **kwargs)
+        self.ps, self.n_model_events = self.base_model.pmf_grids()
+        self.bin_shape = self.ps.shape[1:]
+        self._stream_models(lambda m: m.pmf_grids(), int(np.prod(self.bin_shape, dtype=np.int64)))
+        self._lazy_nm_interpolator = None
+
+    def _rows_of(self, model):
+        return model.pmf_grids()
+
+    def _attach_data(self, ctx):
+        ctx.upload_counts(self.data_events_per_bin.histogram)
+
+    def n_model_events_interpolator(self, zs):
+        if self.model_statistical_uncertainty_handling is None or not len(self.shape_parameters):
+            return None
+        if self._lazy_nm_interpolator is None:      # full [S, *bins] tensor only if somebody asks for it
+            self._lazy_nm_interpolator = self.morpher.make_interpolator(
+                f=lambda m: m.pmf_grids()[1], extra_dims=list(self.ps.shape), anchor_models=self.anchor_models)
+        return self._lazy_nm_interpolator(zs)
+
+    @_needs_preparation
+    def set_data(self, d):
+        """Bin the events of `d` in the analysis space and keep the counts in HBM."""
+        LogLikelihoodBase.set_data(self, d)
+        names, edges = zip(*self.base_model.config['analysis_space'])
+        self.data_events_per_bin = Histdd(bins=edges, axis_names=names)
+        self.data_events_per_bin.add(*self.base_model.to_analysis_dimensions(d))
+        self.ctx.upload_counts(self.data_events_per_bin.histogram)
+
+    @_needs_preparation
+    def set_binned_data(self, counts):
+        """Upload already-binned counts: [*bins] or [T, *bins] for T toy datasets.
+        Dataset 0 is what plain `lf(**params)` evaluates."""
+        counts = np.asarray(counts, dtype=float)
+        if counts.shape[-len(self.bin_shape):] != tuple(self.bin_shape):
+            raise ValueError("counts must end in the analysis-space shape %s" % (tuple(self.bin_shape),))
+        self._data = None
+        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
+        self.data_events_per_bin.histogram = counts.reshape((-1,) + tuple(self.bin_shape))[0].copy()
+        self.ctx.upload_counts(counts)
+        self.is_data_set = True
+
+    @_needs_preparation
+    def simulate_toys(self, n_toys, seed=0, livetime_days=None, **kwargs):
+        """Draw `n_toys` binned toy datasets ON THE DEVICE at the given parameter values and make them the
+        likelihood's data (dataset 0 is what plain `lf(**params)` sees; `eval_toys` evaluates them all).
+        Per bin n ~ Poisson(mu_b): the distribution that `base_model.simulate()` + `set_data()` produces
+        (model.py:69-91, likelihood.py:603-609), without events or host transfers."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is None:
+            raise ValueError("cannot simulate outside the anchor box")
+        self.ctx.generate_toys(zs, scale, n_toys, seed)
+        self._data = None
+        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
+        self.data_events_per_bin.histogram = self.ctx.download_counts(0).reshape(self.bin_shape)
+        self.is_data_set = True
+
+    # -- analytic gradient (one device pass; the reference differentiates numerically) ----------
+    @staticmethod
+    def _prior_slope(log_prior, x):
+        if log_prior is None:
+            return 0.0
+        h = 1e-6 * max(1.0, abs(x))
+        return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
+
+    @_needs_data
+    def value_and_gradient(self, livetime_days=None, **kwargs):
+        """-> (ll, OrderedDict parameter name -> d ll / d parameter) for every registered rate and shape
+        parameter, from ONE pass over the templates (`bi_eval_grad`).  Inside a grid cell ll is smooth in
+        the shape parameters; exactly on an anchor the slope of the cell the point is assigned to is
+        returned.  Prior terms are differentiated numerically on the host (they are Python callables)."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        grads = OrderedDict()
+        names = ['%s_rate_multiplier' % s for s in self.rate_parameters] + list(self.shape_parameters)
+        if prior is None:
+            return -float('inf'), OrderedDict((n, float('nan')) for n in names)
+        multipliers, settings = self._kwargs_to_settings(**kwargs)
+        ll, gz, gs, st = self.ctx.eval_grad(zs if len(zs) else None, scale[None, :])
+        ll = self._interpret(float(ll[0]), int(st[0]))
+        gz, gs = gz[0], gs[0]
+        mult = np.array(multipliers, dtype=float)
+        with np.errstate(all='ignore'):
+            per_mult = np.where(mult != 0, scale / np.where(mult != 0, mult, 1.0), 0.0)
+        if np.any(mult == 0):          # d scale / d multiplier does not depend on the multiplier itself
+            _, _, unit = self._host_terms(livetime_days, {k: v for k, v in kwargs.items()
+                                                          if not k.endswith('_rate_multiplier')})
+            per_mult = np.where(mult != 0, per_mult, unit)
+        for s, name in enumerate(self.source_name_list):
+            if name in self.rate_parameters:
+                grads['%s_rate_multiplier' % name] = gs[s] * per_mult[s] + \
+                    self._prior_slope(self.rate_parameters[name], multipliers[s])
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            g = gz[i] + self._prior_slope(log_prior, settings[name])
+            # a shape parameter that doubles as the efficiency of some sources also scales their rates
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                if self.source_efficiency_names[s] == name and settings[name] != 0:
+                    g += gs[s] * scale[s] / settings[name]
+            grads[name] = g
+        return prior + ll, grads
+
+    # -- toy-MC ---------------------------------------------------------------------------------
     @_needs_data
     def eval_toys(self, livetime_days=None, t0=0, t1=None, **kwargs):
         """One parameter point against every uploaded dataset (see `set_binned_data`): ll [T]."""
@@ -478,8 +514,85 @@ class BinnedLogLikelihood(LogLikelihoodBase):
         return ll + prior if not st else ll
 
 
+class UnbinnedLogLikelihood(DeviceLogLikelihood):
+    """Extended unbinned likelihood, -sum_s mu_s + sum_events log(sum_s mu_s p_s(x_e)), on the same device
+    path (reference: blueice/likelihood.py:528-573, extended_loglikelihood :678-690).  `set_data` scores the
+    events at every anchor model on the host (`Model.score_events`, as the reference does, :557-560) and
+    streams the [anchor][source][event] pdf tensor to HBM; every call is then one fused morph + reduce.
+    Events whose density is not positive get config['outlier_likelihood'] (default 1e-12)."""
+
+    def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
+        super().__init__(pdf_base_config, likelihood_config, **kwargs)
+        self.outlier_likelihood = self.config.get('outlier_likelihood', 1e-12)
+
+    def _rows_of(self, model):
+        return model.score_events(self._data), None
+
+    def _attach_data(self, ctx):
+        ctx.set_unbinned(self.outlier_likelihood)
+
+    @_needs_preparation
+    def set_data(self, d):
+        LogLikelihoodBase.set_data(self, d)
+        self.bin_shape = (len(d),)
+        if not len(self.shape_parameters):
+            self.ps = self.base_model.score_events(d)
+        self._stream_models(self._rows_of, len(d))
+        self.ctx.set_unbinned(self.outlier_likelihood)
+
+
+class LogLikelihoodSum:
+    """Weighted sum of likelihoods sharing (some) parameters, with the likelihood interface the inference
+    helpers need (reference: blueice/likelihood.py:867-955).  A host-side combinator: every term is its own
+    device context and is evaluated with the parameters it knows."""
+
+    def __init__(self, likelihood_list, likelihood_weights=None):
+        self.likelihood_list = list(likelihood_list)
+        self.likelihood_weights = list(likelihood_weights) if likelihood_weights is not None \
+            else [1] * len(self.likelihood_list)
+        self.rate_parameters, self.shape_parameters = dict(), dict()
+        self.pdf_base_config = {}
+        self.source_list = []
+        self.likelihood_parameters = []
+        for ll in self.likelihood_list:
+            self.rate_parameters.update(ll.rate_parameters)
+            self.shape_parameters.update(ll.shape_parameters)
+            names = ['%s_rate_multiplier' % r for r in ll.rate_parameters] + list(ll.shape_parameters)
+            for key in list(ll.rate_parameters) + list(ll.shape_parameters):
+                if ll.pdf_base_config.get(key) is not None:
+                    self.pdf_base_config[key] = ll.pdf_base_config[key]
+            self.likelihood_parameters.append(names)
+
+    def __call__(self, compute_pdf=False, livetime_days=None, **kwargs):
+        total = 0.
+        for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters,
+                                                    self.likelihood_weights)):
+            lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
+            total += weight * ll(compute_pdf=compute_pdf, livetime_days=lt,
+                                 **{k: v for k, v in kwargs.items() if k in names})
+        return total
+
+    def split_results(self, result_dict):
+        return [{k: v for k, v in result_dict.items() if k in names} for names in self.likelihood_parameters]
+
+    def get_bounds(self, parameter_name=None):
+        if parameter_name is None:
+            return [self.get_bounds(p) for p in self.shape_parameters]
+        if parameter_name in self.shape_parameters:
+            b = np.array([ll.get_bounds(parameter_name) for ll in self.likelihood_list
+                          if parameter_name in ll.shape_parameters])
+            lo, hi = np.max(b[:, 0]), np.min(b[:, 1])
+            if hi <= lo:
+                raise InvalidParameterSpecification("lower bound %s higher than upper bound!" % parameter_name)
+            return lo, hi
+        if parameter_name.endswith('_rate_multiplier'):
+            return 0, float('inf')
+        raise InvalidParameter("Non-existing parameter %s" % parameter_name)
+
+
 # inference helpers double as methods, as in the reference (likelihood.py:1004-1007)
 from . import inference  # noqa: E402
 
 for _name in inference.__all__:
-    setattr(LogLikelihoodBase, _name, getattr(inference, _name))
+    for _cls in (LogLikelihoodBase, LogLikelihoodSum):
+        setattr(_cls, _name, getattr(inference, _name))

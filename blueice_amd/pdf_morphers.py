@@ -81,14 +81,16 @@ class GridInterpolator(Morpher):
             scores[multi] = f(anchor_models[zs])
         return DeviceInterpolator(self.anchor_z_arrays, scores, extra_dims, device=self.config.get('device'))
 
-    def stream_to_device(self, ctx, anchor_models, n_sources, n_bins, bb_source=-1):
-        """Fill `ctx` with (pmf grids, expected events[, MC counts of the BB source]) of every anchor
-        model, one anchor at a time -- the dense host tensor of pdf_morphers.py:59 never exists."""
+    def stream_to_device(self, ctx, anchor_models, n_sources, n_bins, bb_source=-1, rows_of=None):
+        """Fill `ctx` with (template rows, expected events[, MC counts of the BB source]) of every anchor
+        model, one anchor at a time -- the dense host tensor of pdf_morphers.py:59 never exists.
+        rows_of(model) -> (rows [S, n_bins], MC counts [S, n_bins] or None); default: the PMF grids."""
+        rows_of = rows_of or (lambda m: m.pmf_grids())
         ctx.begin_model(self.anchor_z_arrays, n_sources, n_bins, bb_source=bb_source)
         for lin, _, zs in self.anchor_items():
             m = anchor_models[zs]
-            pmf, n_mc = m.pmf_grids()
-            ctx.set_anchor(lin, pmf, m.expected_events(), n_mc[bb_source] if bb_source >= 0 else None)
+            rows, n_mc = rows_of(m)
+            ctx.set_anchor(lin, rows, m.expected_events(), n_mc[bb_source] if bb_source >= 0 else None)
         ctx.end_model()
 
 

@@ -87,6 +87,17 @@ int bi_set_allow_negative(bi_ctx* ctx, const int32_t* allow /*[S]*/);
  * (blueice/likelihood.py:603-609).  T datasets of B float64 counts each (toy MC: T > 1). */
 int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
 
+/* Extended unbinned likelihood on the same machinery (UnbinnedLogLikelihood, blueice/likelihood.py:528-573;
+ * extended_loglikelihood :678-690).  Upload the model with B = number of events and `ps` = the pdf values
+ * of every source at every event for every anchor (what `Model.score_events(d)` returns,
+ * likelihood.py:557-560, model.py:97-99), then switch the context:
+ *     ll = -sum_s mu_s + sum_events log( sum_s mu_s p_s(x_e) ),
+ * events whose summed density is not > 0 get `outlier_likelihood` instead when it is non-zero
+ * (config 'outlier_likelihood', default 1e-12, likelihood.py:573,687-689).  No counts are needed;
+ * bi_eval / bi_plan_* / bi_interpolate / bi_eval_full work as for the binned case.  pdf values must be
+ * finite (the reference's nansum over sources is not reproduced).  B = 0 (no events) is allowed. */
+int bi_set_unbinned(bi_ctx* ctx, double outlier_likelihood);
+
 /* Toy-MC datasets generated on the device: n_{t,b} ~ Poisson(mu_b), mu_b = sum_s r_s p_{s,b}(z) -- the binned
  * equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of events per source, each drawn from
  * the source's pdf) followed by set_data's binning (blueice/likelihood.py:603-609).  Philox4x32-10 keyed by

@@ -21,6 +21,9 @@ What is restated (file:line are into the reference tree, JelleAalbers/blueice v1
       with scipy.stats.poisson.logpmf's argument/support handling; logL = np.sum(term).
   a6  BinnedLogLikelihood.adjust_expectations, 'bb_single' (blueice/likelihood.py:618-660)
       with beeston_barlow_root1/2 (:693-712).
+  (next row f-4) extended_loglikelihood (blueice/likelihood.py:678-690) behind
+      UnbinnedLogLikelihood._compute_likelihood (:571-573): -sum mu + sum_e log(nansum_s mu_s p_s(x_e))
+      with the outlier clamp.
 
 Pinning: tests/test_oracle_golden.py checks every function here against
   * the golden fixtures in tests/golden/*.npz, which were produced by importing the real
@@ -35,7 +38,8 @@ from scipy.special import gammaln, xlogy
 
 __all__ = ['find_cell', 'corner_terms', 'interpolate', 'poisson_logpmf', 'compute_likelihood',
            'beeston_barlow_root1', 'beeston_barlow_root2', 'adjust_expectations_bb',
-           'in_bounds', 'rates_at', 'loglikelihood', 'loglikelihood_batch']
+           'in_bounds', 'rates_at', 'loglikelihood', 'loglikelihood_batch',
+           'extended_loglikelihood', 'loglikelihood_unbinned']
 
 
 def find_cell(grid, z):
@@ -214,3 +218,29 @@ def loglikelihood_batch(model, counts, zs, rate_scales, dataset=None, bb_source=
         except AssertionError:
             out[i] = np.nan
     return out
+
+
+def extended_loglikelihood(mu, ps, outlier_likelihood=0.0):
+    """blueice/likelihood.py:678-690."""
+    mu = np.asarray(mu, dtype=float)
+    with np.errstate(all='ignore'):
+        p_events = np.nansum(mu[:, np.newaxis] * np.asarray(ps, dtype=float), axis=0)
+        if outlier_likelihood != 0:
+            p_events[True ^ (p_events > 0)] = outlier_likelihood
+        return -mu.sum() + np.sum(np.log(p_events))
+
+
+def loglikelihood_unbinned(model, z, rate_scale, outlier_likelihood=1e-12, allow_negative=None):
+    """One evaluation of UnbinnedLogLikelihood on explicit tensors: model['ps'] is [A.., S, N_events]
+    (pdf of every source at every event for every anchor), no counts.  Mirrors
+    LogLikelihoodBase.__call__ (likelihood.py:318-427) without priors."""
+    anchor_z = model['anchor_z']
+    z = np.asarray(z, dtype=float)
+    if not in_bounds(anchor_z, z):
+        return -np.inf
+    mus = rates_at(model, z, rate_scale)
+    if allow_negative is None or not any(allow_negative):
+        if not np.all((mus >= 0) & (mus < np.inf)):
+            return -np.inf
+    ps = interpolate(anchor_z, model['ps'], z)
+    return float(extended_loglikelihood(mus, ps.reshape(len(mus), -1), outlier_likelihood))

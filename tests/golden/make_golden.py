@@ -38,8 +38,35 @@ import model_zoo
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def tensors_of_unbinned(lf):
+    """Unbinned: ps = pdf of every source at every event for every anchor [A.., S, N]; no counts."""
+    d = len(lf.shape_parameters)
+    out = {}
+    if d:
+        rgi_ps = lf.ps_interpolator.__closure__[0].cell_contents
+        rgi_mu = lf.mus_interpolator.__closure__[0].cell_contents
+        for i, g in enumerate(rgi_ps.grid):
+            out['anchor_z_%d' % i] = np.asarray(g, dtype=float)
+        out['ps'] = np.asarray(rgi_ps.values, dtype=float)
+        out['mus'] = np.asarray(rgi_mu.values, dtype=float)
+    else:
+        out['ps'] = np.asarray(lf.ps, dtype=float)
+        out['mus'] = np.asarray(lf.base_model.expected_events(), dtype=float)
+    out['d'] = d
+    out['S'] = len(lf.source_name_list)
+    out['bins'] = np.array([out['ps'].shape[-1]])
+    out['counts'] = np.zeros(0)
+    out['bb_source'] = -1
+    out['kind'] = 1
+    out['outlier'] = float(lf.config.get('outlier_likelihood', 1e-12))
+    out['livetime_base'] = float(lf.pdf_base_config.get('livetime_days', np.nan))
+    return out
+
+
 def tensors_of(lf):
     """Pull the anchor tensors out of a prepared reference likelihood."""
+    if type(lf).__name__ == 'UnbinnedLogLikelihood':
+        return tensors_of_unbinned(lf)
     d = len(lf.shape_parameters)
     out = {}
     if d:
@@ -121,7 +148,7 @@ if __name__ == '__main__':
     import scipy
     print('reference blueice', blueice.__version__, 'numpy', np.__version__, 'scipy', scipy.__version__)
     ns = model_zoo.namespace_of('blueice')
-    for name, builder in model_zoo.CASES.items():
+    for name, builder in list(model_zoo.CASES.items()) + list(model_zoo.UNBINNED_CASES.items()):
         lf, calls, full = builder(ns)
         dump(name, lf, calls, full)
     fit_goldens(ns)

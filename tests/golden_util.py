@@ -7,9 +7,18 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def case_names():
+def _all_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
                   if not os.path.basename(p).startswith('fit_'))
+
+
+def case_names():
+    """Binned cases."""
+    return [n for n in _all_names() if not n.startswith('unb_')]
+
+
+def unbinned_case_names():
+    return [n for n in _all_names() if n.startswith('unb_')]
 
 
 def load_case(name):
@@ -21,6 +30,8 @@ def load_case(name):
     case = dict(name=name, d=d, S=int(f['S']), bins=tuple(int(b) for b in f['bins']),
                 model=model, counts=f['counts'], bb_source=int(f['bb_source']),
                 livetime_base=float(f['livetime_base']),
+                kind=int(f['kind']) if 'kind' in f.files else 0,
+                outlier=float(f['outlier']) if 'outlier' in f.files else 0.0,
                 call_z=f['call_z'], call_mult=f['call_mult'], call_livetime=f['call_livetime'],
                 call_ll=f['call_ll'], raw=f)
     return case

@@ -21,6 +21,7 @@ def namespace_of(package):
     src = importlib.import_module(package + '.source')
     th = importlib.import_module(package + '.test_helpers')
     return SimpleNamespace(BinnedLogLikelihood=lk.BinnedLogLikelihood,
+                           UnbinnedLogLikelihood=lk.UnbinnedLogLikelihood, GaussianSource=th.GaussianSource,
                            DensityEstimatingSource=src.DensityEstimatingSource,
                            FixedSampleSource=th.FixedSampleSource, GaussianMCSource=th.GaussianMCSource,
                            conf_for_test=th.conf_for_test, make_data=th.make_data)
@@ -304,6 +305,64 @@ def fit_c1_like(ns):
     space = [['x', np.linspace(-4, 4, 41)]]
     return morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 4000, 300)
 
+
+# ---------------------------------------------------------------------------------------------
+# unbinned cases: analytic Gaussian sources scored at fixed events
+# ---------------------------------------------------------------------------------------------
+def _events(xs):
+    d = np.zeros(len(xs), dtype=[('x', float), ('source', int)])
+    d['x'] = xs
+    return d
+
+
+def unb_ref_value(ns):
+    """tests/test_likelihood.py::test_likelihood_value of the reference."""
+    lf = ns.UnbinnedLogLikelihood(ns.conf_for_test(events_per_day=1))
+    lf.add_rate_parameter('s0')
+    lf.set_data(_events([0.]))
+    return lf, [{}, dict(s0_rate_multiplier=2), dict(s0_rate_multiplier=0.)], (1,)
+
+
+def unb_shape_2src(ns):
+    rng = np.random.default_rng(31)
+    conf = ns.conf_for_test(n_sources=2, events_per_day=15., livetime_days=2.)
+    conf['sources'] = [dict(name='s0', mu=-0.5), dict(name='s1', mu=1.0, sigma=0.7, events_per_day=9.)]
+    lf = ns.UnbinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.add_rate_parameter('s1')
+    lf.add_shape_parameter('sigma', (0.6, 1., 1.5, 2.5))
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 2))
+    lf.prepare()
+    xs = np.concatenate([rng.normal(-0.5, 1.1, 30), rng.normal(1.0, 0.7, 15), [60., -75.]])   # two far outliers
+    lf.set_data(_events(xs))
+    calls = [{}, dict(sigma=0.6), dict(sigma=2.5, some_multiplier=2), dict(sigma=1.2, some_multiplier=0.7),
+             dict(sigma=0.9, some_multiplier=1.6, s0_rate_multiplier=1.4, s1_rate_multiplier=0.3),
+             dict(sigma=1.0, s0_rate_multiplier=0., s1_rate_multiplier=0.), dict(sigma=2.6),
+             dict(sigma=1.3, livetime_days=5.), dict(s1_rate_multiplier=-1.)]
+    return lf, calls, (3,)
+
+
+def unb_d0_three_sources(ns):
+    rng = np.random.default_rng(32)
+    conf = ns.conf_for_test(n_sources=3, events_per_day=5.)
+    conf['sources'] = [dict(name='a', mu=-2.), dict(name='b', mu=0., sigma=2.), dict(name='c', mu=3., events_per_day=1.)]
+    lf = ns.UnbinnedLogLikelihood(conf)
+    lf.add_rate_parameter('a')
+    lf.add_rate_parameter('c')
+    lf.set_data(_events(rng.normal(0, 2.5, 25)))
+    return lf, [{}, dict(a_rate_multiplier=3.), dict(a_rate_multiplier=0., c_rate_multiplier=2.)], (0,)
+
+
+def unb_no_events(ns):
+    lf = ns.UnbinnedLogLikelihood(ns.conf_for_test(events_per_day=3.))
+    lf.add_rate_parameter('s0')
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 2))
+    lf.prepare()
+    lf.set_data(_events([]))
+    return lf, [{}, dict(some_multiplier=1.5, s0_rate_multiplier=2.)], ()
+
+
+UNBINNED_CASES = OrderedDict((f.__name__, f) for f in (unb_ref_value, unb_shape_2src, unb_d0_three_sources, unb_no_events))
 
 CASES = OrderedDict((f.__name__, f) for f in (
     ref_single_bin, ref_zero_bin, ref_multi_bin_single_dim, ref_multi_bin, ref_bb_single_bin,

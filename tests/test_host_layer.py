@@ -40,6 +40,10 @@ class RecordingContext:
         self.counts = np.array(counts, float)
         self.T = self.counts.size // self.B
 
+    def set_unbinned(self, outlier):
+        self.outlier = outlier
+        self.T = 1
+
     def close(self):
         pass
 
@@ -179,3 +183,60 @@ def test_model_simulate_and_source_rates():
     assert 2500 < len(d) < 3500 and set(np.unique(d['source'])) == {0, 1}
     pmf, n_mc = m.pmf_grids()
     assert pmf.shape == (2, 99) and abs(pmf[0].sum() - 1) < 1e-12 and n_mc.sum() == 4000
+
+
+@pytest.mark.parametrize('name', list(model_zoo.UNBINNED_CASES))
+def test_unbinned_uploads_equal_reference_tensors(ns, name):
+    """UnbinnedLogLikelihood.set_data must hand the device the pdf-at-events tensor the reference builds
+    (likelihood.py:557-560)."""
+    lf, calls, _ = model_zoo.UNBINNED_CASES[name](ns)
+    c = load_case(name)
+    rec = lf.ctx
+    n_ev = c['bins'][0]
+    assert rec.S == c['S'] and rec.B == n_ev and rec.bb_source == -1 and rec.outlier == c['outlier']
+    mus_ref = c['model']['mus'].reshape((-1, c['S']))
+    ps_ref = c['model']['ps'].reshape((len(mus_ref), c['S'], n_ev))
+    assert len(rec.anchors) == len(ps_ref)
+    for idx, (ps, mus, nm) in rec.anchors.items():
+        np.testing.assert_array_equal(ps, ps_ref[idx])
+        np.testing.assert_array_equal(mus, mus_ref[idx])
+    for j, kw in enumerate(calls):
+        kw = dict(kw)
+        lt = kw.pop('livetime_days', None)
+        prior, zs, scale = lf._host_terms(lt, kw)
+        if prior is None:
+            continue
+        np.testing.assert_array_equal(zs, c['call_z'][j])
+        np.testing.assert_array_equal(scale, c['call_mult'][j] * (1.0 if lt is None else lt / c['livetime_base']))
+
+
+def test_likelihood_sum_host_logic():
+    from blueice_amd import LogLikelihoodSum
+    from blueice_amd.exceptions import InvalidParameter
+
+    class Fake:
+        def __init__(self, rates, shapes, bounds, value):
+            self.rate_parameters = {r: None for r in rates}
+            self.shape_parameters = {k: ({b[0]: 0, b[1]: 0}, None, None) for k, b in zip(shapes, bounds)}
+            self.pdf_base_config = {k: 1.0 for k in shapes}
+            self._bounds, self.value, self.seen = dict(zip(shapes, bounds)), value, None
+
+        def get_bounds(self, name):
+            return self._bounds[name]
+
+        def __call__(self, compute_pdf=False, livetime_days=None, **kw):
+            self.seen = (livetime_days, dict(kw))
+            return self.value
+
+    a = Fake(['s0'], ['x', 'y'], [(-1, 2), (0, 1)], 3.0)
+    b = Fake(['s1'], ['x'], [(0, 3)], 10.0)
+    tot = LogLikelihoodSum([a, b], likelihood_weights=[1, 0.5])
+    assert tot(x=1, y=0.5, s0_rate_multiplier=2, s1_rate_multiplier=3, livetime_days=[1., 2.]) == 3.0 + 5.0
+    assert a.seen == (1., dict(x=1, y=0.5, s0_rate_multiplier=2)) and b.seen == (2., dict(x=1, s1_rate_multiplier=3))
+    assert tot.get_bounds('x') == (0, 2) and tot.get_bounds('y') == (0, 1)
+    assert tot.get_bounds('s0_rate_multiplier') == (0, float('inf'))
+    with pytest.raises(InvalidParameter):
+        tot.get_bounds('nope')
+    assert tot.split_results(dict(x=1, y=2, s1_rate_multiplier=3)) == [dict(x=1, y=2), dict(x=1, s1_rate_multiplier=3)]
+    objective, names, guess, bounds = tot.make_objective()
+    assert names == ['s0_rate_multiplier', 's1_rate_multiplier', 'x', 'y']

@@ -8,7 +8,7 @@ from scipy import stats
 from scipy.interpolate import RegularGridInterpolator
 
 from oracle import blueice_oracle as orc
-from golden_util import case_names, load_case, rate_scale_of, same
+from golden_util import case_names, load_case, rate_scale_of, same, unbinned_case_names
 
 
 @pytest.mark.parametrize('name', case_names())
@@ -115,3 +115,21 @@ def test_edge_semantics():
     assert c['call_ll'][-1] == -np.inf and c['call_ll'][-2] == -np.inf     # nan z, out-of-box z
     c = load_case('c1_like')
     assert c['call_ll'][8] == -np.inf                                      # negative rate
+
+
+@pytest.mark.parametrize('name', unbinned_case_names())
+def test_unbinned_oracle_matches_reference_goldens(name):
+    """extended_loglikelihood path: oracle vs the reference's UnbinnedLogLikelihood."""
+    c = load_case(name)
+    assert c['kind'] == 1
+    for j, ll_ref in enumerate(c['call_ll']):
+        ll = orc.loglikelihood_unbinned(c['model'], c['call_z'][j], rate_scale_of(c, j), c['outlier'])
+        assert same(ll, ll_ref, rtol=4e-16), (name, j, ll, ll_ref)
+    for key in c['raw'].files:
+        if key.startswith('full_') and key.endswith('_ps'):
+            j = int(key.split('_')[1])
+            ps = orc.interpolate(c['model']['anchor_z'], c['model']['ps'], c['call_z'][j])
+            np.testing.assert_array_equal(ps, c['raw'][key])
+    if name == 'unb_ref_value':            # the reference's own closed forms (test_likelihood_value)
+        assert c['call_ll'][0] == -1 + stats.norm.logpdf(0)
+        assert c['call_ll'][1] == -2 + np.log(2 * stats.norm.pdf(0))

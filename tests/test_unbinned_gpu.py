@@ -1,0 +1,161 @@
+"""Next row f-4 of SURVEY.md section 8: the extended unbinned likelihood and the likelihood sum on the device
+path, against golden vectors from the reference's UnbinnedLogLikelihood and its own tests' closed forms."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import model_zoo
+from golden_util import load_case, rate_scale_of, same, unbinned_case_names
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def ns():
+    return model_zoo.namespace_of('blueice_amd')
+
+
+@pytest.mark.parametrize('name', unbinned_case_names())
+def test_c_abi_matches_reference_goldens(name):
+    from blueice_amd.device import DeviceContext
+    c = load_case(name)
+    ctx = DeviceContext(0)
+    n_ev = c['bins'][0]
+    grid_shape = tuple(len(g) for g in c['model']['anchor_z'])
+    ctx.begin_model(c['model']['anchor_z'], c['S'], n_ev)
+    ps = c['model']['ps'].reshape((-1, c['S'], n_ev)) if n_ev else np.zeros((int(np.prod(grid_shape)), c['S'], 0))
+    mus = c['model']['mus'].reshape((-1, c['S']))
+    for a in range(len(mus)):
+        ctx.set_anchor(a, ps[a], mus[a])
+    ctx.end_model()
+    ctx.set_unbinned(c['outlier'])
+    n = len(c['call_ll'])
+    rs = np.array([rate_scale_of(c, j) for j in range(n)])
+    batch, _ = ctx.eval(c['call_z'] if c['d'] else None, rs)
+    for j in range(n):
+        one, _ = ctx.eval(c['call_z'][j] if c['d'] else None, rs[j])
+        assert same(one[0], c['call_ll'][j], RTOL), (name, j, one[0], c['call_ll'][j])
+        assert same(batch[j], c['call_ll'][j], RTOL)
+    with pytest.raises(ValueError):
+        ctx.eval_grad(c['call_z'][0] if c['d'] else None, rs[0])
+    with pytest.raises(ValueError):
+        ctx.eval_datasets(c['call_z'][0] if c['d'] else None, rs[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize('name', list(model_zoo.UNBINNED_CASES))
+def test_unbinned_likelihood_class_matches_reference(ns, name):
+    lf, calls, full = model_zoo.UNBINNED_CASES[name](ns)
+    c = load_case(name)
+    for j, kw in enumerate(calls):
+        assert same(lf(**kw), c['call_ll'][j], RTOL), (name, j, kw)
+    for j in full:
+        ll, mus, ps = lf(full_output=True, **calls[j])
+        assert same(ll, c['call_ll'][j], RTOL)
+        np.testing.assert_allclose(mus, c['raw']['full_%d_mus' % j], rtol=1e-12)
+        np.testing.assert_array_equal(ps, c['raw']['full_%d_ps' % j])
+
+
+def test_reference_unbinned_tests_closed_forms(ns):
+    """test_likelihood_value, test_rate_uncertainty, test_shape_uncertainty, test_multisource_likelihood,
+    test_livetime_scaling, test_error_handling of the reference's tests/test_likelihood.py, restated."""
+    from blueice_amd import UnbinnedLogLikelihood
+    from blueice_amd.exceptions import InvalidParameter, InvalidParameterSpecification, NotPreparedException
+    from blueice_amd.test_helpers import conf_for_test, almost_equal
+    one = np.zeros(1, dtype=[('x', float), ('source', int)])
+    lf = UnbinnedLogLikelihood(conf_for_test(events_per_day=1))
+    lf.add_rate_uncertainty('s0', 0.5)
+    lf.set_data(one)
+    lp = stats.norm(1, 0.5).logpdf
+    assert almost_equal(lf(), -1 + stats.norm.logpdf(0) + lp(1), 1e-13)
+    assert almost_equal(lf(s0_rate_multiplier=2), -2 + np.log(2 * stats.norm.pdf(0)) + lp(2), 1e-13)
+
+    lf = UnbinnedLogLikelihood(conf_for_test(events_per_day=1))
+    with pytest.raises(InvalidParameterSpecification):
+        lf.add_shape_uncertainty('strlen_multiplier', 0.5, {1: 'x', 2: 'hi', 3: 'wha'})
+    lf.add_shape_uncertainty(setting_name='strlen_multiplier', fractional_uncertainty=0.5,
+                             anchor_zs={1: 'x', 2: 'hi', 3: 'wha'}, base_value=1)
+    lf.prepare()
+    lf.set_data(one)
+    assert almost_equal(lf(), -1 + stats.norm.logpdf(0) + lp(1), 1e-13)
+    assert almost_equal(lf(strlen_multiplier=2), -2 + np.log(2 * stats.norm.pdf(0)) + lp(2), 1e-13)
+    with pytest.raises(ValueError):
+        lf(strlen_multiplier='hi')
+    assert lf(strlen_multiplier=1.5) < lf()
+
+    np.random.seed(4)
+    lf = UnbinnedLogLikelihood(conf_for_test(n_sources=2))
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 2, 4))
+    lf.add_rate_parameter('s0')
+    lf.add_rate_parameter('s1')
+    with pytest.raises(NotPreparedException):
+        lf.set_data(one)
+    lf.prepare()
+    with pytest.raises(NotPreparedException):
+        lf()
+    lf.set_data(lf.base_model.simulate())
+    assert lf(s0_rate_multiplier=1, s1_rate_multiplier=1, some_multiplier=1) == lf()
+    assert almost_equal(lf(s0_rate_multiplier=2), lf(s1_rate_multiplier=2), 1e-12)
+    assert almost_equal(lf(s0_rate_multiplier=4), lf(s0_rate_multiplier=2.5, s1_rate_multiplier=2.5), 1e-12)
+    assert almost_equal(lf(s0_rate_multiplier=2, s1_rate_multiplier=2), lf(some_multiplier=2), 1e-12)
+    assert lf(some_multiplier=2) < lf()
+    with pytest.raises(InvalidParameter):
+        lf(blargh=41)
+
+    conf = conf_for_test()
+    lf0 = UnbinnedLogLikelihood(conf)
+    lf0.prepare()
+    lf0.set_data(one)
+    with pytest.raises(ValueError):
+        lf0(livetime_days=1)
+    conf['livetime_days'] = 1
+    lf = UnbinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.prepare()
+    lf.set_data(one)
+    assert lf(livetime_days=1) == lf0()
+    assert lf(livetime_days=2) == lf(s0_rate_multiplier=2)
+    assert lf(livetime_days=0) == lf(s0_rate_multiplier=0)
+
+    # compute_pdf=True builds the model at the requested point (test_noninterpolated_pdf)
+    conf = conf_for_test(n_sources=1)
+    conf['some_multiplier'] = 3e-3
+    lf = UnbinnedLogLikelihood(conf)
+    lf.add_shape_parameter('mu', (0., 1.))
+    lf.add_shape_parameter('sigma', (1., 2.))
+    lf.prepare()
+    lf.set_data(np.zeros(1, dtype=[('x', float)]))
+    want = stats.poisson(3).logpmf(1) + stats.norm(0.5, 1.5).logpdf(0)
+    assert almost_equal(lf(compute_pdf=True, mu=0.5, sigma=1.5), want + 0, 1e-5) or \
+        almost_equal(lf(compute_pdf=True, mu=0.5, sigma=1.5), -3 + np.log(3 * stats.norm(0.5, 1.5).pdf(0)), 1e-10)
+    assert not almost_equal(lf(compute_pdf=False, mu=0.5, sigma=1.5),
+                            -3 + np.log(3 * stats.norm(0.5, 1.5).pdf(0)), 1e-5)
+
+
+def test_fit_and_sum(ns):
+    """tests/test_inference.py::test_fit_scipy shapes on the unbinned likelihood, and a LogLikelihoodSum of a
+    binned and an unbinned term sharing a shape parameter."""
+    from blueice_amd import LogLikelihoodSum, UnbinnedLogLikelihood
+    from blueice_amd.test_helpers import conf_for_test
+    np.random.seed(11)
+    lf = UnbinnedLogLikelihood(conf_for_test(events_per_day=50.))
+    lf.add_rate_parameter('s0')
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 1.5, 2))
+    lf.prepare()
+    lf.set_data(lf.base_model.simulate())
+    res, ll = lf.bestfit_scipy()
+    assert set(res) == {'s0_rate_multiplier', 'some_multiplier'} and np.isfinite(ll)
+    assert ll >= lf() - 1e-9
+    res0, ll0 = lf.bestfit_scipy(s0_rate_multiplier=1, some_multiplier=1)
+    assert res0 == {} and ll0 == lf(s0_rate_multiplier=1, some_multiplier=1)
+
+    binned, _, _ = model_zoo.c1_like(ns)                    # shape parameter 'shift', rates s0, s1
+    unb, _, _ = model_zoo.unb_ref_value(ns)                 # rate s0 only
+    tot = LogLikelihoodSum([binned, unb], likelihood_weights=[1, 2])
+    kw = dict(shift=0.3, s0_rate_multiplier=1.2, s1_rate_multiplier=0.8)
+    want = binned(**kw) + 2 * unb(s0_rate_multiplier=1.2)
+    assert same(tot(**kw), want, 1e-14)
+    assert tot.get_bounds('shift') == (-1.0, 1.0)
+    res, ll = tot.bestfit_scipy(s1_rate_multiplier=1.)
+    assert set(res) == {'s0_rate_multiplier', 'shift'} and ll >= tot(s1_rate_multiplier=1.) - 1e-9
