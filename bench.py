@@ -41,6 +41,27 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 POOL = 8
 
 
+def cpu_baseline_all_cores(config, n_procs, budget_s=10.0):
+    """N independent host processes (tools/cpu_worker.py), each evaluating its own point with the oracle
+    (BASELINE.md section 4, step 2).  Plain subprocesses: nothing is forked from this GPU-initialised process."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_worker.py'), config]
+    procs = [subprocess.Popen(cmd + [str(500 + i), str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              env=env, text=True) for i in range(n_procs)]
+    rate, done = 0.0, 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s + 120)
+            n, dt = out.split()
+            rate += float(n) / float(dt)
+            done += 1
+        except Exception:
+            p.kill()
+    return dict(value=rate, unit='evals/s', cores=done, kind='port',
+                sample='%d processes x %.0f s of single-thread oracle evaluations, one point each' % (done, budget_s))
+
+
 def cpu_baseline(model, counts, points, budget_s=20.0):
     """Time the oracle (numpy/scipy restatement of the reference path) on this host, one thread."""
     from oracle import blueice_oracle as orc
@@ -286,6 +307,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(model, counts, (z, r))
         result['cpu_baseline']['host_cores_available'] = os.cpu_count()
+        try:
+            n_procs = max(1, min(16, os.cpu_count() or 1))          # a 1-GPU box's CPU share
+            result['cpu_baseline']['all_cores'] = cpu_baseline_all_cores(args.config, n_procs)
+        except Exception as e:                                       # never let the side figure break the line
+            result['cpu_baseline']['all_cores'] = {'error': repr(e)}
     elif rank == 0:
         result['cpu_baseline'] = None
 

@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, 'csrc', 'blueice_hip.hip')
+CSRC = os.path.join(_HERE, 'csrc')
+SRC = os.path.join(CSRC, 'blueice_hip.hip')          # the one translation unit; bi_*.h are included by it
 HDR = os.path.join(os.path.dirname(_HERE), 'include', 'blueice_hip.h')
 OUT_DIR = os.path.join(_HERE, 'lib')
 OUT = os.path.join(OUT_DIR, 'libblueice_hip.so')
@@ -24,7 +25,8 @@ def hipcc():
 def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     if not force and os.path.exists(OUT):
-        newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+        deps = [HDR] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+        newest = max(os.path.getmtime(f) for f in deps)
         if os.path.getmtime(OUT) >= newest:
             return OUT
     cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-shared', '-fPIC',

@@ -1,0 +1,163 @@
+// bi_context.h -- the context / plan objects behind the opaque C handles, error and device-memory helpers.
+#pragma once
+
+namespace {
+
+constexpr int kThreads = 256;           // 4 wave64 per block
+constexpr int kBinsPerThread = 2;       // one 16-byte load per stream per lane
+constexpr int kTile = kThreads * kBinsPerThread;  // 512 bins = 4 KiB per stream per block tile
+constexpr int kMaxDim = 8;              // shape parameters
+constexpr int kMaxG = 16;               // points per cell pass
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct bi_plan {
+    int64_t P = 0;
+    struct Class {
+        int G = 0;
+        int64_t n_items = 0;
+        int nbx = 0;
+        DevBuf rowoff, coef, aux, item_cnt, item_tiles, perm, slot_lg, partial, pflags;
+    };
+    std::vector<Class> classes;
+    DevBuf bad_idx;            // points answered on the host side with -inf
+    int64_t n_bad = 0;
+    DevBuf out, status;        // internal result buffers [P]
+    std::vector<int32_t> h_status;
+    int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    bool no_reuse = false;     // no anchor model is touched by two items of the plan
+    bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
+    int64_t bytes = 0;         // algorithmic HBM bytes per run
+    int64_t launches = 0;
+};
+
+struct bi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::string err;
+
+    // model
+    bool model_ready = false, model_open = false;
+    int d = 0, S = 0;
+    int64_t B = 0, Bp = 0, A = 0;
+    std::vector<int> n_anchor;
+    std::vector<std::vector<double>> grid;
+    std::vector<int64_t> astride;  // anchor-index stride per axis
+    std::vector<int> eff_axes;     // axes with >= 2 anchors
+    int bb_source = -1;
+    std::vector<int32_t> allow_neg;
+    DevBuf ps, nm, nm_tot;
+    std::vector<double> h_mus;     // [A][S]
+    std::vector<double> h_nm_tot;  // [A]
+    std::vector<char> anchor_set;
+
+    // data
+    bool unbinned = false;      // extended unbinned likelihood: rows are pdf values at the events
+    double outlier = 0.0;
+    bool ps_finite = true;
+    bool data_ready = false;
+    bool dense_counts = false;  // counts [T][Bp] resident (false for device-generated toys: CSR lists only)
+    int64_t T = 0;
+    DevBuf counts, lgsum;
+    std::vector<double> h_lgsum;
+
+    // model statistics (for the sparse forms)
+    std::vector<double> h_rowsum;  // [A*S] sum over bins of every ps row
+    bool ps_nonneg = false;        // every ps entry is finite and >= 0
+
+    // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
+    bool csr_ready = false, compact_ready = false;
+    DevBuf nz_idx, nz_n, nz_off, ps_c, cnt_c;
+    std::vector<int64_t> h_nz_off;            // [T+1]
+    std::vector<int64_t> h_c_off, h_cnt_off;  // [T] element offsets into ps_c / cnt_c
+    std::vector<int64_t> h_c_np;              // [T] padded non-empty bins per dataset
+    std::vector<double> h_Tz;                 // [T][A*S] sum of every ps row over the EMPTY bins of the dataset
+
+    // persistent single-point slot (the lf(**kw) call shape): no allocation, one H2D, one D2H per call
+    DevBuf slot_dev, slot_partial, slot_pflags;
+    void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
+    size_t slot_host_bytes = 0;
+
+    // scratch
+    DevBuf scratch, scratch2, logmu;
+
+    int64_t epoch = 0;  // bumped by every model / data upload
+
+    // tunables
+    int64_t blocks_per_cu = 8;
+    int64_t max_group = kMaxG;
+    int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse
+    int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent
+    int64_t compact_budget = (int64_t)16 << 30;  // bytes of HBM the compacted templates may take
+
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+namespace {
+
+int fail(bi_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), BI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return BI_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, BI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return BI_OK;
+}
+
+void dev_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+template <class T>
+int dev_upload(bi_ctx* c, DevBuf& b, const std::vector<T>& h) {
+    int rc = dev_alloc(c, b, h.size() * sizeof(T));
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(c, hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return BI_OK;
+}
+
+void free_plan_buffers(bi_plan* p) {
+    for (auto& k : p->classes) {
+        dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
+        dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
+    }
+    dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status);
+}
+
+}  // namespace

@@ -1,0 +1,711 @@
+// bi_kernels.h -- every __global__ / __device__ function of libblueice_hip (gfx950 only).
+// Included once by blueice_hip.hip; see DESIGN.md section 4 for what each kernel is for and what bounds it.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+    return v;
+}
+
+// Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
+// (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
+//   mu not >= 0 (negative or nan) or n nan -> nan
+//   n negative or non-integer             -> -inf
+//   else xlogy(n, mu) - mu                  (xlogy(0, mu) = 0, also for mu = 0)
+__device__ __forceinline__ double poisson_term(double n, double mu) {
+    double t;
+    if (n > 0.0) {
+        t = n * log(mu) - mu;  // mu = 0 -> -inf; mu < 0 -> nan
+    } else {
+        t = -mu;
+    }
+    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
+    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
+    return t;
+}
+
+// Beeston-Barlow roots, evaluated in the reference's own operation order without FMA
+// contraction (blueice/likelihood.py:693-712) so that the sign tests behind its two asserts
+// see the same rounding.
+__device__ __forceinline__ void bb_roots(double a, double p, double U, double d, double& r1, double& r2) {
+#pragma clang fp contract(off)
+    double U2 = U * U, p2 = p * p, a2 = a * a, d2 = d * d;
+    double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * a * p2 + 2 * U * a * p - 2 * U * d * p2 - 2 * U * d * p +
+                  a2 * p2 + 2 * a * d * p2 + d2 * p2;
+    double lead = -U * p - U + a * p + d * p;
+    double den = 2 * p * (p + 1);
+    double sq = sqrt(disc);
+    r1 = (lead - sq) / den;
+    r2 = (lead + sq) / den;
+}
+
+struct LaunchArgs {
+    const double* ps;       // [rows][Bp]
+    const double* nm;       // [A][Bp] (BB) or null
+    const double* counts;   // [T][Bp]
+    const int64_t* rowoff;  // [items][NS]  element offsets of the stream rows
+    const double* coef;     // [items][NS][G]
+    const double* aux;      // [items][G][2]  (p_cal, N) for BB
+    const int64_t* item_cnt; // [items] element offset of the item's counts row
+    const int32_t* item_tiles; // [items] 512-bin tiles of the item's rows (NULL: n_tiles)
+    double* partial;        // [items][nbx][G]
+    unsigned* pflags;       // [items][nbx][G]
+    int64_t B, Bp;
+    double outlier;         // MODE 2: likelihood given to events with a non-positive density (0 = none)
+    int n0, n1, n2;         // streams into U (or mu), into P_i, into a
+    int n_tiles;
+};
+
+// The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
+// blockIdx.x strides over 512-bin tiles.
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double* p) {
+    if constexpr (NT) {
+        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
+        double2 v;
+        v.x = __builtin_nontemporal_load(p);
+        v.y = __builtin_nontemporal_load(p + 1);
+        return v;
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+
+// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
+// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
+// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
+// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
+template <int G, bool BB, bool NT, int MODE = 0>
+__global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
+    const int item = blockIdx.y;
+    const int NS = a.n0 + a.n1 + a.n2;
+    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
+    const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
+    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
+    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
+
+    double sum[G];
+    unsigned flg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
+        double acc[G][2];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
+
+#pragma unroll 8
+        for (int k = 0; k < a.n0; ++k) {
+            const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double c = coef[k * G + g];
+                acc[g][0] = fma(c, v.x, acc[g][0]);
+                acc[g][1] = fma(c, v.y, acc[g][1]);
+            }
+        }
+        double2 nv;
+        if constexpr (MODE == 2) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
+
+        if constexpr (MODE == 2) {
+            // extended unbinned likelihood (blueice/likelihood.py:678-690): the "bins" are the events,
+            // the term is log(sum_s mu_s p_s(x_e)) with the outlier clamp; -sum_s mu_s is added by the host
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (bin0 + j < a.B) {
+                        double lam = acc[g][j];
+                        if (a.outlier != 0.0 && !(lam > 0.0)) lam = a.outlier;
+                        sum[g] += log(lam);
+                    }
+                }
+            }
+        } else if constexpr (MODE == 1) {
+            sum[0] += poisson_term(nv.x, acc[0][0]) + poisson_term(nv.y, acc[0][1]);
+            const double f0 = (nv.x != 0.0 ? nv.x / acc[0][0] : 0.0) - 1.0;
+            const double f1 = (nv.y != 0.0 ? nv.y / acc[0][1] : 0.0) - 1.0;
+#pragma unroll
+            for (int g = 1; g < G; ++g) sum[g] += f0 * acc[g][0] + f1 * acc[g][1];
+        } else if constexpr (!BB) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                sum[g] += poisson_term(nv.x, acc[g][0]) + poisson_term(nv.y, acc[g][1]);
+            }
+        } else {
+            double pi[G][2], ai[G][2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
+#pragma unroll 4
+            for (int k = 0; k < a.n1; ++k) {
+                const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double c = coef[(a.n0 + k) * G + g];
+                    pi[g][0] = fma(c, v.x, pi[g][0]);
+                    pi[g][1] = fma(c, v.y, pi[g][1]);
+                }
+            }
+#pragma unroll 4
+            for (int k = 0; k < a.n2; ++k) {
+                const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double c = coef[(a.n0 + a.n1 + k) * G + g];
+                    ai[g][0] = fma(c, v.x, ai[g][0]);
+                    ai[g][1] = fma(c, v.y, ai[g][1]);
+                }
+            }
+            const double* __restrict__ aux = a.aux + (int64_t)item * G * 2;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double p_cal = aux[g * 2 + 0];
+                const double Ntot = aux[g * 2 + 1];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (bin0 + j < a.B) {
+                        const double n = j ? nv.y : nv.x;
+                        const double U = acc[g][j];
+                        const double ab = ai[g][j];
+                        // likelihood.py:645-646
+                        const double w = pi[g][j] / ab * Ntot;
+                        double r1, r2;
+                        bb_roots(ab, w * p_cal, U, n, r1, r2);
+                        if (!(r1 <= 0.0)) flg[g] |= BI_ST_BB_ROOT1;
+                        const double A = (U == 0.0) ? (n + ab) / (1.0 + p_cal) : r2;
+                        if (!(0.0 <= A)) flg[g] |= BI_ST_BB_NEG;
+                        const double mu = U + (A * w) * p_cal;
+                        sum[g] += poisson_term(n, mu);
+                    }
+                }
+            }
+        }
+    }
+
+    __shared__ double s_sum[kThreads / 64][G];
+    __shared__ unsigned s_flg[kThreads / 64][G];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const double s = wave_sum(sum[g]);
+        const unsigned f = BB ? wave_or(flg[g]) : 0u;
+        if (lane == 0) { s_sum[wave][g] = s; s_flg[wave][g] = f; }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        const int g = threadIdx.x;
+        double s = s_sum[0][g];
+        unsigned f = s_flg[0][g];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w][g]; f |= s_flg[w][g]; }
+        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * G + g;
+        a.partial[o] = s;
+        a.pflags[o] = f;
+    }
+}
+
+// Sum the per-block partials of every (item, g) in a fixed order, subtract the dataset's
+// sum lgamma(n+1), scatter to the caller's point order.  `lanes` (64 or 256) threads per slot.
+__global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ partial,
+                                                     const unsigned* __restrict__ pflags, int nbx, int G, int lanes,
+                                                     int64_t n_slots, const int64_t* __restrict__ perm,
+                                                     const double* __restrict__ slot_lg, double* __restrict__ out,
+                                                     int32_t* __restrict__ status) {
+    __shared__ double sh[kThreads / 64];
+    __shared__ unsigned shf[kThreads / 64];
+    const int per_block = kThreads / lanes;
+    const int64_t slot = (int64_t)blockIdx.x * per_block + threadIdx.x / lanes;
+    const int l = threadIdx.x % lanes;
+    const bool live = slot < n_slots;
+    const int64_t item = live ? slot / G : 0;
+    const int g = live ? (int)(slot % G) : 0;
+    const int64_t p = live ? perm[slot] : -1;
+    const double lg = live ? slot_lg[slot] : 0.0;
+    double s = 0.0;
+    unsigned f = 0u;
+    if (p >= 0) {
+#pragma unroll 8
+        for (int b = l; b < nbx; b += lanes) {
+            const int64_t o = (item * nbx + b) * G + g;
+            s += partial[o];
+            f |= pflags[o];
+        }
+    }
+    s = wave_sum(s);
+    f = wave_or(f);
+    if (lanes == 64) {
+        if ((threadIdx.x & 63) == 0 && p >= 0) {
+            out[p] = s - lg;
+            if (status) status[p] |= (int32_t)f;
+        }
+        return;
+    }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shf[threadIdx.x >> 6] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0 && p >= 0) {
+        double t = sh[0];
+        unsigned ff = shf[0];
+        for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; ff |= shf[w]; }
+        out[p] = t - lg;
+        if (status) status[p] |= (int32_t)ff;
+    }
+}
+
+__global__ void k_fill_const(double* __restrict__ out, const int64_t* __restrict__ idx, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[idx[i]] = v;
+}
+
+// sum_b lgamma(n_b + 1) over the valid counts of one dataset chunk -> partial[t][blk]
+__global__ __launch_bounds__(kThreads) void k_counts_lgamma(const double* __restrict__ counts, int64_t B, int64_t Bp,
+                                                            double* __restrict__ partial, int nblk) {
+    const int t = blockIdx.y;
+    const double* __restrict__ c = counts + (int64_t)t * Bp;
+    double s = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)nblk * kThreads) {
+        const double n = c[b];
+        if (n > 1.0 && n == floor(n)) s += lgamma(n + 1.0);
+    }
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) r += sh[w];
+        partial[(int64_t)t * nblk + blockIdx.x] = r;
+    }
+}
+
+__global__ void k_rows_sum(const double* __restrict__ partial, int nblk, double* __restrict__ out, int64_t T) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[t * nblk + b];
+    out[t] = s;
+}
+
+// Compatibility morph: out[r][b] = sum_c V[row(c, r)][b] * w_c in the reference's corner order
+// with separate multiply and add (scipy _evaluate_linear: `value = value + term`), i.e.
+// bit-identical to the CPU path.  rows of `src` have stride Bp, rows of `out` stride B.
+__global__ __launch_bounds__(kThreads) void k_morph_store(const double* __restrict__ src,
+                                                          const int64_t* __restrict__ rowoff,  // [R][nc]
+                                                          const double* __restrict__ w,        // [nc]
+                                                          int nc, int64_t B, double* __restrict__ out) {
+    const int r = blockIdx.y;
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    double v = 0.0;
+    for (int c = 0; c < nc; ++c) {
+        const double term = __dmul_rn(src[rowoff[(int64_t)r * nc + c] + b], w[c]);
+        v = __dadd_rn(v, term);
+    }
+    out[(int64_t)r * B + b] = v;
+}
+
+// sum over bins of one padded row -> out[row]  (used for the Beeston-Barlow N table)
+__global__ __launch_bounds__(kThreads) void k_row_total(const double* __restrict__ rows, int64_t B, int64_t Bp,
+                                                        double* __restrict__ out) {
+    const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
+    double s = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += kThreads) s += r[b];
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
+        out[blockIdx.x] = t;
+    }
+}
+
+// full_output with Beeston-Barlow (likelihood.py:634-658) on already-morphed templates:
+// aw[b] = A_b * w_b and per-block partial sums of it.
+__global__ __launch_bounds__(kThreads) void k_bb_full(const double* __restrict__ ps_m, const double* __restrict__ a_row,
+                                                      const double* __restrict__ counts_row,
+                                                      const double* __restrict__ mus, int S, int src, double p_cal,
+                                                      double Ntot, int64_t B, double* __restrict__ aw,
+                                                      double* __restrict__ partial) {
+    double s = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)gridDim.x * kThreads) {
+        double U = 0.0;
+        for (int k = 0; k < S; ++k) {
+            const double e = __dmul_rn(ps_m[(int64_t)k * B + b], k == src ? 0.0 : mus[k]);
+            U = k == 0 ? e : __dadd_rn(U, e);
+        }
+        const double ab = a_row[b];
+        const double w = ps_m[(int64_t)src * B + b] / ab * Ntot;
+        double r1, r2;
+        bb_roots(ab, w * p_cal, U, counts_row[b], r1, r2);
+        const double A = (U == 0.0) ? (counts_row[b] + ab) / (1.0 + p_cal) : r2;
+        const double v = A * w;
+        aw[b] = v;
+        s += v;
+    }
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ void k_bb_normalise(const double* __restrict__ aw, const double* __restrict__ tot, int64_t B,
+                               double* __restrict__ row) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) row[b] = aw[b] / tot[0];
+}
+
+// per padded row: sum over bins, minimum, and a "has non-finite" flag -> out[row*3 + {0,1,2}]
+__global__ __launch_bounds__(kThreads) void k_row_stats(const double* __restrict__ rows, int64_t B, int64_t Bp,
+                                                        double* __restrict__ out) {
+    const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
+    double s = 0.0, mn = __builtin_inf(), bad = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += kThreads) {
+        const double v = r[b];
+        s += v;
+        mn = fmin(mn, v);
+        if (!(fabs(v) < __builtin_inf())) bad = 1.0;
+    }
+    __shared__ double sh[3][kThreads / 64];
+    s = wave_sum(s);
+    bad = wave_sum(bad);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = mn; sh[2][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0][0], m = sh[1][0], f = sh[2][0];
+        for (int w = 1; w < kThreads / 64; ++w) { t += sh[0][w]; m = fmin(m, sh[1][w]); f += sh[2][w]; }
+        out[(int64_t)blockIdx.x * 3 + 0] = t;
+        out[(int64_t)blockIdx.x * 3 + 1] = m;
+        out[(int64_t)blockIdx.x * 3 + 2] = f;
+    }
+}
+
+// ---- non-empty-bin lists (CSR) of the datasets, built in bin order (deterministic) -----------
+constexpr int kNzPerThread = 8;
+constexpr int kNzChunk = kThreads * kNzPerThread;  // 2048 bins per block
+
+__device__ __forceinline__ bool is_nz(double n) { return n != 0.0; }  // true for nan as well
+
+__global__ __launch_bounds__(kThreads) void k_nz_count(const double* __restrict__ counts, int64_t B, int64_t Bp,
+                                                       int32_t* __restrict__ cnt, int nchunks) {
+    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (b0 + j < B && is_nz(c[b0 + j])) ++k;
+    __shared__ int sh[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(kThreads) void k_nz_scatter(const double* __restrict__ counts, int64_t B, int64_t Bp,
+                                                         const int64_t* __restrict__ chunk_off, int nchunks,
+                                                         int32_t* __restrict__ nz_idx, double* __restrict__ nz_n) {
+    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    double v[kNzPerThread];
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j) {
+        v[j] = (b0 + j < B) ? c[b0 + j] : 0.0;
+        if (is_nz(v[j])) ++k;
+    }
+    // exclusive prefix of k over the block, in thread order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __shared__ int sh[kThreads / 64];
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (is_nz(v[j])) {
+            nz_idx[pos] = (int32_t)(b0 + j);
+            nz_n[pos] = v[j];
+            ++pos;
+        }
+}
+
+// compacted templates of one dataset: out[row][j] = rows[row][idx[j]] (0 beyond nnz)
+__global__ __launch_bounds__(kThreads) void k_gather_rows(const double* __restrict__ rows, int64_t Bp,
+                                                          const int32_t* __restrict__ idx, int64_t nnz, int64_t np,
+                                                          double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (j >= np) return;
+    const int64_t row = blockIdx.y;
+    out[row * np + j] = j < nnz ? rows[row * Bp + idx[j]] : 0.0;
+}
+
+__global__ void k_pad_copy(const double* __restrict__ src, int64_t n, int64_t np, double* __restrict__ dst) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < np) dst[j] = j < n ? src[j] : 0.0;
+}
+
+// toy-MC, CSR form: for dataset t: sum_j xlogy(n_j, mu[idx_j]); one block per dataset
+__global__ __launch_bounds__(kThreads) void k_dataset_dot_csr(const int32_t* __restrict__ nz_idx,
+                                                              const double* __restrict__ nz_n,
+                                                              const int64_t* __restrict__ nz_off,
+                                                              const double* __restrict__ logmu, int64_t t0,
+                                                              double* __restrict__ partial) {
+    const int64_t t = t0 + blockIdx.x;
+    const int64_t lo = nz_off[t], hi = nz_off[t + 1];
+    double s = 0.0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += kThreads) {
+        const double n = nz_n[j];
+        double term = n * logmu[nz_idx[j]];
+        if (n != n) term = __builtin_nan("");
+        else if (n < 0.0 || n != floor(n)) term = -__builtin_inf();
+        s += term;
+    }
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) r += sh[w];
+        partial[blockIdx.x] = r;
+    }
+}
+
+// ---- toy-MC generation on the device ---------------------------------------------------------
+// n_{t,b} ~ Poisson(mu_b): the binned equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of
+// events per source, each drawn from the source's pdf) followed by set_data's binning (likelihood.py:603-609).
+// Counter-based Philox4x32-10 keyed by the seed, counter = (bin, dataset, attempt): every (dataset, bin) draw
+// is independent of launch geometry and can be regenerated, which is what lets the two-pass CSR build
+// (count, then scatter) see the same numbers twice.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // uniform on [0, 1) with 53 random bits
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__device__ double poisson_draw(double lam, uint64_t seed, int64_t t, int64_t b) {
+    if (!(lam > 0.0)) return 0.0;  // mu = 0 (or invalid) -> no events
+    uint32_t r[4];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (lam < 10.0) {
+        // inversion by sequential search (one uniform)
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, k0, k1, r);
+        const double u = u53(r[0], r[1]);
+        double p = exp(-lam), F = p;
+        double n = 0.0;
+        while (u > F && n < 1000.0) {
+            n += 1.0;
+            p *= lam / n;
+            F += p;
+        }
+        return n;
+    }
+    // PTRS, Hoermann (1993): transformed rejection with squeeze, as in numpy's random_poisson_ptrs
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb;
+    const double invalpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
+    for (uint32_t attempt = 0; attempt < 4096u; ++attempt) {
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, ((uint32_t)(t >> 32) & 0xFFFFu) | ((attempt + 1u) << 16), k0, k1, r);
+        const double U = u53(r[0], r[1]) - 0.5, V = u53(r[2], r[3]);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * aa / us + bb) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(aa / (us * us) + bb) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam);  // unreachable in practice (acceptance > 0.9 per attempt)
+}
+
+__global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
+                                                        int32_t* __restrict__ cnt, int nchunks) {
+    const int64_t t = t0 + blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    int k = 0;
+#pragma unroll 1
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (b0 + j < B && poisson_draw(mu[b0 + j], seed, t, b0 + j) != 0.0) ++k;
+    __shared__ int sh[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
+                                                          const int64_t* __restrict__ chunk_off, int nchunks,
+                                                          int32_t* __restrict__ nz_idx, double* __restrict__ nz_n,
+                                                          double* __restrict__ lg_partial) {
+    const int64_t t = t0 + blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
+    double v[kNzPerThread];
+    int k = 0;
+    double lg = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < kNzPerThread; ++j) {
+        v[j] = (b0 + j < B) ? poisson_draw(mu[b0 + j], seed, t, b0 + j) : 0.0;
+        if (v[j] != 0.0) { ++k; if (v[j] > 1.0) lg += lgamma(v[j] + 1.0); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int q = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += q;
+    }
+    __shared__ int sh[kThreads / 64];
+    __shared__ double shl[kThreads / 64];
+    lg = wave_sum(lg);
+    if (lane == 63) sh[wave] = incl;
+    if (lane == 0) shl[wave] = lg;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; ++j)
+        if (v[j] != 0.0) {
+            nz_idx[pos] = (int32_t)(b0 + j);
+            nz_n[pos] = v[j];
+            ++pos;
+        }
+    if (threadIdx.x == 0) lg_partial[(int64_t)blockIdx.y * nchunks + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
+}
+
+// densify one dataset from its non-empty-bin list
+__global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __restrict__ n, int64_t nnz,
+                               double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nnz) out[idx[j]] = n[j];
+}
+
+// ---- toy-MC form: one parameter point, many datasets --------------------------------------
+// pass 1: mu_b -> logmu[b] (log mu, or -inf for mu == 0, or nan for invalid mu), partial sum mu
+__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu, int store_mu) {
+    const int64_t* __restrict__ rowoff = a.rowoff;
+    const double* __restrict__ coef = a.coef;
+    double sum = 0.0;
+    unsigned bad = 0u;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
+        double m0 = 0.0, m1 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < a.n0; ++k) {
+            const double2 v = *reinterpret_cast<const double2*>(a.ps + rowoff[k] + bin0);
+            const double c = coef[k];
+            m0 = fma(c, v.x, m0);
+            m1 = fma(c, v.y, m1);
+        }
+        double2 l;
+        if (store_mu) {  // toy generation wants the expectation itself
+            l.x = m0;
+            l.y = m1;
+        } else {
+            l.x = (m0 >= 0.0) ? log(m0) : __builtin_nan("");
+            l.y = (m1 >= 0.0) ? log(m1) : __builtin_nan("");
+        }
+        if (!(m0 >= 0.0) || !(m1 >= 0.0)) bad = 1u;
+        *reinterpret_cast<double2*>(logmu + bin0) = l;
+        sum += m0 + m1;
+    }
+    __shared__ double sh[kThreads / 64];
+    __shared__ unsigned shf[kThreads / 64];
+    sum = wave_sum(sum);
+    bad = wave_or(bad);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = sum; shf[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        unsigned f = shf[0];
+        for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; f |= shf[w]; }
+        a.partial[blockIdx.x] = t;
+        a.pflags[blockIdx.x] = f;
+    }
+}
+
+// pass 2: for dataset t: sum_b xlogy(n_tb, mu_b) ; blockIdx.y = dataset, x strides tiles
+__global__ __launch_bounds__(kThreads) void k_dataset_dot(const double* __restrict__ counts,
+                                                          const double* __restrict__ logmu, int64_t Bp, int n_tiles,
+                                                          int64_t t0, double* __restrict__ partial) {
+    const double* __restrict__ c = counts + (t0 + blockIdx.y) * Bp;
+    double s = 0.0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
+        const double2 n = *reinterpret_cast<const double2*>(c + bin0);
+        const double2 l = *reinterpret_cast<const double2*>(logmu + bin0);
+        double t0v = (n.x > 0.0) ? n.x * l.x : 0.0;
+        double t1v = (n.y > 0.0) ? n.y * l.y : 0.0;
+        if (n.x != n.x) t0v = __builtin_nan("");
+        else if (n.x < 0.0 || n.x != floor(n.x)) t0v = -__builtin_inf();
+        if (n.y != n.y) t1v = __builtin_nan("");
+        else if (n.y < 0.0 || n.y != floor(n.y)) t1v = -__builtin_inf();
+        s += t0v + t1v;
+    }
+    __shared__ double sh[kThreads / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
+        partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// out[t] = sum_blocks partial[t][:] - summu - lgsum[t0 + t]   (nan if any mu invalid)
+__global__ void k_dataset_finish(const double* __restrict__ partial, int nbx, const double* __restrict__ mu_partial,
+                                 const unsigned* __restrict__ mu_flags, int nmu, const double* __restrict__ lgsum,
+                                 int64_t t0, int64_t n, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nbx; ++b) s += partial[t * nbx + b];
+    double m = 0.0;
+    unsigned f = 0u;
+    for (int b = 0; b < nmu; ++b) { m += mu_partial[b]; f |= mu_flags[b]; }
+    double r = (s - m) - lgsum[t0 + t];
+    if (f) r = __builtin_nan("");
+    out[t] = r;
+}
+
+}  // namespace

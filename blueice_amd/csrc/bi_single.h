@@ -1,0 +1,125 @@
+// bi_single.h -- the synchronous single-point fast path behind bi_eval(P = 1).
+#pragma once
+
+namespace {
+
+// One point, synchronous: the call shape of `lf(**kwargs)` inside a minimizer (inference.py:111-122 makes
+// ~500 of them per fit).  Same kernels as the batched path, but the descriptors live in a persistent
+// device slot fed from pinned memory: one small H2D, two launches, one 16-byte D2H, one sync.
+int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds, double* out, int32_t* status) {
+    const int S = c->S;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    if (ds < 0 || ds >= c->T) { *out = ninf; if (status) *status = BI_ST_BAD_DATASET; return BI_OK; }
+    PointGeom g;
+    if (!point_geometry(c, z, g)) { *out = ninf; if (status) *status = BI_ST_OUT_OF_BOUNDS; return BI_OK; }
+    double r[64];
+    std::vector<double> rbig;
+    double* rates = r;
+    if (S > 64) { rbig.resize((size_t)S); rates = rbig.data(); }
+    interp_mus(c, g, rates);
+    if (rate_scale) for (int s = 0; s < S; ++s) rates[s] *= rate_scale[s];
+    if (!rates_physical(c, rates)) { *out = ninf; if (status) *status = BI_ST_UNPHYSICAL; return BI_OK; }
+
+    const bool bb = c->bb_source >= 0;
+    const int nc = (int)g.w.size();
+    const int n0 = bb ? nc * (S - 1) : nc * S, n1 = bb ? nc : 0, n2 = bb ? nc : 0, NS = n0 + n1 + n2;
+    bool any_neg = false;
+    for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
+    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
+    if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
+    const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
+    const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
+    const int tiles = (int)(row_stride / kTile);
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
+    const int nbx = (int)std::min<int64_t>(tiles, slots);
+
+    // slot layout (8-byte units): rowoff[NS] coef[NS] aux[2] cnt_off tiles perm slot_lg | result {ll, status}
+    const size_t n_words = (size_t)NS * 2 + 2 + 4 + 2;
+    const size_t bytes = n_words * 8;
+    int rc;
+    if (c->slot_host_bytes < bytes) {
+        if (c->slot_host) (void)hipHostFree(c->slot_host);
+        c->slot_host = nullptr;
+        HIP_TRY(c, hipHostMalloc(&c->slot_host, bytes * 2, hipHostMallocDefault));
+        c->slot_host_bytes = bytes * 2;
+    }
+    if ((rc = dev_alloc(c, c->slot_dev, bytes)) || (rc = dev_alloc(c, c->slot_partial, (size_t)slots * sizeof(double))) ||
+        (rc = dev_alloc(c, c->slot_pflags, (size_t)slots * sizeof(unsigned))))
+        return rc;
+    int64_t* w64 = (int64_t*)c->slot_host;
+    double* wd = (double*)c->slot_host;
+    int64_t* rowoff = w64;
+    double* coef = wd + NS;
+    double* aux = wd + 2 * NS;
+    int k = 0;
+    double zsum = 0.0;
+    const int64_t n_rows = c->A * S;
+    for (int corner = 0; corner < nc; ++corner) {
+        const int64_t a = g.cell_anchor + corner_offset(c, corner);
+        for (int s = 0; s < S; ++s) {
+            if (bb && s == c->bb_source) continue;
+            rowoff[k] = row_base + (a * S + s) * row_stride;
+            coef[k] = g.w[(size_t)corner] * rates[s];
+            if (sparse) zsum += coef[k] * c->h_Tz[(size_t)(ds * n_rows + a * S + s)];
+            ++k;
+        }
+    }
+    aux[0] = 1.0; aux[1] = 1.0;
+    if (bb) {
+        double Ntot = 0.0;
+        for (int corner = 0; corner < nc; ++corner) {
+            const int64_t a = g.cell_anchor + corner_offset(c, corner);
+            rowoff[n0 + corner] = (a * S + c->bb_source) * c->Bp;
+            coef[n0 + corner] = g.w[(size_t)corner];
+            rowoff[n0 + n1 + corner] = a * c->Bp;
+            coef[n0 + n1 + corner] = g.w[(size_t)corner];
+            const double term = c->h_nm_tot[(size_t)a] * g.w[(size_t)corner];
+            Ntot = Ntot + term;
+        }
+        aux[0] = rates[c->bb_source] / Ntot;
+        aux[1] = Ntot;
+    }
+    const size_t o = (size_t)2 * NS + 2;
+    w64[o + 0] = sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp;   // cnt_off
+    ((int32_t*)(w64 + o + 1))[0] = tiles;                            // tiles (+ pad)
+    ((int32_t*)(w64 + o + 1))[1] = 0;
+    w64[o + 2] = 0;                                                  // perm -> out[0]
+    wd[o + 3] = c->h_lgsum[(size_t)ds] + zsum;                       // slot_lg
+    if (c->unbinned) {
+        double rsum = 0.0;
+        for (int s = 0; s < S; ++s) rsum += rates[s];
+        wd[o + 3] = rsum;
+    }
+    // the result {ll, status} is written by k_finish straight into the pinned host block (second half)
+    char* res = (char*)c->slot_host + bytes;
+    *(double*)res = 0.0;
+    *(int64_t*)(res + 8) = 0;
+
+    char* dev = (char*)c->slot_dev.p;
+    HIP_TRY(c, hipMemcpyAsync(dev, c->slot_host, bytes, hipMemcpyHostToDevice, c->stream));
+    LaunchArgs a{};
+    a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
+    a.nm = (const double*)c->nm.p;
+    a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
+    a.rowoff = (const int64_t*)dev;
+    a.coef = (const double*)(dev + (size_t)NS * 8);
+    a.aux = (const double*)(dev + (size_t)NS * 16);
+    a.item_cnt = (const int64_t*)(dev + (o + 0) * 8);
+    a.item_tiles = (const int32_t*)(dev + (o + 1) * 8);
+    a.partial = (double*)c->slot_partial.p;
+    a.pflags = (unsigned*)c->slot_pflags.p;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
+    a.outlier = c->outlier;
+    launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
+    const int lanes = nbx > 64 ? kThreads : 64;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kThreads), 0, c->stream, (const double*)a.partial,
+                       (const unsigned*)a.pflags, nbx, 1, lanes, (int64_t)1, (const int64_t*)(dev + (o + 2) * 8),
+                       (const double*)(dev + (o + 3) * 8), (double*)res, (int32_t*)(res + 8));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = *(double*)res;
+    if (status) *status = *(int32_t*)(res + 8);
+    return BI_OK;
+}
+
+}  // namespace

@@ -30,1274 +30,20 @@
 #include <limits>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/blueice_hip.h"
 
 #define BI_VERSION "blueice_hip 0.1 (gfx950)"
 
-namespace {
-
-constexpr int kThreads = 256;           // 4 wave64 per block
-constexpr int kBinsPerThread = 2;       // one 16-byte load per stream per lane
-constexpr int kTile = kThreads * kBinsPerThread;  // 512 bins = 4 KiB per stream per block tile
-constexpr int kMaxDim = 8;              // shape parameters
-constexpr int kMaxG = 16;               // points per cell pass
-
-thread_local std::string g_create_error;
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
-// ------------------------------------------------------------------------------------------
-// device code
-// ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ unsigned wave_or(unsigned v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
-    return v;
-}
-
-// Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
-// (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
-//   mu not >= 0 (negative or nan) or n nan -> nan
-//   n negative or non-integer             -> -inf
-//   else xlogy(n, mu) - mu                  (xlogy(0, mu) = 0, also for mu = 0)
-__device__ __forceinline__ double poisson_term(double n, double mu) {
-    double t;
-    if (n > 0.0) {
-        t = n * log(mu) - mu;  // mu = 0 -> -inf; mu < 0 -> nan
-    } else {
-        t = -mu;
-    }
-    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
-    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
-    return t;
-}
-
-// Beeston-Barlow roots, evaluated in the reference's own operation order without FMA
-// contraction (blueice/likelihood.py:693-712) so that the sign tests behind its two asserts
-// see the same rounding.
-__device__ __forceinline__ void bb_roots(double a, double p, double U, double d, double& r1, double& r2) {
-#pragma clang fp contract(off)
-    double U2 = U * U, p2 = p * p, a2 = a * a, d2 = d * d;
-    double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * a * p2 + 2 * U * a * p - 2 * U * d * p2 - 2 * U * d * p +
-                  a2 * p2 + 2 * a * d * p2 + d2 * p2;
-    double lead = -U * p - U + a * p + d * p;
-    double den = 2 * p * (p + 1);
-    double sq = sqrt(disc);
-    r1 = (lead - sq) / den;
-    r2 = (lead + sq) / den;
-}
-
-struct LaunchArgs {
-    const double* ps;       // [rows][Bp]
-    const double* nm;       // [A][Bp] (BB) or null
-    const double* counts;   // [T][Bp]
-    const int64_t* rowoff;  // [items][NS]  element offsets of the stream rows
-    const double* coef;     // [items][NS][G]
-    const double* aux;      // [items][G][2]  (p_cal, N) for BB
-    const int64_t* item_cnt; // [items] element offset of the item's counts row
-    const int32_t* item_tiles; // [items] 512-bin tiles of the item's rows (NULL: n_tiles)
-    double* partial;        // [items][nbx][G]
-    unsigned* pflags;       // [items][nbx][G]
-    int64_t B, Bp;
-    double outlier;         // MODE 2: likelihood given to events with a non-positive density (0 = none)
-    int n0, n1, n2;         // streams into U (or mu), into P_i, into a
-    int n_tiles;
-};
-
-// The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
-// blockIdx.x strides over 512-bin tiles.
-template <bool NT>
-__device__ __forceinline__ double2 stream_load(const double* p) {
-    if constexpr (NT) {
-        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
-        double2 v;
-        v.x = __builtin_nontemporal_load(p);
-        v.y = __builtin_nontemporal_load(p + 1);
-        return v;
-    } else {
-        return *reinterpret_cast<const double2*>(p);
-    }
-}
-
-// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
-// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
-// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
-// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
-template <int G, bool BB, bool NT, int MODE = 0>
-__global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
-    const int item = blockIdx.y;
-    const int NS = a.n0 + a.n1 + a.n2;
-    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
-    const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
-    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
-    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
-
-    double sum[G];
-    unsigned flg[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        double acc[G][2];
-#pragma unroll
-        for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
-
-#pragma unroll 8
-        for (int k = 0; k < a.n0; ++k) {
-            const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const double c = coef[k * G + g];
-                acc[g][0] = fma(c, v.x, acc[g][0]);
-                acc[g][1] = fma(c, v.y, acc[g][1]);
-            }
-        }
-        double2 nv;
-        if constexpr (MODE == 2) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
-
-        if constexpr (MODE == 2) {
-            // extended unbinned likelihood (blueice/likelihood.py:678-690): the "bins" are the events,
-            // the term is log(sum_s mu_s p_s(x_e)) with the outlier clamp; -sum_s mu_s is added by the host
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (bin0 + j < a.B) {
-                        double lam = acc[g][j];
-                        if (a.outlier != 0.0 && !(lam > 0.0)) lam = a.outlier;
-                        sum[g] += log(lam);
-                    }
-                }
-            }
-        } else if constexpr (MODE == 1) {
-            sum[0] += poisson_term(nv.x, acc[0][0]) + poisson_term(nv.y, acc[0][1]);
-            const double f0 = (nv.x != 0.0 ? nv.x / acc[0][0] : 0.0) - 1.0;
-            const double f1 = (nv.y != 0.0 ? nv.y / acc[0][1] : 0.0) - 1.0;
-#pragma unroll
-            for (int g = 1; g < G; ++g) sum[g] += f0 * acc[g][0] + f1 * acc[g][1];
-        } else if constexpr (!BB) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                sum[g] += poisson_term(nv.x, acc[g][0]) + poisson_term(nv.y, acc[g][1]);
-            }
-        } else {
-            double pi[G][2], ai[G][2];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
-#pragma unroll 4
-            for (int k = 0; k < a.n1; ++k) {
-                const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const double c = coef[(a.n0 + k) * G + g];
-                    pi[g][0] = fma(c, v.x, pi[g][0]);
-                    pi[g][1] = fma(c, v.y, pi[g][1]);
-                }
-            }
-#pragma unroll 4
-            for (int k = 0; k < a.n2; ++k) {
-                const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const double c = coef[(a.n0 + a.n1 + k) * G + g];
-                    ai[g][0] = fma(c, v.x, ai[g][0]);
-                    ai[g][1] = fma(c, v.y, ai[g][1]);
-                }
-            }
-            const double* __restrict__ aux = a.aux + (int64_t)item * G * 2;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const double p_cal = aux[g * 2 + 0];
-                const double Ntot = aux[g * 2 + 1];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (bin0 + j < a.B) {
-                        const double n = j ? nv.y : nv.x;
-                        const double U = acc[g][j];
-                        const double ab = ai[g][j];
-                        // likelihood.py:645-646
-                        const double w = pi[g][j] / ab * Ntot;
-                        double r1, r2;
-                        bb_roots(ab, w * p_cal, U, n, r1, r2);
-                        if (!(r1 <= 0.0)) flg[g] |= BI_ST_BB_ROOT1;
-                        const double A = (U == 0.0) ? (n + ab) / (1.0 + p_cal) : r2;
-                        if (!(0.0 <= A)) flg[g] |= BI_ST_BB_NEG;
-                        const double mu = U + (A * w) * p_cal;
-                        sum[g] += poisson_term(n, mu);
-                    }
-                }
-            }
-        }
-    }
-
-    __shared__ double s_sum[kThreads / 64][G];
-    __shared__ unsigned s_flg[kThreads / 64][G];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const double s = wave_sum(sum[g]);
-        const unsigned f = BB ? wave_or(flg[g]) : 0u;
-        if (lane == 0) { s_sum[wave][g] = s; s_flg[wave][g] = f; }
-    }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
-        double s = s_sum[0][g];
-        unsigned f = s_flg[0][g];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w][g]; f |= s_flg[w][g]; }
-        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * G + g;
-        a.partial[o] = s;
-        a.pflags[o] = f;
-    }
-}
-
-// Sum the per-block partials of every (item, g) in a fixed order, subtract the dataset's
-// sum lgamma(n+1), scatter to the caller's point order.  `lanes` (64 or 256) threads per slot.
-__global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ partial,
-                                                     const unsigned* __restrict__ pflags, int nbx, int G, int lanes,
-                                                     int64_t n_slots, const int64_t* __restrict__ perm,
-                                                     const double* __restrict__ slot_lg, double* __restrict__ out,
-                                                     int32_t* __restrict__ status) {
-    __shared__ double sh[kThreads / 64];
-    __shared__ unsigned shf[kThreads / 64];
-    const int per_block = kThreads / lanes;
-    const int64_t slot = (int64_t)blockIdx.x * per_block + threadIdx.x / lanes;
-    const int l = threadIdx.x % lanes;
-    const bool live = slot < n_slots;
-    const int64_t item = live ? slot / G : 0;
-    const int g = live ? (int)(slot % G) : 0;
-    const int64_t p = live ? perm[slot] : -1;
-    const double lg = live ? slot_lg[slot] : 0.0;
-    double s = 0.0;
-    unsigned f = 0u;
-    if (p >= 0) {
-#pragma unroll 8
-        for (int b = l; b < nbx; b += lanes) {
-            const int64_t o = (item * nbx + b) * G + g;
-            s += partial[o];
-            f |= pflags[o];
-        }
-    }
-    s = wave_sum(s);
-    f = wave_or(f);
-    if (lanes == 64) {
-        if ((threadIdx.x & 63) == 0 && p >= 0) {
-            out[p] = s - lg;
-            if (status) status[p] |= (int32_t)f;
-        }
-        return;
-    }
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shf[threadIdx.x >> 6] = f; }
-    __syncthreads();
-    if (threadIdx.x == 0 && p >= 0) {
-        double t = sh[0];
-        unsigned ff = shf[0];
-        for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; ff |= shf[w]; }
-        out[p] = t - lg;
-        if (status) status[p] |= (int32_t)ff;
-    }
-}
-
-__global__ void k_fill_const(double* __restrict__ out, const int64_t* __restrict__ idx, int64_t n, double v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[idx[i]] = v;
-}
-
-// sum_b lgamma(n_b + 1) over the valid counts of one dataset chunk -> partial[t][blk]
-__global__ __launch_bounds__(kThreads) void k_counts_lgamma(const double* __restrict__ counts, int64_t B, int64_t Bp,
-                                                            double* __restrict__ partial, int nblk) {
-    const int t = blockIdx.y;
-    const double* __restrict__ c = counts + (int64_t)t * Bp;
-    double s = 0.0;
-    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)nblk * kThreads) {
-        const double n = c[b];
-        if (n > 1.0 && n == floor(n)) s += lgamma(n + 1.0);
-    }
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) r += sh[w];
-        partial[(int64_t)t * nblk + blockIdx.x] = r;
-    }
-}
-
-__global__ void k_rows_sum(const double* __restrict__ partial, int nblk, double* __restrict__ out, int64_t T) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[t * nblk + b];
-    out[t] = s;
-}
-
-// Compatibility morph: out[r][b] = sum_c V[row(c, r)][b] * w_c in the reference's corner order
-// with separate multiply and add (scipy _evaluate_linear: `value = value + term`), i.e.
-// bit-identical to the CPU path.  rows of `src` have stride Bp, rows of `out` stride B.
-__global__ __launch_bounds__(kThreads) void k_morph_store(const double* __restrict__ src,
-                                                          const int64_t* __restrict__ rowoff,  // [R][nc]
-                                                          const double* __restrict__ w,        // [nc]
-                                                          int nc, int64_t B, double* __restrict__ out) {
-    const int r = blockIdx.y;
-    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (b >= B) return;
-    double v = 0.0;
-    for (int c = 0; c < nc; ++c) {
-        const double term = __dmul_rn(src[rowoff[(int64_t)r * nc + c] + b], w[c]);
-        v = __dadd_rn(v, term);
-    }
-    out[(int64_t)r * B + b] = v;
-}
-
-// sum over bins of one padded row -> out[row]  (used for the Beeston-Barlow N table)
-__global__ __launch_bounds__(kThreads) void k_row_total(const double* __restrict__ rows, int64_t B, int64_t Bp,
-                                                        double* __restrict__ out) {
-    const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
-    double s = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += kThreads) s += r[b];
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
-        out[blockIdx.x] = t;
-    }
-}
-
-// full_output with Beeston-Barlow (likelihood.py:634-658) on already-morphed templates:
-// aw[b] = A_b * w_b and per-block partial sums of it.
-__global__ __launch_bounds__(kThreads) void k_bb_full(const double* __restrict__ ps_m, const double* __restrict__ a_row,
-                                                      const double* __restrict__ counts_row,
-                                                      const double* __restrict__ mus, int S, int src, double p_cal,
-                                                      double Ntot, int64_t B, double* __restrict__ aw,
-                                                      double* __restrict__ partial) {
-    double s = 0.0;
-    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)gridDim.x * kThreads) {
-        double U = 0.0;
-        for (int k = 0; k < S; ++k) {
-            const double e = __dmul_rn(ps_m[(int64_t)k * B + b], k == src ? 0.0 : mus[k]);
-            U = k == 0 ? e : __dadd_rn(U, e);
-        }
-        const double ab = a_row[b];
-        const double w = ps_m[(int64_t)src * B + b] / ab * Ntot;
-        double r1, r2;
-        bb_roots(ab, w * p_cal, U, counts_row[b], r1, r2);
-        const double A = (U == 0.0) ? (counts_row[b] + ab) / (1.0 + p_cal) : r2;
-        const double v = A * w;
-        aw[b] = v;
-        s += v;
-    }
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
-        partial[blockIdx.x] = t;
-    }
-}
-
-__global__ void k_bb_normalise(const double* __restrict__ aw, const double* __restrict__ tot, int64_t B,
-                               double* __restrict__ row) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) row[b] = aw[b] / tot[0];
-}
-
-// per padded row: sum over bins, minimum, and a "has non-finite" flag -> out[row*3 + {0,1,2}]
-__global__ __launch_bounds__(kThreads) void k_row_stats(const double* __restrict__ rows, int64_t B, int64_t Bp,
-                                                        double* __restrict__ out) {
-    const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
-    double s = 0.0, mn = __builtin_inf(), bad = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += kThreads) {
-        const double v = r[b];
-        s += v;
-        mn = fmin(mn, v);
-        if (!(fabs(v) < __builtin_inf())) bad = 1.0;
-    }
-    __shared__ double sh[3][kThreads / 64];
-    s = wave_sum(s);
-    bad = wave_sum(bad);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = mn; sh[2][threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0][0], m = sh[1][0], f = sh[2][0];
-        for (int w = 1; w < kThreads / 64; ++w) { t += sh[0][w]; m = fmin(m, sh[1][w]); f += sh[2][w]; }
-        out[(int64_t)blockIdx.x * 3 + 0] = t;
-        out[(int64_t)blockIdx.x * 3 + 1] = m;
-        out[(int64_t)blockIdx.x * 3 + 2] = f;
-    }
-}
-
-// ---- non-empty-bin lists (CSR) of the datasets, built in bin order (deterministic) -----------
-constexpr int kNzPerThread = 8;
-constexpr int kNzChunk = kThreads * kNzPerThread;  // 2048 bins per block
-
-__device__ __forceinline__ bool is_nz(double n) { return n != 0.0; }  // true for nan as well
-
-__global__ __launch_bounds__(kThreads) void k_nz_count(const double* __restrict__ counts, int64_t B, int64_t Bp,
-                                                       int32_t* __restrict__ cnt, int nchunks) {
-    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
-    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
-    int k = 0;
-#pragma unroll
-    for (int j = 0; j < kNzPerThread; ++j)
-        if (b0 + j < B && is_nz(c[b0 + j])) ++k;
-    __shared__ int sh[kThreads / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-__global__ __launch_bounds__(kThreads) void k_nz_scatter(const double* __restrict__ counts, int64_t B, int64_t Bp,
-                                                         const int64_t* __restrict__ chunk_off, int nchunks,
-                                                         int32_t* __restrict__ nz_idx, double* __restrict__ nz_n) {
-    const double* __restrict__ c = counts + (int64_t)blockIdx.y * Bp;
-    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
-    double v[kNzPerThread];
-    int k = 0;
-#pragma unroll
-    for (int j = 0; j < kNzPerThread; ++j) {
-        v[j] = (b0 + j < B) ? c[b0 + j] : 0.0;
-        if (is_nz(v[j])) ++k;
-    }
-    // exclusive prefix of k over the block, in thread order
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = k;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    __shared__ int sh[kThreads / 64];
-    if (lane == 63) sh[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += sh[w];
-    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
-#pragma unroll
-    for (int j = 0; j < kNzPerThread; ++j)
-        if (is_nz(v[j])) {
-            nz_idx[pos] = (int32_t)(b0 + j);
-            nz_n[pos] = v[j];
-            ++pos;
-        }
-}
-
-// compacted templates of one dataset: out[row][j] = rows[row][idx[j]] (0 beyond nnz)
-__global__ __launch_bounds__(kThreads) void k_gather_rows(const double* __restrict__ rows, int64_t Bp,
-                                                          const int32_t* __restrict__ idx, int64_t nnz, int64_t np,
-                                                          double* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (j >= np) return;
-    const int64_t row = blockIdx.y;
-    out[row * np + j] = j < nnz ? rows[row * Bp + idx[j]] : 0.0;
-}
-
-__global__ void k_pad_copy(const double* __restrict__ src, int64_t n, int64_t np, double* __restrict__ dst) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < np) dst[j] = j < n ? src[j] : 0.0;
-}
-
-// toy-MC, CSR form: for dataset t: sum_j xlogy(n_j, mu[idx_j]); one block per dataset
-__global__ __launch_bounds__(kThreads) void k_dataset_dot_csr(const int32_t* __restrict__ nz_idx,
-                                                              const double* __restrict__ nz_n,
-                                                              const int64_t* __restrict__ nz_off,
-                                                              const double* __restrict__ logmu, int64_t t0,
-                                                              double* __restrict__ partial) {
-    const int64_t t = t0 + blockIdx.x;
-    const int64_t lo = nz_off[t], hi = nz_off[t + 1];
-    double s = 0.0;
-    for (int64_t j = lo + threadIdx.x; j < hi; j += kThreads) {
-        const double n = nz_n[j];
-        double term = n * logmu[nz_idx[j]];
-        if (n != n) term = __builtin_nan("");
-        else if (n < 0.0 || n != floor(n)) term = -__builtin_inf();
-        s += term;
-    }
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) r += sh[w];
-        partial[blockIdx.x] = r;
-    }
-}
-
-// ---- toy-MC generation on the device ---------------------------------------------------------
-// n_{t,b} ~ Poisson(mu_b): the binned equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of
-// events per source, each drawn from the source's pdf) followed by set_data's binning (likelihood.py:603-609).
-// Counter-based Philox4x32-10 keyed by the seed, counter = (bin, dataset, attempt): every (dataset, bin) draw
-// is independent of launch geometry and can be regenerated, which is what lets the two-pass CSR build
-// (count, then scatter) see the same numbers twice.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // uniform on [0, 1) with 53 random bits
-    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
-}
-
-__device__ double poisson_draw(double lam, uint64_t seed, int64_t t, int64_t b) {
-    if (!(lam > 0.0)) return 0.0;  // mu = 0 (or invalid) -> no events
-    uint32_t r[4];
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (lam < 10.0) {
-        // inversion by sequential search (one uniform)
-        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, k0, k1, r);
-        const double u = u53(r[0], r[1]);
-        double p = exp(-lam), F = p;
-        double n = 0.0;
-        while (u > F && n < 1000.0) {
-            n += 1.0;
-            p *= lam / n;
-            F += p;
-        }
-        return n;
-    }
-    // PTRS, Hoermann (1993): transformed rejection with squeeze, as in numpy's random_poisson_ptrs
-    const double slam = sqrt(lam), loglam = log(lam);
-    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb;
-    const double invalpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
-    for (uint32_t attempt = 0; attempt < 4096u; ++attempt) {
-        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, ((uint32_t)(t >> 32) & 0xFFFFu) | ((attempt + 1u) << 16), k0, k1, r);
-        const double U = u53(r[0], r[1]) - 0.5, V = u53(r[2], r[3]);
-        const double us = 0.5 - fabs(U);
-        const double k = floor((2.0 * aa / us + bb) * U + lam + 0.43);
-        if (us >= 0.07 && V <= vr) return k;
-        if (k < 0.0 || (us < 0.013 && V > us)) continue;
-        if (log(V) + log(invalpha) - log(aa / (us * us) + bb) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
-    }
-    return floor(lam);  // unreachable in practice (acceptance > 0.9 per attempt)
-}
-
-__global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
-                                                        int32_t* __restrict__ cnt, int nchunks) {
-    const int64_t t = t0 + blockIdx.y;
-    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
-    int k = 0;
-#pragma unroll 1
-    for (int j = 0; j < kNzPerThread; ++j)
-        if (b0 + j < B && poisson_draw(mu[b0 + j], seed, t, b0 + j) != 0.0) ++k;
-    __shared__ int sh[kThreads / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-__global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
-                                                          const int64_t* __restrict__ chunk_off, int nchunks,
-                                                          int32_t* __restrict__ nz_idx, double* __restrict__ nz_n,
-                                                          double* __restrict__ lg_partial) {
-    const int64_t t = t0 + blockIdx.y;
-    const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
-    double v[kNzPerThread];
-    int k = 0;
-    double lg = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < kNzPerThread; ++j) {
-        v[j] = (b0 + j < B) ? poisson_draw(mu[b0 + j], seed, t, b0 + j) : 0.0;
-        if (v[j] != 0.0) { ++k; if (v[j] > 1.0) lg += lgamma(v[j] + 1.0); }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = k;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int q = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += q;
-    }
-    __shared__ int sh[kThreads / 64];
-    __shared__ double shl[kThreads / 64];
-    lg = wave_sum(lg);
-    if (lane == 63) sh[wave] = incl;
-    if (lane == 0) shl[wave] = lg;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += sh[w];
-    int64_t pos = chunk_off[(int64_t)blockIdx.y * nchunks + blockIdx.x] + base + incl - k;
-#pragma unroll
-    for (int j = 0; j < kNzPerThread; ++j)
-        if (v[j] != 0.0) {
-            nz_idx[pos] = (int32_t)(b0 + j);
-            nz_n[pos] = v[j];
-            ++pos;
-        }
-    if (threadIdx.x == 0) lg_partial[(int64_t)blockIdx.y * nchunks + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
-}
-
-// densify one dataset from its non-empty-bin list
-__global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __restrict__ n, int64_t nnz,
-                               double* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nnz) out[idx[j]] = n[j];
-}
-
-// ---- toy-MC form: one parameter point, many datasets --------------------------------------
-// pass 1: mu_b -> logmu[b] (log mu, or -inf for mu == 0, or nan for invalid mu), partial sum mu
-__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu, int store_mu) {
-    const int64_t* __restrict__ rowoff = a.rowoff;
-    const double* __restrict__ coef = a.coef;
-    double sum = 0.0;
-    unsigned bad = 0u;
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        double m0 = 0.0, m1 = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < a.n0; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(a.ps + rowoff[k] + bin0);
-            const double c = coef[k];
-            m0 = fma(c, v.x, m0);
-            m1 = fma(c, v.y, m1);
-        }
-        double2 l;
-        if (store_mu) {  // toy generation wants the expectation itself
-            l.x = m0;
-            l.y = m1;
-        } else {
-            l.x = (m0 >= 0.0) ? log(m0) : __builtin_nan("");
-            l.y = (m1 >= 0.0) ? log(m1) : __builtin_nan("");
-        }
-        if (!(m0 >= 0.0) || !(m1 >= 0.0)) bad = 1u;
-        *reinterpret_cast<double2*>(logmu + bin0) = l;
-        sum += m0 + m1;
-    }
-    __shared__ double sh[kThreads / 64];
-    __shared__ unsigned shf[kThreads / 64];
-    sum = wave_sum(sum);
-    bad = wave_or(bad);
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = sum; shf[threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0];
-        unsigned f = shf[0];
-        for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; f |= shf[w]; }
-        a.partial[blockIdx.x] = t;
-        a.pflags[blockIdx.x] = f;
-    }
-}
-
-// pass 2: for dataset t: sum_b xlogy(n_tb, mu_b) ; blockIdx.y = dataset, x strides tiles
-__global__ __launch_bounds__(kThreads) void k_dataset_dot(const double* __restrict__ counts,
-                                                          const double* __restrict__ logmu, int64_t Bp, int n_tiles,
-                                                          int64_t t0, double* __restrict__ partial) {
-    const double* __restrict__ c = counts + (t0 + blockIdx.y) * Bp;
-    double s = 0.0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        const double2 n = *reinterpret_cast<const double2*>(c + bin0);
-        const double2 l = *reinterpret_cast<const double2*>(logmu + bin0);
-        double t0v = (n.x > 0.0) ? n.x * l.x : 0.0;
-        double t1v = (n.y > 0.0) ? n.y * l.y : 0.0;
-        if (n.x != n.x) t0v = __builtin_nan("");
-        else if (n.x < 0.0 || n.x != floor(n.x)) t0v = -__builtin_inf();
-        if (n.y != n.y) t1v = __builtin_nan("");
-        else if (n.y < 0.0 || n.y != floor(n.y)) t1v = -__builtin_inf();
-        s += t0v + t1v;
-    }
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
-        partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
-    }
-}
-
-// out[t] = sum_blocks partial[t][:] - summu - lgsum[t0 + t]   (nan if any mu invalid)
-__global__ void k_dataset_finish(const double* __restrict__ partial, int nbx, const double* __restrict__ mu_partial,
-                                 const unsigned* __restrict__ mu_flags, int nmu, const double* __restrict__ lgsum,
-                                 int64_t t0, int64_t n, double* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nbx; ++b) s += partial[t * nbx + b];
-    double m = 0.0;
-    unsigned f = 0u;
-    for (int b = 0; b < nmu; ++b) { m += mu_partial[b]; f |= mu_flags[b]; }
-    double r = (s - m) - lgsum[t0 + t];
-    if (f) r = __builtin_nan("");
-    out[t] = r;
-}
-
-}  // namespace
-
-// ------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------
-
-struct bi_plan {
-    int64_t P = 0;
-    struct Class {
-        int G = 0;
-        int64_t n_items = 0;
-        int nbx = 0;
-        DevBuf rowoff, coef, aux, item_cnt, item_tiles, perm, slot_lg, partial, pflags;
-    };
-    std::vector<Class> classes;
-    DevBuf bad_idx;            // points answered on the host side with -inf
-    int64_t n_bad = 0;
-    DevBuf out, status;        // internal result buffers [P]
-    std::vector<int32_t> h_status;
-    int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
-    bool no_reuse = false;     // no anchor model is touched by two items of the plan
-    bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
-    int64_t bytes = 0;         // algorithmic HBM bytes per run
-    int64_t launches = 0;
-};
-
-struct bi_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipDeviceProp_t prop{};
-    std::string err;
-
-    // model
-    bool model_ready = false, model_open = false;
-    int d = 0, S = 0;
-    int64_t B = 0, Bp = 0, A = 0;
-    std::vector<int> n_anchor;
-    std::vector<std::vector<double>> grid;
-    std::vector<int64_t> astride;  // anchor-index stride per axis
-    std::vector<int> eff_axes;     // axes with >= 2 anchors
-    int bb_source = -1;
-    std::vector<int32_t> allow_neg;
-    DevBuf ps, nm, nm_tot;
-    std::vector<double> h_mus;     // [A][S]
-    std::vector<double> h_nm_tot;  // [A]
-    std::vector<char> anchor_set;
-
-    // data
-    bool unbinned = false;      // extended unbinned likelihood: rows are pdf values at the events
-    double outlier = 0.0;
-    bool ps_finite = true;
-    bool data_ready = false;
-    bool dense_counts = false;  // counts [T][Bp] resident (false for device-generated toys: CSR lists only)
-    int64_t T = 0;
-    DevBuf counts, lgsum;
-    std::vector<double> h_lgsum;
-
-    // model statistics (for the sparse forms)
-    std::vector<double> h_rowsum;  // [A*S] sum over bins of every ps row
-    bool ps_nonneg = false;        // every ps entry is finite and >= 0
-
-    // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
-    bool csr_ready = false, compact_ready = false;
-    DevBuf nz_idx, nz_n, nz_off, ps_c, cnt_c;
-    std::vector<int64_t> h_nz_off;            // [T+1]
-    std::vector<int64_t> h_c_off, h_cnt_off;  // [T] element offsets into ps_c / cnt_c
-    std::vector<int64_t> h_c_np;              // [T] padded non-empty bins per dataset
-    std::vector<double> h_Tz;                 // [T][A*S] sum of every ps row over the EMPTY bins of the dataset
-
-    // persistent single-point slot (the lf(**kw) call shape): no allocation, one H2D, one D2H per call
-    DevBuf slot_dev, slot_partial, slot_pflags;
-    void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
-    size_t slot_host_bytes = 0;
-
-    // scratch
-    DevBuf scratch, scratch2, logmu;
-
-    int64_t epoch = 0;  // bumped by every model / data upload
-
-    // tunables
-    int64_t blocks_per_cu = 8;
-    int64_t max_group = kMaxG;
-    int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse
-    int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent
-    int64_t compact_budget = (int64_t)16 << 30;  // bytes of HBM the compacted templates may take
-
-    // profiling
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    int64_t prof_launches = 0;
-    double prof_ms = 0.0;
-};
-
-namespace {
-
-int fail(bi_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define HIP_TRY(c, expr)                                                                          \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail((c), BI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
-    if (b.p && b.bytes >= bytes) return BI_OK;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&b.p, bytes);
-    if (e != hipSuccess) {
-        b.p = nullptr;
-        return fail(c, BI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-    }
-    b.bytes = bytes;
-    return BI_OK;
-}
-
-void dev_free(DevBuf& b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
-}
-
-template <class T>
-int dev_upload(bi_ctx* c, DevBuf& b, const std::vector<T>& h) {
-    int rc = dev_alloc(c, b, h.size() * sizeof(T));
-    if (rc) return rc;
-    if (!h.empty()) HIP_TRY(c, hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    return BI_OK;
-}
-
-void free_plan_buffers(bi_plan* p) {
-    for (auto& k : p->classes) {
-        dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
-        dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
-    }
-    dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status);
-}
-
-// scipy find_indices semantics on one axis (oracle/blueice_oracle.py:find_cell)
-inline void find_cell(const std::vector<double>& g, double z, int& k, double& t) {
-    const int n = (int)g.size();
-    if (n == 1) { k = 0; t = 0.0; return; }
-    if (z == g[n - 1]) {
-        k = n - 2;
-    } else {
-        k = (int)(std::upper_bound(g.begin(), g.end(), z) - g.begin()) - 1;
-        k = std::min(std::max(k, 0), n - 2);
-    }
-    const double denom = g[k + 1] - g[k];
-    t = (z - g[k]) / denom;
-}
-
-struct PointGeom {
-    int64_t cell_anchor;          // linear anchor index of the lower corner
-    std::vector<double> w;        // [2^deff] corner weights, reference order
-    double t[kMaxDim];            // per axis: normalised distance in the cell
-    double inv_delta[kMaxDim];    // per axis: 1 / (g[k+1] - g[k])  (0 for single-anchor axes)
-};
-
-// corner c (bit i from the most significant = effective axis 0) -> anchor offset
-inline int64_t corner_offset(const bi_ctx* c, int corner) {
-    const int de = (int)c->eff_axes.size();
-    int64_t off = 0;
-    for (int i = 0; i < de; ++i)
-        if ((corner >> (de - 1 - i)) & 1) off += c->astride[c->eff_axes[i]];
-    return off;
-}
-
-// returns false when z is outside the anchor box (or nan): likelihood.py:345-347
-bool point_geometry(const bi_ctx* c, const double* z, PointGeom& g) {
-    for (int i = 0; i < c->d; ++i) {
-        const auto& gr = c->grid[i];
-        if (!(gr.front() <= z[i] && z[i] <= gr.back())) return false;
-    }
-    const int de = (int)c->eff_axes.size();
-    int kk[kMaxDim];
-    double tt[kMaxDim];
-    int64_t base = 0;
-    for (int i = 0; i < c->d; ++i) {
-        int k; double t;
-        find_cell(c->grid[i], z[i], k, t);
-        base += (int64_t)k * c->astride[i];
-        kk[i] = k; tt[i] = t;
-        g.t[i] = t;
-        g.inv_delta[i] = c->grid[i].size() > 1 ? 1.0 / (c->grid[i][(size_t)k + 1] - c->grid[i][(size_t)k]) : 0.0;
-    }
-    (void)kk;
-    g.cell_anchor = base;
-    const int nc = 1 << de;
-    g.w.assign(nc, 1.0);
-    for (int corner = 0; corner < nc; ++corner) {
-        double w = 1.0;
-        for (int i = 0; i < de; ++i) {
-            const double t = tt[c->eff_axes[i]];
-            const double wi = ((corner >> (de - 1 - i)) & 1) ? t : (1 - t);
-            w = w * wi;
-        }
-        g.w[corner] = w;
-    }
-    return true;
-}
-
-// mus_interpolator(z): value = value + V*w per corner, left to right from 0.0
-void interp_mus(const bi_ctx* c, const PointGeom& g, double* mus) {
-    const int nc = (int)g.w.size();
-    for (int s = 0; s < c->S; ++s) {
-        double v = 0.0;
-        for (int corner = 0; corner < nc; ++corner) {
-            const int64_t a = g.cell_anchor + corner_offset(c, corner);
-            const double term = c->h_mus[a * c->S + s] * g.w[corner];
-            v = v + term;
-        }
-        mus[s] = v;
-    }
-}
-
-// likelihood.py:397-415
-bool rates_physical(const bi_ctx* c, const double* mus) {
-    const double inf = std::numeric_limits<double>::infinity();
-    bool any_allowed = false;
-    for (int s = 0; s < c->S; ++s) any_allowed |= (c->allow_neg[s] != 0);
-    if (!any_allowed) {
-        for (int s = 0; s < c->S; ++s)
-            if (!(mus[s] >= 0 && mus[s] < inf)) return false;
-        return true;
-    }
-    bool any_fin = false;
-    double tot = 0;
-    for (int s = 0; s < c->S; ++s) { any_fin |= (mus[s] < inf); tot += mus[s]; }
-    if (!any_fin || tot < 0) return false;
-    for (int s = 0; s < c->S; ++s)
-        if (!(0 <= mus[s]) && !c->allow_neg[s]) return false;
-    return true;
-}
-
-int pick_class(int n, int maxg) {
-    int g = 1;
-    while (g < n && g < maxg) g <<= 1;
-    return g;
-}
-
-struct EventScope {
-    bi_ctx* c;
-    size_t idx = (size_t)-1;
-    explicit EventScope(bi_ctx* ctx) : c(ctx) {
-        if (!c->profiling) return;
-        if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            c->ev_pool.emplace_back(a, b);
-        }
-        idx = c->ev_used++;
-        (void)hipEventRecord(c->ev_pool[idx].first, c->stream);
-    }
-    ~EventScope() {
-        if (idx != (size_t)-1) (void)hipEventRecord(c->ev_pool[idx].second, c->stream);
-    }
-};
-
-template <int G>
-void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
-    if (c->unbinned) {
-        if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true, 2>), grid, dim3(kThreads), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_morph_reduce<G, false, false, 2>), grid, dim3(kThreads), 0, c->stream, a);
-        return;
-    }
-    if (bb && nt) hipLaunchKernelGGL((k_morph_reduce<G, true, true>), grid, dim3(kThreads), 0, c->stream, a);
-    else if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true, false>), grid, dim3(kThreads), 0, c->stream, a);
-    else if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true>), grid, dim3(kThreads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_morph_reduce<G, false, false>), grid, dim3(kThreads), 0, c->stream, a);
-}
-
-void launch_morph_grad(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool nt) {
-    EventScope ev(c);
-#define BI_GRAD_CASE(GG)                                                                                          \
-    case GG:                                                                                                      \
-        if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 1>), grid, dim3(kThreads), 0, c->stream, a); \
-        else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 1>), grid, dim3(kThreads), 0, c->stream, a);   \
-        break;
-    switch (G) {
-        BI_GRAD_CASE(2)
-        BI_GRAD_CASE(4)
-        BI_GRAD_CASE(8)
-        default:
-            BI_GRAD_CASE(16)
-    }
-#undef BI_GRAD_CASE
-}
-
-// nt: the launch streams its template rows exactly once (no two items touch the same anchor), so the loads
-// carry the nontemporal hint: +8 % HBM rate on gfx950; with shared rows the default policy (L2 / MALL) wins.
-void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
-    EventScope ev(c);
-    switch (G) {
-        case 1: launch_morph<1>(c, a, grid, bb, nt); break;
-        case 2: launch_morph<2>(c, a, grid, bb, nt); break;
-        case 4: launch_morph<4>(c, a, grid, bb, nt); break;
-        case 8: launch_morph<8>(c, a, grid, bb, nt); break;
-        default: launch_morph<16>(c, a, grid, bb, nt); break;
-    }
-}
-
-int check_ready(bi_ctx* c, bool need_data) {
-    if (!c) return BI_ERR_INVALID;
-    if (!c->model_ready) return fail(c, BI_ERR_STATE, "no model uploaded (prepare() first)");
-    if (need_data && !c->data_ready) return fail(c, BI_ERR_STATE, "no data uploaded (set_data() first)");
-    return BI_OK;
-}
-
-int n_tiles_of(const bi_ctx* c) { return (int)(c->Bp / kTile); }
-
-// per-dataset compacted copies of all template rows over the non-empty bins (needs the CSR lists)
-int build_compact_templates(bi_ctx* c) {
-    c->compact_ready = false;
-    const int64_t T = c->T, Bp = c->Bp;
-    int rc;
-    hipError_t e;
-    if (!c->ps_nonneg || c->bb_source >= 0) return BI_OK;
-    const int64_t rows = c->A * c->S;
-    c->h_c_np.assign((size_t)T, 0);
-    c->h_c_off.assign((size_t)T, 0);
-    c->h_cnt_off.assign((size_t)T, 0);
-    int64_t tot_ps = 0, tot_cnt = 0;
-    for (int64_t t = 0; t < T; ++t) {
-        const int64_t nnz = c->h_nz_off[(size_t)t + 1] - c->h_nz_off[(size_t)t];
-        const int64_t np = std::max<int64_t>(kTile, (nnz + kTile - 1) / kTile * kTile);
-        c->h_c_np[(size_t)t] = np;
-        c->h_c_off[(size_t)t] = tot_ps;
-        c->h_cnt_off[(size_t)t] = tot_cnt;
-        tot_ps += rows * np;
-        tot_cnt += np;
-    }
-    if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
-    if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
-        (rc = dev_alloc(c, c->scratch, (size_t)rows * sizeof(double))))
-        return rc;
-    c->h_Tz.assign((size_t)T * rows, 0.0);
-    std::vector<double> tnz((size_t)rows);
-    for (int64_t t = 0; t < T; ++t) {
-        const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo, np = c->h_c_np[(size_t)t];
-        double* dst = (double*)c->ps_c.p + c->h_c_off[(size_t)t];
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((np + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0,
-                           c->stream, (const double*)c->ps.p, Bp, (const int32_t*)c->nz_idx.p + lo, nnz, np, dst);
-        hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->nz_n.p + lo, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
-        hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
-                           (double*)c->scratch.p);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
-        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
-    }
-    c->compact_ready = true;
-    return BI_OK;
-}
-
-// CSR lists of the non-empty bins of every dataset (always, unless the data are dense), and -- when the
-// templates are non-negative and the budget allows -- per-dataset compacted copies of all template rows,
-// so that an evaluation only touches non-empty bins:
-//   sum_b [n log mu - mu - lgamma(n+1)] = sum_{b: n_b != 0} [n log mu - mu] - sum_k coef_k Tz_k - sum lgamma
-// with Tz_k = sum of row k over the EMPTY bins.  Exact (to rounding) because mu_b >= 0 is then guaranteed,
-// so the only per-bin terms that are not linear in the templates are those of the non-empty bins.
-int build_sparse_forms(bi_ctx* c) {
-    c->csr_ready = c->compact_ready = false;
-    const int64_t T = c->T, B = c->B, Bp = c->Bp;
-    const int nchunks = (int)((B + kNzChunk - 1) / kNzChunk);
-    int rc;
-    DevBuf d_cnt, d_off;
-    auto cleanup = [&]() { dev_free(d_cnt); dev_free(d_off); };
-    if ((rc = dev_alloc(c, d_cnt, (size_t)T * nchunks * sizeof(int32_t)))) return rc;
-    const int64_t tchunk = 32768;
-    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
-        const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_nz_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream,
-                           (const double*)c->counts.p + t0 * Bp, B, Bp, (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
-    }
-    std::vector<int32_t> h_cnt((size_t)T * nchunks);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt.p, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { cleanup(); return fail(c, BI_ERR_HIP, "non-empty-bin count: %s", hipGetErrorString(e)); }
-    std::vector<int64_t> h_off(h_cnt.size());
-    c->h_nz_off.assign((size_t)T + 1, 0);
-    int64_t run = 0;
-    for (int64_t t = 0; t < T; ++t) {
-        c->h_nz_off[(size_t)t] = run;
-        for (int k = 0; k < nchunks; ++k) { h_off[(size_t)t * nchunks + k] = run; run += h_cnt[(size_t)t * nchunks + k]; }
-    }
-    c->h_nz_off[(size_t)T] = run;
-    if (c->sparse == 0 || (c->sparse == 1 && run > T * B / 4)) { cleanup(); return BI_OK; }  // dense data: dense forms
-    if ((rc = dev_upload(c, d_off, h_off)) || (rc = dev_alloc(c, c->nz_idx, (size_t)std::max<int64_t>(run, 1) * sizeof(int32_t))) ||
-        (rc = dev_alloc(c, c->nz_n, (size_t)std::max<int64_t>(run, 1) * sizeof(double))) || (rc = dev_upload(c, c->nz_off, c->h_nz_off))) {
-        cleanup();
-        return rc;
-    }
-    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
-        const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_nz_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream,
-                           (const double*)c->counts.p + t0 * Bp, B, Bp, (const int64_t*)d_off.p + t0 * nchunks, nchunks,
-                           (int32_t*)c->nz_idx.p, (double*)c->nz_n.p);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "non-empty-bin scatter: %s", hipGetErrorString(e));
-    c->csr_ready = true;
-
-    return build_compact_templates(c);
-}
-
-
-
-// One point, synchronous: the call shape of `lf(**kwargs)` inside a minimizer (inference.py:111-122 makes
-// ~500 of them per fit).  Same kernels as the batched path, but the descriptors live in a persistent
-// device slot fed from pinned memory: one small H2D, two launches, one 16-byte D2H, one sync.
-int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds, double* out, int32_t* status) {
-    const int S = c->S;
-    const double ninf = -std::numeric_limits<double>::infinity();
-    if (ds < 0 || ds >= c->T) { *out = ninf; if (status) *status = BI_ST_BAD_DATASET; return BI_OK; }
-    PointGeom g;
-    if (!point_geometry(c, z, g)) { *out = ninf; if (status) *status = BI_ST_OUT_OF_BOUNDS; return BI_OK; }
-    double r[64];
-    std::vector<double> rbig;
-    double* rates = r;
-    if (S > 64) { rbig.resize((size_t)S); rates = rbig.data(); }
-    interp_mus(c, g, rates);
-    if (rate_scale) for (int s = 0; s < S; ++s) rates[s] *= rate_scale[s];
-    if (!rates_physical(c, rates)) { *out = ninf; if (status) *status = BI_ST_UNPHYSICAL; return BI_OK; }
-
-    const bool bb = c->bb_source >= 0;
-    const int nc = (int)g.w.size();
-    const int n0 = bb ? nc * (S - 1) : nc * S, n1 = bb ? nc : 0, n2 = bb ? nc : 0, NS = n0 + n1 + n2;
-    bool any_neg = false;
-    for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
-    if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
-    const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
-    const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
-    const int tiles = (int)(row_stride / kTile);
-    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
-    const int nbx = (int)std::min<int64_t>(tiles, slots);
-
-    // slot layout (8-byte units): rowoff[NS] coef[NS] aux[2] cnt_off tiles perm slot_lg | result {ll, status}
-    const size_t n_words = (size_t)NS * 2 + 2 + 4 + 2;
-    const size_t bytes = n_words * 8;
-    int rc;
-    if (c->slot_host_bytes < bytes) {
-        if (c->slot_host) (void)hipHostFree(c->slot_host);
-        c->slot_host = nullptr;
-        HIP_TRY(c, hipHostMalloc(&c->slot_host, bytes * 2, hipHostMallocDefault));
-        c->slot_host_bytes = bytes * 2;
-    }
-    if ((rc = dev_alloc(c, c->slot_dev, bytes)) || (rc = dev_alloc(c, c->slot_partial, (size_t)slots * sizeof(double))) ||
-        (rc = dev_alloc(c, c->slot_pflags, (size_t)slots * sizeof(unsigned))))
-        return rc;
-    int64_t* w64 = (int64_t*)c->slot_host;
-    double* wd = (double*)c->slot_host;
-    int64_t* rowoff = w64;
-    double* coef = wd + NS;
-    double* aux = wd + 2 * NS;
-    int k = 0;
-    double zsum = 0.0;
-    const int64_t n_rows = c->A * S;
-    for (int corner = 0; corner < nc; ++corner) {
-        const int64_t a = g.cell_anchor + corner_offset(c, corner);
-        for (int s = 0; s < S; ++s) {
-            if (bb && s == c->bb_source) continue;
-            rowoff[k] = row_base + (a * S + s) * row_stride;
-            coef[k] = g.w[(size_t)corner] * rates[s];
-            if (sparse) zsum += coef[k] * c->h_Tz[(size_t)(ds * n_rows + a * S + s)];
-            ++k;
-        }
-    }
-    aux[0] = 1.0; aux[1] = 1.0;
-    if (bb) {
-        double Ntot = 0.0;
-        for (int corner = 0; corner < nc; ++corner) {
-            const int64_t a = g.cell_anchor + corner_offset(c, corner);
-            rowoff[n0 + corner] = (a * S + c->bb_source) * c->Bp;
-            coef[n0 + corner] = g.w[(size_t)corner];
-            rowoff[n0 + n1 + corner] = a * c->Bp;
-            coef[n0 + n1 + corner] = g.w[(size_t)corner];
-            const double term = c->h_nm_tot[(size_t)a] * g.w[(size_t)corner];
-            Ntot = Ntot + term;
-        }
-        aux[0] = rates[c->bb_source] / Ntot;
-        aux[1] = Ntot;
-    }
-    const size_t o = (size_t)2 * NS + 2;
-    w64[o + 0] = sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp;   // cnt_off
-    ((int32_t*)(w64 + o + 1))[0] = tiles;                            // tiles (+ pad)
-    ((int32_t*)(w64 + o + 1))[1] = 0;
-    w64[o + 2] = 0;                                                  // perm -> out[0]
-    wd[o + 3] = c->h_lgsum[(size_t)ds] + zsum;                       // slot_lg
-    if (c->unbinned) {
-        double rsum = 0.0;
-        for (int s = 0; s < S; ++s) rsum += rates[s];
-        wd[o + 3] = rsum;
-    }
-    // the result {ll, status} is written by k_finish straight into the pinned host block (second half)
-    char* res = (char*)c->slot_host + bytes;
-    *(double*)res = 0.0;
-    *(int64_t*)(res + 8) = 0;
-
-    char* dev = (char*)c->slot_dev.p;
-    HIP_TRY(c, hipMemcpyAsync(dev, c->slot_host, bytes, hipMemcpyHostToDevice, c->stream));
-    LaunchArgs a{};
-    a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
-    a.nm = (const double*)c->nm.p;
-    a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
-    a.rowoff = (const int64_t*)dev;
-    a.coef = (const double*)(dev + (size_t)NS * 8);
-    a.aux = (const double*)(dev + (size_t)NS * 16);
-    a.item_cnt = (const int64_t*)(dev + (o + 0) * 8);
-    a.item_tiles = (const int32_t*)(dev + (o + 1) * 8);
-    a.partial = (double*)c->slot_partial.p;
-    a.pflags = (unsigned*)c->slot_pflags.p;
-    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
-    a.outlier = c->outlier;
-    launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
-    const int lanes = nbx > 64 ? kThreads : 64;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kThreads), 0, c->stream, (const double*)a.partial,
-                       (const unsigned*)a.pflags, nbx, 1, lanes, (int64_t)1, (const int64_t*)(dev + (o + 2) * 8),
-                       (const double*)(dev + (o + 3) * 8), (double*)res, (int32_t*)(res + 8));
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *out = *(double*)res;
-    if (status) *status = *(int32_t*)(res + 8);
-    return BI_OK;
-}
-
-}  // namespace
+#include "bi_context.h"
+#include "bi_kernels.h"
+#include "bi_geometry.h"
+#include "bi_launch.h"
+#include "bi_sparse.h"
+#include "bi_single.h"
+#include "bi_planning.h"
 
 extern "C" {
 
@@ -1590,196 +336,7 @@ int64_t bi_plan_launches(const bi_plan* p) { return p ? p->launches : 0; }
 
 int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
                    bi_plan** out) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!out) return fail(c, BI_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (P < 0) return fail(c, BI_ERR_INVALID, "P < 0");
-    if (c->d > 0 && P > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
-    HIP_TRY(c, hipSetDevice(c->device));
-
-    const int S = c->S, d = c->d;
-    const bool bb = c->bb_source >= 0;
-    const int nc = 1 << (int)c->eff_axes.size();
-    const int n0 = bb ? nc * (S - 1) : nc * S;
-    const int n1 = bb ? nc : 0, n2 = bb ? nc : 0;
-    const int NS = n0 + n1 + n2;
-
-    bool any_neg = false;
-    for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
-    const int64_t n_rows = c->A * S;
-    if (!sparse && !c->dense_counts)
-        return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
-                                     "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
-
-    bi_plan* plan = new bi_plan();
-    plan->P = P;
-    plan->sparse = sparse;
-    plan->epoch = c->epoch;
-    plan->h_status.assign((size_t)P, 0);
-
-    struct Pt { int64_t key; int64_t idx; };
-    std::vector<Pt> pts;
-    pts.reserve((size_t)P);
-    std::vector<int64_t> bad;
-    std::vector<PointGeom> geom((size_t)P);
-    std::vector<double> rates((size_t)P * S);
-    std::vector<double> ones((size_t)S, 1.0);
-
-    for (int64_t p = 0; p < P; ++p) {
-        const int64_t ds = dataset ? dataset[p] : 0;
-        if (ds < 0 || ds >= c->T) { plan->h_status[p] |= BI_ST_BAD_DATASET; bad.push_back(p); continue; }
-        PointGeom& g = geom[(size_t)p];
-        if (!point_geometry(c, z ? z + p * d : nullptr, g)) { plan->h_status[p] |= BI_ST_OUT_OF_BOUNDS; bad.push_back(p); continue; }
-        double* r = &rates[(size_t)p * S];
-        interp_mus(c, g, r);
-        const double* rs = rate_scale ? rate_scale + p * S : ones.data();
-        for (int s = 0; s < S; ++s) r[s] *= rs[s];
-        if (!rates_physical(c, r)) { plan->h_status[p] |= BI_ST_UNPHYSICAL; bad.push_back(p); continue; }
-        pts.push_back({g.cell_anchor * c->T + ds, p});
-    }
-    std::stable_sort(pts.begin(), pts.end(), [](const Pt& a, const Pt& b) { return a.key < b.key; });
-
-    // chop every (cell, dataset) group into items of the available G classes
-    const int classG[5] = {1, 2, 4, 8, 16};
-    struct HostClass { std::vector<int64_t> rowoff, cnt_off; std::vector<double> coef, aux, slot_lg; std::vector<int32_t> tiles; std::vector<int64_t> perm; int64_t bytes = 0; };
-    HostClass hc[5];
-    const int maxg = bb ? (int)std::min<int64_t>(c->max_group, 8) : (int)c->max_group;  // G=16 with BB spills past 256 VGPRs
-    size_t i = 0;
-    std::vector<int64_t> corner_off((size_t)nc);
-    for (int k = 0; k < nc; ++k) corner_off[(size_t)k] = corner_offset(c, k);
-    std::vector<char> anchor_used((size_t)c->A, 0);
-    bool reuse = false;
-    while (i < pts.size()) {
-        size_t j = i;
-        while (j < pts.size() && pts[j].key == pts[i].key) ++j;
-        size_t n = j - i;
-        while (n > 0) {
-            const int G = pick_class((int)std::min<size_t>(n, (size_t)maxg), maxg);
-            const int take = (int)std::min<size_t>(n, (size_t)G);
-            int ci = 0;
-            while (classG[ci] != G) ++ci;
-            HostClass& h = hc[ci];
-            const int64_t p0 = pts[i].idx;
-            const int64_t cell = geom[(size_t)p0].cell_anchor;
-            const int64_t ds = pts[i].key % c->T;
-            for (int corner = 0; corner < nc; ++corner) {
-                char& u = anchor_used[(size_t)(cell + corner_off[(size_t)corner])];
-                if (u) reuse = true;
-                u = 1;
-            }
-            const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
-            const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
-            const size_t ro = h.rowoff.size();
-            h.rowoff.resize(ro + NS);
-            // stream rows: [n0] (corner, source != bb) ; [n1] (corner, bb source) ; [n2] n_model corner rows
-            int k0 = 0;
-            for (int corner = 0; corner < nc; ++corner)
-                for (int s = 0; s < S; ++s) {
-                    if (bb && s == c->bb_source) continue;
-                    h.rowoff[ro + k0++] = row_base + ((cell + corner_off[(size_t)corner]) * S + s) * row_stride;
-                }
-            for (int corner = 0; corner < n1; ++corner)
-                h.rowoff[ro + n0 + corner] = ((cell + corner_off[(size_t)corner]) * S + c->bb_source) * c->Bp;
-            for (int corner = 0; corner < n2; ++corner)
-                h.rowoff[ro + n0 + n1 + corner] = (cell + corner_off[(size_t)corner]) * c->Bp;
-            const size_t co = h.coef.size();
-            h.coef.resize(co + (size_t)NS * G, 0.0);
-            const size_t ao = h.aux.size();
-            h.aux.resize(ao + (size_t)G * 2, 1.0);
-            const size_t po = h.perm.size();
-            h.perm.resize(po + G, -1);
-            h.cnt_off.push_back(sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp);
-            h.tiles.push_back((int32_t)(row_stride / kTile));
-            h.bytes += (int64_t)sizeof(double) * ((int64_t)NS + 1) * (sparse ? row_stride : c->B);
-            h.slot_lg.resize(po + G, c->h_lgsum[(size_t)ds]);
-            for (int g = 0; g < take; ++g) {
-                const int64_t p = pts[i + g].idx;
-                const PointGeom& pg = geom[(size_t)p];
-                const double* r = &rates[(size_t)p * S];
-                int k = 0;
-                for (int corner = 0; corner < nc; ++corner)
-                    for (int s = 0; s < S; ++s) {
-                        if (bb && s == c->bb_source) continue;
-                        h.coef[co + (size_t)(k++) * G + g] = pg.w[(size_t)corner] * r[s];
-                    }
-                for (int corner = 0; corner < n1; ++corner) h.coef[co + (size_t)(n0 + corner) * G + g] = pg.w[(size_t)corner];
-                for (int corner = 0; corner < n2; ++corner) h.coef[co + (size_t)(n0 + n1 + corner) * G + g] = pg.w[(size_t)corner];
-                if (bb) {
-                    double Ntot = 0.0;
-                    for (int corner = 0; corner < nc; ++corner) {
-                        const double term = c->h_nm_tot[(size_t)(pg.cell_anchor + corner_off[(size_t)corner])] * pg.w[(size_t)corner];
-                        Ntot = Ntot + term;
-                    }
-                    h.aux[ao + (size_t)g * 2 + 0] = r[c->bb_source] / Ntot;  // p_calibration, likelihood.py:645
-                    h.aux[ao + (size_t)g * 2 + 1] = Ntot;
-                }
-                h.perm[po + g] = p;
-                if (c->unbinned) {   // ll = -sum_s mu_s + sum_e log(...)   (likelihood.py:690)
-                    double rsum = 0.0;
-                    for (int s = 0; s < S; ++s) rsum += r[s];
-                    h.slot_lg[po + g] = rsum;
-                }
-                if (sparse) {
-                    // minus sum_k coef_k * (sum of row k over the empty bins of this dataset)
-                    double zsum = 0.0;
-                    int kk = 0;
-                    for (int corner = 0; corner < nc; ++corner)
-                        for (int s = 0; s < S; ++s) {
-                            const int64_t row = (cell + corner_off[(size_t)corner]) * S + s;
-                            zsum += h.coef[co + (size_t)(kk++) * G + g] * c->h_Tz[(size_t)(ds * n_rows + row)];
-                        }
-                    h.slot_lg[po + g] += zsum;
-                }
-            }
-            i += take;
-            n -= take;
-        }
-    }
-
-    // grid shape: enough blocks to fill the chip, few enough that partial buffers stay small
-    const int n_tiles = n_tiles_of(c);
-    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
-    int64_t total_items = 0;
-    for (auto& h : hc) total_items += (int64_t)h.tiles.size();
-
-    for (int ci = 0; ci < 5; ++ci) {
-        HostClass& h = hc[ci];
-        if (h.tiles.empty()) continue;
-        bi_plan::Class k;
-        k.G = classG[ci];
-        k.n_items = (int64_t)h.tiles.size();
-        const int64_t max_tiles = sparse ? *std::max_element(h.tiles.begin(), h.tiles.end()) : n_tiles;
-        int64_t nbx = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + total_items - 1) / total_items));
-        if (total_items == 1) nbx = std::min<int64_t>(max_tiles, slots);
-        k.nbx = (int)nbx;
-        if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
-            (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_cnt, h.cnt_off)) ||
-            (rc = dev_upload(c, k.item_tiles, h.tiles)) ||
-            (rc = dev_upload(c, k.perm, h.perm)) || (rc = dev_upload(c, k.slot_lg, h.slot_lg)) ||
-            (rc = dev_alloc(c, k.partial, (size_t)k.n_items * k.nbx * k.G * sizeof(double))) ||
-            (rc = dev_alloc(c, k.pflags, (size_t)k.n_items * k.nbx * k.G * sizeof(unsigned)))) {
-            plan->classes.push_back(k);
-            free_plan_buffers(plan);
-            delete plan;
-            return rc;
-        }
-        plan->bytes += h.bytes;
-        plan->launches += (k.n_items + 65534) / 65535;
-        plan->classes.push_back(k);
-    }
-    plan->no_reuse = !reuse;
-    plan->n_bad = (int64_t)bad.size();
-    if ((rc = dev_upload(c, plan->bad_idx, bad)) || (rc = dev_alloc(c, plan->out, (size_t)std::max<int64_t>(P, 1) * sizeof(double))) ||
-        (rc = dev_upload(c, plan->status, plan->h_status))) {
-        free_plan_buffers(plan);
-        delete plan;
-        return rc;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die with this scope
-    *out = plan;
-    return BI_OK;
+    return plan_points(c, P, z, rate_scale, dataset, out);
 }
 
 int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
