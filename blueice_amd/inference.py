@@ -9,12 +9,13 @@ from collections import OrderedDict
 from copy import deepcopy
 
 import numpy as np
-from scipy.optimize import minimize
+from scipy import stats
+from scipy.optimize import brentq, minimize
 
 from .exceptions import NoOpimizationNecessary, OptimizationFailed
 from .utils import is_numeric
 
-__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy']
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'one_parameter_interval', 'likelihood_ratio_scan']
 
 
 def best_anchor(lf):
@@ -107,3 +108,59 @@ def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bound
     for n, v in zip(names, x):
         out[n] = 10 ** v if (rates_in_log_space and n.endswith('_rate_multiplier')) else v
     return out, -res.fun
+
+
+def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper', bestfit_routine=None,
+                           t_ppf=None, **kwargs):
+    """Profile-likelihood interval on parameter `target` (reference: blueice/inference.py:332-389).
+    kind 'upper' / 'lower': `bound` is the far end of the line search; 'central': a 2-tuple.
+    The test statistic 2 (max logL - logL profiled at the hypothesis) is compared with
+    norm.ppf(quantile)**2 (Wilks) or with t_ppf(hypothesis, quantile); the crossing is found with brentq.
+    Every profile point is one nested fit, i.e. a stream of single-point device calls."""
+    fit = bestfit_routine or bestfit_scipy
+    if target is None:
+        target = lf.source_list[-1] + '_rate_multiplier'
+    best, max_ll = fit(lf, **kwargs)
+    global_best = best[target]
+
+    def t(hypothesis, quantile):
+        critical = stats.norm.ppf(quantile) ** 2 if t_ppf is None else t_ppf(hypothesis, quantile)
+        one_sided_ok = (kind == 'upper' and hypothesis <= global_best) or (kind == 'lower' and hypothesis >= global_best)
+        if one_sided_ok:
+            return 0 - critical
+        _, ll = fit(lf, **dict(kwargs, **{target: hypothesis}))
+        return 2 * (max_ll - ll) - critical
+
+    if kind == 'central':
+        return (brentq(t, bound[0], global_best, args=((1 - confidence_level) / 2,)),
+                brentq(t, global_best, bound[1], args=(1 - (1 - confidence_level) / 2,)))
+    if kind == 'lower':
+        return brentq(t, bound, global_best, args=(1 - confidence_level,))
+    if kind == 'upper':
+        return brentq(t, global_best, bound, args=(confidence_level,))
+    raise ValueError("kind must be 'upper', 'lower' or 'central'")
+
+
+def likelihood_ratio_scan(lf, *space, bestfit_routine=None, **kwargs):
+    """-log likelihood ratio over a 1-d or 2-d grid of parameter values: the numbers behind the reference's
+    `plot_likelihood_ratio` (blueice/inference.py:392-443) without the plotting.
+    space: (name, values) tuples.  Parameters given in kwargs are fixed, all others are fitted at every grid
+    point; when nothing is left to fit the whole grid is ONE batched device call (`lf.eval_points`).
+    Returns an array of shape [len(values_0)(, len(values_1))], best point = 0."""
+    if not 1 <= len(space) <= 2:
+        raise ValueError("Can't handle %d dimensions" % len(space))
+    fit = bestfit_routine or bestfit_scipy
+    names = [n for n, _ in space]
+    grids = np.meshgrid(*[np.asarray(v, dtype=float) for _, v in space], indexing='ij')
+    floating = [p + '_rate_multiplier' for p in lf.rate_parameters if p + '_rate_multiplier' not in kwargs] + \
+               [p for p in lf.shape_parameters if p not in kwargs]
+    floating = [p for p in floating if p not in names]
+    if not floating and hasattr(lf, 'eval_points'):
+        pts = {n: g.ravel() for n, g in zip(names, grids)}
+        pts.update({k: v for k, v in kwargs.items()})
+        ll = np.asarray(lf.eval_points(pts)).reshape(grids[0].shape)
+    else:
+        ll = np.empty(grids[0].shape)
+        for idx in np.ndindex(*grids[0].shape):
+            ll[idx] = fit(lf, **dict(kwargs, **{n: float(g[idx]) for n, g in zip(names, grids)}))[1]
+    return np.nanmax(ll) - ll

@@ -140,6 +140,9 @@ def fit_goldens(ns):
     t['fit_fixshift_ll'] = ll
     res, ll = lf.bestfit_scipy(shift=0.2, s0_rate_multiplier=1., s1_rate_multiplier=0.9)
     t['fit_none_ll'] = ll
+    t['upper_s1_90'] = lf.one_parameter_interval('s1_rate_multiplier', bound=50., kind='upper', confidence_level=0.9)
+    t['central_s0_68'] = np.array(lf.one_parameter_interval('s0_rate_multiplier', bound=(2., 20.), kind='central',
+                                                             confidence_level=0.68, s1_rate_multiplier=0.))
     np.savez_compressed(os.path.join(OUT, 'fit_c1_like.npz'), **t)
     print('fit_c1_like', dict(zip(t['fit_all_names'], t['fit_all_values'])), t['fit_all_ll'])
 

@@ -197,3 +197,26 @@ def test_toys_match_scalar_calls(ns):
     assert same(lf(shift=0.2, stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3), want[0], 0)   # dataset 0
     both = lf.eval_points(dict(shift=[0.2, 0.2], stretch=-0.4, tilt=0.9, s2_rate_multiplier=1.3), dataset=[3, 6])
     assert same(both[0], want[3], 1e-12) and same(both[1], want[6], 1e-12)
+
+
+def test_intervals_and_scans_match_reference(ns):
+    """one_parameter_interval (blueice/inference.py:332-389) against the reference's own numbers, and the
+    batched likelihood-ratio scan against scalar calls."""
+    f = np.load(GOLDEN_DIR + '/fit_c1_like.npz')
+    lf = model_zoo.fit_c1_like(ns)
+    up = lf.one_parameter_interval('s1_rate_multiplier', bound=50., kind='upper', confidence_level=0.9)
+    assert abs(up - float(f['upper_s1_90'])) < 2e-3 * float(f['upper_s1_90'])
+    lo, hi = lf.one_parameter_interval('s0_rate_multiplier', bound=(2., 20.), kind='central', confidence_level=0.68,
+                                       s1_rate_multiplier=0.)
+    np.testing.assert_allclose([lo, hi], f['central_s0_68'], rtol=2e-3)
+    # nothing left to fit -> the whole grid in one device call
+    s0 = np.linspace(5., 10., 11)
+    sh = np.linspace(-0.5, 0.9, 8)
+    grid = lf.likelihood_ratio_scan(('s0_rate_multiplier', s0), ('shift', sh), s1_rate_multiplier=0.)
+    assert grid.shape == (11, 8) and grid.min() == 0
+    ll = np.array([[lf(s0_rate_multiplier=a, shift=b, s1_rate_multiplier=0.) for b in sh] for a in s0])
+    np.testing.assert_allclose(grid, ll.max() - ll, rtol=1e-10, atol=1e-9)
+    # one parameter profiled out at every grid point
+    prof = lf.likelihood_ratio_scan(('shift', sh[:4]), s1_rate_multiplier=0.)
+    want = np.array([lf.bestfit_scipy(shift=b, s1_rate_multiplier=0.)[1] for b in sh[:4]])
+    np.testing.assert_allclose(prof, want.max() - want, atol=1e-6)
