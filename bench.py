@@ -300,6 +300,17 @@ def main():
         ex['sparse_scan_131072_evals_per_s_incl_host_planning'] = len(zz) / (dt + t_plan)
         ex['sparse_nonempty_bins'] = ctx.get_param('nnz_total')
         p.close()
+        # BASELINE.json configs[2] at full scale: 10^4 toy datasets drawn on the device at one parameter point,
+        # all evaluated by one call at a nearby point (wall time includes the D2H of the 10^4 results)
+        t = time.perf_counter()
+        ctx.generate_toys(z[0], r[0], 10000, seed=1)
+        ex['toy_mc_10000_generate_s'] = time.perf_counter() - t
+        z_near = np.clip(z[0] + 0.03, [g[0] for g in model.anchor_z], [g[-1] for g in model.anchor_z])
+        ctx.eval_datasets(z_near, r[0])
+        t = time.perf_counter()
+        for _ in range(5):
+            ctx.eval_datasets(z_near, r[0])
+        ex['toy_mc_10000_evals_per_s_wall'] = 5 * 10000 / (time.perf_counter() - t)
         ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
         result['extras'] = ex
