@@ -1,6 +1,8 @@
 // bi_context.h -- the context / plan objects behind the opaque C handles, error and device-memory helpers.
 #pragma once
 
+struct bi_ctx;
+
 namespace {
 
 constexpr int kThreads = 256;           // 4 wave64 per block
@@ -14,6 +16,7 @@ thread_local std::string g_create_error;
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    struct ::bi_ctx* owner = nullptr;  // context whose recycle cache takes the buffer back on dev_free
 };
 
 }  // namespace
@@ -89,6 +92,12 @@ struct bi_ctx {
     // scratch
     DevBuf scratch, scratch2, logmu;
 
+    // recycle cache for the small transient buffers of a call (descriptors, partials): hipMalloc / hipFree
+    // cost tens of microseconds each and every call needs about ten of them.  All work of a context is
+    // ordered on its one stream, so handing a buffer to the next call is safe without a sync.
+    std::vector<DevBuf> cache;
+    size_t cache_bytes = 0;
+
     int64_t epoch = 0;  // bumped by every model / data upload
 
     // tunables
@@ -125,23 +134,57 @@ int fail(bi_ctx* c, int code, const char* fmt, ...) {
             return fail((c), BI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+constexpr size_t kCacheMaxBuf = (size_t)64 << 20;     // only buffers up to 64 MiB are recycled
+constexpr size_t kCacheMaxTotal = (size_t)1 << 30;    // at most 1 GiB parked
+constexpr size_t kCacheMaxEntries = 256;
+
+void dev_free(DevBuf& b) {
+    if (b.p) {
+        bi_ctx* c = b.owner;
+        if (c && b.bytes <= kCacheMaxBuf && c->cache.size() < kCacheMaxEntries && c->cache_bytes + b.bytes <= kCacheMaxTotal) {
+            c->cache.push_back(b);
+            c->cache_bytes += b.bytes;
+        } else {
+            (void)hipFree(b.p);
+        }
+    }
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
 int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p && b.bytes >= bytes) return BI_OK;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) dev_free(b);
     if (bytes == 0) bytes = 16;
+    if (bytes <= kCacheMaxBuf) {  // smallest parked buffer that fits without wasting more than 4x
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c->cache.size(); ++i)
+            if (c->cache[i].bytes >= bytes && c->cache[i].bytes <= 4 * bytes + 4096 &&
+                (best == (size_t)-1 || c->cache[i].bytes < c->cache[best].bytes))
+                best = i;
+        if (best != (size_t)-1) {
+            b = c->cache[best];
+            c->cache_bytes -= b.bytes;
+            c->cache[best] = c->cache.back();
+            c->cache.pop_back();
+            return BI_OK;
+        }
+    }
     hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        // give parked memory back and retry once
+        for (auto& q : c->cache) (void)hipFree(q.p);
+        c->cache.clear();
+        c->cache_bytes = 0;
+        e = hipMalloc(&b.p, bytes);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(c, BI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     }
     b.bytes = bytes;
+    b.owner = c;
     return BI_OK;
-}
-
-void dev_free(DevBuf& b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
 }
 
 template <class T>

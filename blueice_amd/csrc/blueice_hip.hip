@@ -81,6 +81,8 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
+    for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
+    c->cache.clear();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(c->stream);
     delete c;

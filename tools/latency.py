@@ -29,3 +29,18 @@ for sparse in (0, 1):
                     out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
     dt2 = (time.perf_counter() - t) / 500
     print('sparse=%d: DeviceContext.eval %.1f us/call, raw bi_eval %.1f us/call' % (sparse, dt * 1e6, dt2 * 1e6))
+# small batches and the gradient call (recycled transient buffers)
+ctx.set_param('sparse', 0)
+ctx.upload_counts(counts)
+for P in (4, 16):
+    for i in range(5): ctx.eval(z[:P], r[:P])
+    t = time.perf_counter()
+    for i in range(100): ctx.eval(z[:P], r[:P])
+    print('dense batch P=%d: %.1f us/call' % (P, (time.perf_counter() - t) / 100 * 1e6))
+for sparse in (0, 1):
+    ctx.set_param('sparse', sparse)
+    ctx.upload_counts(counts)
+    for i in range(5): ctx.eval_grad(z[0], r[0])
+    t = time.perf_counter()
+    for i in range(100): ctx.eval_grad(z[i % 64], r[i % 64])
+    print('sparse=%d eval_grad: %.1f us/call' % (sparse, (time.perf_counter() - t) / 100 * 1e6))
