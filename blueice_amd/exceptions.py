@@ -2,6 +2,11 @@
 including its historical spelling `NoOpimizationNecessary`, so user `except` clauses keep working)."""
 
 
+__all__ = ['BlueIceException', 'NoOpimizationNecessary', 'OptimizationFailed', 'NotPreparedException',
+           'NoShapeParameters', 'InvalidParameter', 'InvalidParameterSpecification', 'PDFNotComputedException',
+           'DeviceError']
+
+
 class BlueIceException(Exception):
     """Root of all errors raised on purpose by this package."""
 

@@ -1,71 +1,88 @@
-"""Analytic toy sources and config builders used by the test-suite (the counterparts of the
-fixtures in the reference's blueice/test_helpers.py:13-126; same names so tests read alike)."""
-from copy import deepcopy
+"""Toy sources and config builders for the test-suite.
 
+The names (`GaussianSource`, `GaussianMCSource`, `FixedSampleSource`, `conf_for_test`, `make_data`,
+`almost_equal`) are the fixtures the reference's tests are written against (blueice/test_helpers.py), kept so
+that parity tests read like the reference's own; the implementations are this package's.
+"""
 import numpy as np
-from scipy import stats
+from scipy.stats import norm
 
 from .source import DensityEstimatingSource, MonteCarloSource, Source
-from .utils import combine_dicts
 
 __all__ = ['GaussianSourceBase', 'GaussianSource', 'GaussianMCSource', 'FixedSampleSource',
            'BASE_CONFIG', 'conf_for_test', 'almost_equal', 'make_data']
 
+_EVENT_DTYPE = [('x', float), ('source', int)]
+
 
 class GaussianSourceBase(Source):
-    """1-d source that can draw events from N(mu, sigma)."""
+    """One observable, x ~ Normal(config['mu'], config['sigma'])."""
+
+    def _dist(self):
+        return norm(loc=self.config['mu'], scale=self.config['sigma'])
 
     def simulate(self, n_events):
-        d = np.zeros(n_events, dtype=[('x', float), ('source', int)])
-        d['x'] = stats.norm(self.config['mu'], self.config['sigma']).rvs(n_events)
-        return d
+        events = np.zeros(int(n_events), dtype=_EVENT_DTYPE)
+        events['x'] = self._dist().rvs(int(n_events))
+        return events
 
 
 class GaussianSource(GaussianSourceBase):
-    """Analytic Gaussian pdf; rate responds to `some_multiplier` and len(`strlen_multiplier`)."""
+    """Closed-form pdf.  Two settings act on the rate only: `some_multiplier` (a number) and
+    `strlen_multiplier` (a string, the rate scales with its length) -- handy stand-ins for numeric and
+    non-numeric shape parameters."""
 
     def compute_pdf(self):
-        self.events_per_day *= self.config.get('some_multiplier', 1)
-        self.events_per_day *= len(self.config.get('strlen_multiplier', 'x'))
+        factor = self.config.get('some_multiplier', 1) * len(self.config.get('strlen_multiplier', 'x'))
+        self.events_per_day = self.events_per_day * factor
         super().compute_pdf()
 
-    def pdf(self, *args):
+    def pdf(self, *coords):
         if not self.pdf_has_been_computed:
             raise RuntimeError("Trying to call a PDF that hasn't been computed!")
-        return stats.norm(self.config['mu'], self.config['sigma']).pdf(args[0])
+        return self._dist().pdf(coords[0])
 
 
 class GaussianMCSource(GaussianSourceBase, MonteCarloSource):
-    """Same events, pdf estimated from its own Monte Carlo."""
+    """Same generator; the pdf is a histogram of its own Monte Carlo."""
 
 
 class FixedSampleSource(DensityEstimatingSource):
-    """Density estimated from the fixed sample in config['data']."""
+    """Histogram density of the events given in config['data']; rate x len(strlen_multiplier)."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.events_per_day *= len(self.config.get('strlen_multiplier', 'x'))
+        self.events_per_day = self.events_per_day * len(self.config.get('strlen_multiplier', 'x'))
 
     def get_events_for_density_estimate(self):
-        return self.config['data'], len(self.config['data'])
+        sample = self.config['data']
+        return sample, len(sample)
 
 
-BASE_CONFIG = dict(
-    sources=[{'name': 's0', 'events_per_day': 1000.}],
-    mu=0, sigma=1, strlen_multiplier='q', some_multiplier=1,
-    events_per_day=1000., n_events_for_pdf=int(1e6),
-    default_source_class=GaussianSource,
-    force_pdf_recalculation=True,
-    analysis_space=[['x', np.linspace(-10, 10, 100)]],
-)
+def _base_config():
+    return {
+        'analysis_space': [['x', np.linspace(-10, 10, 100)]],
+        'default_source_class': GaussianSource,
+        'sources': [{'name': 's0', 'events_per_day': 1000.}],
+        'events_per_day': 1000.,
+        'mu': 0, 'sigma': 1,
+        'some_multiplier': 1, 'strlen_multiplier': 'q',
+        'n_events_for_pdf': int(1e6),
+        'force_pdf_recalculation': True,
+    }
 
 
-def conf_for_test(n_sources=1, mc=False, **kwargs):
-    conf = deepcopy(BASE_CONFIG)
+BASE_CONFIG = _base_config()
+
+
+def conf_for_test(n_sources=1, mc=False, **overrides):
+    """Model config with `n_sources` identical sources named s0, s1, ...; `mc` switches to GaussianMCSource."""
+    conf = _base_config()
     conf['sources'] = [{'name': 's%d' % i} for i in range(n_sources)]
     if mc:
         conf['default_source_class'] = GaussianMCSource
-    return combine_dicts(conf, kwargs)
+    conf.update(overrides)
+    return conf
 
 
 def almost_equal(a, b, fraction=1e-6):
@@ -73,14 +90,13 @@ def almost_equal(a, b, fraction=1e-6):
 
 
 def make_data(instructions):
-    """[dict(n_events=24, x=0.5), dict(n_events=56, x=1.5)] -> (record array, total events)."""
-    n_tot = sum(ins['n_events'] for ins in instructions)
-    d = np.zeros(n_tot, dtype=[('source', int), ('x', float), ('y', float)])
-    start = 0
-    for ins in instructions:
-        stop = start + ins['n_events']
-        for k, v in ins.items():
-            if k != 'n_events':
-                d[k][start:stop] = v
-        start = stop
-    return d, n_tot
+    """Events from a recipe: each dict gives n_events and constant values for some of the fields
+    (source, x, y).  -> (record array, number of events)."""
+    counts = [int(step['n_events']) for step in instructions]
+    events = np.zeros(sum(counts), dtype=[('source', int), ('x', float), ('y', float)])
+    edges = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+    for step, lo, hi in zip(instructions, edges[:-1], edges[1:]):
+        for field, value in step.items():
+            if field != 'n_events':
+                events[field][lo:hi] = value
+    return events, int(edges[-1])
