@@ -62,6 +62,11 @@ struct bi_ctx {
     std::vector<double> h_nm_tot;  // [A]
     std::vector<char> anchor_set;
 
+    // analysis space (bin edges) for device-side binning of events
+    int space_k = 0;
+    std::vector<int32_t> space_n_edges;
+    DevBuf space_edges;
+
     // data
     bool unbinned = false;      // extended unbinned likelihood: rows are pdf values at the events
     double outlier = 0.0;

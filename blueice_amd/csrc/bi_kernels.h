@@ -612,6 +612,38 @@ __global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restri
     if (threadIdx.x == 0) lg_partial[(int64_t)blockIdx.y * nchunks + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
 }
 
+// set_data on the device: bin events into the analysis space with numpy.histogramdd semantics (what
+// Histdd.add does in blueice/likelihood.py:608-609): per axis the bin is searchsorted(edges, x, 'right') - 1,
+// the right-most edge is inclusive, events outside any axis range (or nan) are dropped.  Adding 1.0 with an fp64
+// atomic is exact, so the result does not depend on the order of arrival.
+struct HistArgs {
+    int k;
+    int n_edges[kMaxDim];
+    int edge_off[kMaxDim];
+};
+
+__global__ __launch_bounds__(kThreads) void k_histogram(const double* __restrict__ coords /*[k][N]*/, int64_t N, HistArgs h,
+                                                        const double* __restrict__ edges, double* __restrict__ counts) {
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= N) return;
+    int64_t bin = 0;
+    for (int a = 0; a < h.k; ++a) {
+        const double x = coords[(int64_t)a * N + e];
+        const double* __restrict__ g = edges + h.edge_off[a];
+        const int n = h.n_edges[a];
+        if (!(x >= g[0] && x <= g[n - 1])) return;      // out of range or nan
+        int lo = 0, hi = n;                               // first index with g[idx] > x  (side = 'right')
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (g[mid] <= x) lo = mid + 1; else hi = mid;
+        }
+        int b = lo - 1;
+        if (b == n - 1) b = n - 2;                        // x == last edge: belongs to the last bin
+        bin = bin * (n - 1) + b;
+    }
+    atomicAdd(&counts[bin], 1.0);
+}
+
 // densify one dataset from its non-empty-bin list
 __global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __restrict__ n, int64_t nnz,
                                double* __restrict__ out) {

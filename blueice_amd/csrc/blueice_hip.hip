@@ -45,6 +45,36 @@
 #include "bi_single.h"
 #include "bi_planning.h"
 
+namespace {
+
+// dense counts [T][Bp] are resident: per-dataset sum lgamma(n+1), then the sparse forms
+int finish_counts(bi_ctx* c, int64_t T) {
+    int rc;
+    // sum_b lgamma(n+1) per dataset, on the device
+    const int nblk = (int)std::min<int64_t>(256, (c->B + kThreads - 1) / kThreads);
+    if ((rc = dev_alloc(c, c->lgsum, (size_t)T * sizeof(double)))) return rc;
+    const int64_t chunk = 32768;  // datasets per launch (gridDim.y limit)
+    if ((rc = dev_alloc(c, c->scratch, (size_t)std::min(T, chunk) * nblk * sizeof(double)))) return rc;
+    for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+        const int64_t n = std::min(chunk, T - t0);
+        hipLaunchKernelGGL(k_counts_lgamma, dim3(nblk, (unsigned)n), dim3(kThreads), 0, c->stream,
+                           (const double*)c->counts.p + t0 * c->Bp, c->B, c->Bp, (double*)c->scratch.p, nblk);
+        hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)c->scratch.p, nblk, (double*)c->lgsum.p + t0, n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->h_lgsum.assign((size_t)T, 0.0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->T = T;
+    c->dense_counts = true;
+    if ((rc = build_sparse_forms(c))) return rc;
+    c->data_ready = true;
+    return BI_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* bi_version(void) { return BI_VERSION; }
@@ -78,7 +108,7 @@ void bi_destroy(bi_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
-    dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags);
+    dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->space_edges);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
@@ -301,27 +331,69 @@ int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {
     HIP_TRY(c, hipMemsetAsync(c->counts.p, 0, bytes, c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(c->counts.p, c->Bp * sizeof(double), counts, c->B * sizeof(double),
                                 c->B * sizeof(double), (size_t)T, hipMemcpyHostToDevice, c->stream));
-    // sum_b lgamma(n+1) per dataset, on the device
-    const int nblk = (int)std::min<int64_t>(256, (c->B + kThreads - 1) / kThreads);
-    if ((rc = dev_alloc(c, c->lgsum, (size_t)T * sizeof(double)))) return rc;
-    const int64_t chunk = 32768;  // datasets per launch (gridDim.y limit)
-    if ((rc = dev_alloc(c, c->scratch, (size_t)std::min(T, chunk) * nblk * sizeof(double)))) return rc;
-    for (int64_t t0 = 0; t0 < T; t0 += chunk) {
-        const int64_t n = std::min(chunk, T - t0);
-        hipLaunchKernelGGL(k_counts_lgamma, dim3(nblk, (unsigned)n), dim3(kThreads), 0, c->stream,
-                           (const double*)c->counts.p + t0 * c->Bp, c->B, c->Bp, (double*)c->scratch.p, nblk);
-        hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->scratch.p, nblk, (double*)c->lgsum.p + t0, n);
+    return finish_counts(c, T);
+}
+
+
+// ---- set_data on the device ---------------------------------------------------------------------
+
+int bi_set_analysis_space(bi_ctx* c, int k, const int32_t* n_edges, const double* edges) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (k < 1 || k > kMaxDim || !n_edges || !edges) return fail(c, BI_ERR_INVALID, "need 1..%d axes with edges", kMaxDim);
+    int64_t bins = 1;
+    std::vector<double> flat;
+    std::vector<int32_t> ne(n_edges, n_edges + k);
+    for (int i = 0; i < k; ++i) {
+        if (ne[(size_t)i] < 2) return fail(c, BI_ERR_INVALID, "axis %d needs at least two edges", i);
+        bins *= ne[(size_t)i] - 1;
     }
-    HIP_TRY(c, hipGetLastError());
-    c->h_lgsum.assign((size_t)T, 0.0);
-    HIP_TRY(c, hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const double* e = edges;
+    for (int i = 0; i < k; ++i) {
+        for (int j = 1; j < ne[(size_t)i]; ++j)
+            if (!(e[j] > e[j - 1])) return fail(c, BI_ERR_INVALID, "bin edges of axis %d are not strictly ascending", i);
+        flat.insert(flat.end(), e, e + ne[(size_t)i]);
+        e += ne[(size_t)i];
+    }
+    if (bins != c->B) return fail(c, BI_ERR_INVALID, "analysis space has %lld bins, the model %lld", (long long)bins, (long long)c->B);
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->space_k = k;
+    c->space_n_edges = ne;
+    if ((rc = dev_upload(c, c->space_edges, flat))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->T = T;
-    c->dense_counts = true;
-    if ((rc = build_sparse_forms(c))) return rc;
-    c->data_ready = true;
     return BI_OK;
+}
+
+int bi_upload_events(bi_ctx* c, int64_t N, const double* coords) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (c->space_k < 1) return fail(c, BI_ERR_STATE, "bi_set_analysis_space first");
+    if (c->unbinned) return fail(c, BI_ERR_STATE, "the context holds an unbinned likelihood");
+    if (N < 0 || (N > 0 && !coords)) return fail(c, BI_ERR_INVALID, "bad N / coords");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->data_ready = false;
+    ++c->epoch;
+    const size_t bytes = (size_t)c->Bp * sizeof(double);
+    if ((rc = dev_alloc(c, c->counts, bytes))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counts.p, 0, bytes, c->stream));
+    if (N > 0) {
+        DevBuf d_ev;
+        if ((rc = dev_alloc(c, d_ev, (size_t)N * c->space_k * sizeof(double)))) return rc;
+        hipError_t e = hipMemcpyAsync(d_ev.p, coords, (size_t)N * c->space_k * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        HistArgs h{};
+        h.k = c->space_k;
+        int off = 0;
+        for (int i = 0; i < c->space_k; ++i) { h.n_edges[i] = c->space_n_edges[(size_t)i]; h.edge_off[i] = off; off += h.n_edges[i]; }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_histogram, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                               (const double*)d_ev.p, N, h, (const double*)c->space_edges.p, (double*)c->counts.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // coords are borrowed for the call only
+        dev_free(d_ev);
+        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_upload_events: %s", hipGetErrorString(e));
+    }
+    return finish_counts(c, 1);
 }
 
 // ---- planning ------------------------------------------------------------------------------

@@ -140,6 +140,22 @@ class DeviceContext:
         self._check(self._lib.bi_upload_counts(self._h, T, ptr(c)))
         self.T = T
 
+    def set_analysis_space(self, edges):
+        """edges: one ascending array of bin edges per analysis dimension."""
+        edges = [np.ascontiguousarray(e, dtype=np.float64) for e in edges]
+        n_edges = np.array([len(e) for e in edges], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(edges))
+        self._check(self._lib.bi_set_analysis_space(self._h, len(edges), ptr(n_edges), ptr(flat)))
+        self.space_dims = len(edges)
+
+    def upload_events(self, *coords):
+        """Bin events (one coordinate array per analysis dimension) on the device into dataset 0."""
+        cols = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64).ravel() for c in coords]))
+        if cols.shape[0] != self.space_dims:
+            raise ValueError("need %d coordinate arrays" % self.space_dims)
+        self._check(self._lib.bi_upload_events(self._h, cols.shape[1], ptr(cols)))
+        self.T = 1
+
     def set_unbinned(self, outlier_likelihood=1e-12):
         """Treat the uploaded rows as pdf values at the events: extended unbinned likelihood."""
         self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))

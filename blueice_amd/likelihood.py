@@ -382,6 +382,7 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         pdf_base_config['pdf_interpolation_method'] = 'piecewise'
         self.model_statistical_uncertainty_handling = self.config.get('model_statistical_uncertainty_handling')
         self._lazy_nm_interpolator = None
+        self._binned = None
 
     # -- lifecycle -------------------------------------------------------------------------
     def _bb_source_index(self):
@@ -400,7 +401,9 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         self.ps, self.n_model_events = self.base_model.pmf_grids()
         self.bin_shape = self.ps.shape[1:]
         self._stream_models(lambda m: m.pmf_grids(), int(np.prod(self.bin_shape, dtype=np.int64)))
+        self.ctx.set_analysis_space([edges for _, edges in self.base_model.config['analysis_space']])
         self._lazy_nm_interpolator = None
+        self._binned = None
 
     def _rows_of(self, model):
         return model.pmf_grids()
@@ -418,12 +421,21 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
 
     @_needs_preparation
     def set_data(self, d):
-        """Bin the events of `d` in the analysis space and keep the counts in HBM."""
+        """Bin the events of `d` in the analysis space ON THE DEVICE (numpy.histogramdd semantics, as the
+        reference's Histdd.add, likelihood.py:608-609); only the event coordinates cross PCIe."""
         LogLikelihoodBase.set_data(self, d)
-        names, edges = zip(*self.base_model.config['analysis_space'])
-        self.data_events_per_bin = Histdd(bins=edges, axis_names=names)
-        self.data_events_per_bin.add(*self.base_model.to_analysis_dimensions(d))
-        self.ctx.upload_counts(self.data_events_per_bin.histogram)
+        self.ctx.upload_events(*self.base_model.to_analysis_dimensions(d))
+        self._binned = None
+
+    @property
+    def data_events_per_bin(self):
+        """The binned data as a histogram object (`.histogram` = counts of dataset 0), fetched from the device
+        on first use -- the attribute the reference fills in set_data."""
+        if self._binned is None:
+            names, edges = zip(*self.base_model.config['analysis_space'])
+            self._binned = Histdd(bins=edges, axis_names=names)
+            self._binned.histogram = self.ctx.download_counts(0).reshape(self.bin_shape)
+        return self._binned
 
     @_needs_preparation
     def set_binned_data(self, counts):
@@ -433,9 +445,8 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         if counts.shape[-len(self.bin_shape):] != tuple(self.bin_shape):
             raise ValueError("counts must end in the analysis-space shape %s" % (tuple(self.bin_shape),))
         self._data = None
-        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
-        self.data_events_per_bin.histogram = counts.reshape((-1,) + tuple(self.bin_shape))[0].copy()
         self.ctx.upload_counts(counts)
+        self._binned = None
         self.is_data_set = True
 
     @_needs_preparation
@@ -449,8 +460,7 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
             raise ValueError("cannot simulate outside the anchor box")
         self.ctx.generate_toys(zs, scale, n_toys, seed)
         self._data = None
-        self.data_events_per_bin = Histdd(bins=[e for _, e in self.base_model.config['analysis_space']])
-        self.data_events_per_bin.histogram = self.ctx.download_counts(0).reshape(self.bin_shape)
+        self._binned = None
         self.is_data_set = True
 
     # -- analytic gradient (one device pass; the reference differentiates numerically) ----------

@@ -87,6 +87,13 @@ int bi_set_allow_negative(bi_ctx* ctx, const int32_t* allow /*[S]*/);
  * (blueice/likelihood.py:603-609).  T datasets of B float64 counts each (toy MC: T > 1). */
 int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
 
+/* set_data on the device: declare the analysis space once (config['analysis_space'] = [[name, edges], ...],
+ * blueice/likelihood.py:607), then bin N events into dataset 0 there -- numpy.histogramdd semantics, which is
+ * what multihist's Histdd.add applies in likelihood.py:608-609 (right-most edge inclusive, events outside the
+ * range dropped).  coords: [k][N] (one column per analysis dimension).  Replaces the context's data. */
+int bi_set_analysis_space(bi_ctx* ctx, int k, const int32_t* n_edges /*[k]*/, const double* edges /*concatenated*/);
+int bi_upload_events(bi_ctx* ctx, int64_t N, const double* coords);
+
 /* Extended unbinned likelihood on the same machinery (UnbinnedLogLikelihood, blueice/likelihood.py:528-573;
  * extended_loglikelihood :678-690).  Upload the model with B = number of events and `ps` = the pdf values
  * of every source at every event for every anchor (what `Model.score_events(d)` returns,

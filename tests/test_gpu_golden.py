@@ -111,3 +111,33 @@ def test_state_errors():
         c.d, c.S, c.B = 0, 1, 1
         c.eval(None, [[1.]])
     c.close()
+
+
+def test_device_histogram_equals_numpy_histogramdd(ctx):
+    """bi_upload_events (set_data on the device) against numpy.histogramdd, the semantics of the reference's
+    binning (likelihood.py:608-609): non-uniform edges, events on edges, out of range, nan."""
+    rng = np.random.default_rng(5)
+    edges = [np.array([0., 1., 2.5, 7.]), np.linspace(-1, 1, 6), np.array([-3., 0., 0.5, 4., 4.25])]
+    shape = tuple(len(e) - 1 for e in edges)
+    B = int(np.prod(shape))
+    ctx.upload_model([], np.full((1, B), 1.0 / B), np.array([10.]))
+    ctx.set_analysis_space(edges)
+    N = 20000
+    x = rng.uniform(-1, 8, N)
+    y = rng.uniform(-1.3, 1.3, N)
+    w = rng.uniform(-4, 5, N)
+    x[:6] = [7., 0., 2.5, 1., 7.0000001, np.nan]
+    y[:6] = [1., -1., 0.2, -0.6, 0., 0.]
+    w[:6] = [4.25, -3., 0.5, 0., 1., 1.]
+    ctx.upload_events(x, y, w)
+    got = ctx.download_counts(0).reshape(shape)
+    keep = ~(np.isnan(x) | np.isnan(y) | np.isnan(w))
+    want = np.histogramdd(np.stack([x[keep], y[keep], w[keep]], 1), bins=edges)[0]
+    np.testing.assert_array_equal(got, want)
+    assert got.sum() < N
+    ll, st = ctx.eval(None, [[1.]])
+    assert np.isfinite(ll[0]) and st[0] == 0
+    ctx.upload_events(np.zeros(0), np.zeros(0), np.zeros(0))            # empty dataset
+    assert ctx.download_counts(0).sum() == 0
+    with pytest.raises(ValueError):
+        ctx.set_analysis_space([np.array([0., 1.])])                    # bin count mismatch

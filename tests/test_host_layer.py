@@ -40,6 +40,19 @@ class RecordingContext:
         self.counts = np.array(counts, float)
         self.T = self.counts.size // self.B
 
+    def set_analysis_space(self, edges):
+        self.edges = [np.asarray(e, float) for e in edges]
+
+    def upload_events(self, *coords):
+        # the recorder bins on the host only to let the test compare with the reference's counts; the
+        # device kernel that does it for real is pinned against numpy.histogramdd in tests/test_gpu_golden.py
+        sample = np.stack([np.asarray(c, float).ravel() for c in coords], axis=1)
+        self.counts = np.histogramdd(sample, bins=self.edges)[0] if len(sample) else np.zeros([len(e) - 1 for e in self.edges])
+        self.T = 1
+
+    def download_counts(self, t=0):
+        return np.array(self.counts, float).ravel()
+
     def set_unbinned(self, outlier):
         self.outlier = outlier
         self.T = 1
