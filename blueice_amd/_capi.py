@@ -12,7 +12,7 @@ import numpy as np
 from .exceptions import DeviceError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libblueice_hip.so')
+LIB_PATH = os.environ.get('BLUEICE_AMD_LIB') or os.path.join(_HERE, 'lib', 'libblueice_hip.so')   # env: A/B builds
 
 # status bits (include/blueice_hip.h)
 ST_OUT_OF_BOUNDS, ST_UNPHYSICAL, ST_BB_ROOT1, ST_BB_NEG, ST_BAD_DATASET = 1, 2, 4, 8, 16
