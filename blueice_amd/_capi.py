@@ -33,6 +33,8 @@ SIGNATURES = {
     'bi_model_begin': (C.c_int, [_p, C.c_int, _p, _p, C.c_int, _i64, C.c_int]),
     'bi_model_set_anchor': (C.c_int, [_p, _i64, _p, _p, _p]),
     'bi_model_end': (C.c_int, [_p]),
+    'bi_get_bb_totals': (C.c_int, [_p, _p]),
+    'bi_set_bb_totals': (C.c_int, [_p, _p]),
     'bi_set_allow_negative': (C.c_int, [_p, _p]),
     'bi_upload_counts': (C.c_int, [_p, _i64, _p]),
     'bi_set_analysis_space': (C.c_int, [_p, C.c_int, _p, _p]),

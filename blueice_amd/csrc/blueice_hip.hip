@@ -315,6 +315,24 @@ int bi_set_allow_negative(bi_ctx* c, const int32_t* allow) {
     return BI_OK;
 }
 
+int bi_set_bb_totals(bi_ctx* c, const double* totals) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (c->bb_source < 0) return fail(c, BI_ERR_INVALID, "the model has no Beeston-Barlow source");
+    if (!totals) return fail(c, BI_ERR_INVALID, "totals is NULL");
+    c->h_nm_tot.assign(totals, totals + c->A);
+    ++c->epoch;
+    return BI_OK;
+}
+
+int bi_get_bb_totals(bi_ctx* c, double* totals) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (c->bb_source < 0 || !totals) return fail(c, BI_ERR_INVALID, "no Beeston-Barlow source / totals is NULL");
+    std::copy(c->h_nm_tot.begin(), c->h_nm_tot.end(), totals);
+    return BI_OK;
+}
+
 // ---- data ----------------------------------------------------------------------------------
 
 int bi_upload_counts(bi_ctx* c, int64_t T, const double* counts) {

@@ -123,6 +123,18 @@ class DeviceContext:
     def end_model(self):
         self._check(self._lib.bi_model_end(self._h))
 
+    def bb_totals(self, new=None):
+        """Per-anchor sums of the Beeston-Barlow source's MC counts; pass `new` to overwrite them with the
+        globally reduced values when the bins are sharded over ranks."""
+        n_anchor = int(np.prod([len(g) for g in self.anchor_z], dtype=np.int64)) if self.anchor_z else 1
+        if new is None:
+            out = np.empty(n_anchor, dtype=np.float64)
+            self._check(self._lib.bi_get_bb_totals(self._h, ptr(out)))
+            return out
+        new = as_f64(new, (n_anchor,))
+        self._check(self._lib.bi_set_bb_totals(self._h, ptr(new)))
+        return new
+
     def set_allow_negative(self, flags):
         flags = np.ascontiguousarray(flags, dtype=np.int32)
         if flags.shape != (self.S,):

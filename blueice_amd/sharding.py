@@ -10,7 +10,8 @@ The reference has no counterpart: its scans are Python loops over `lf(**kw)`
 """
 import numpy as np
 
-__all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys']
+__all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys',
+           'allreduce_sum', 'bin_sharded_eval']
 
 
 def split_range(n, rank, world):
@@ -107,3 +108,29 @@ def sharded_eval_toys(eval_range_fn, T, dist=None):
     t0, t1 = ranges[rank]
     local = np.asarray(eval_range_fn(t0, t1), dtype=np.float64) if t1 > t0 else np.zeros(0)
     return np.concatenate(gather_vector(local, [b - a for a, b in ranges], dist))
+
+
+def allreduce_sum(local, dist=None):
+    """Element-wise sum of an fp64 vector over the ranks (identity for a single process)."""
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    import torch
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.from_numpy(local.copy()).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def bin_sharded_eval(ctx, z, rate_scale, dist=None):
+    """The one configuration with a real exchange step: an anchor tensor too large for
+    one GPU is sharded over the BIN axis -- `ctx` holds this rank's slice of the bins of every template row and
+    of the data -- every rank evaluates all P points on its slice, and the partial log likelihoods are summed
+    with ONE all-reduce of P doubles.  Everything in the likelihood is additive over bins; the only global
+    quantity, the Beeston-Barlow normalisation sum_b n_model[bb, b], is all-reduced once per model
+    (`ctx.bb_totals`) before the first evaluation."""
+    if ctx.bb_source >= 0 and not getattr(ctx, '_bb_totals_global', False):
+        ctx.bb_totals(allreduce_sum(ctx.bb_totals(), dist))
+        ctx._bb_totals_global = True
+    ll, status = ctx.eval(z, rate_scale)
+    return allreduce_sum(ll, dist), status

@@ -80,6 +80,13 @@ int bi_model_set_anchor(bi_ctx* ctx, int64_t anchor_index, const double* ps, con
                         const double* n_model_row);
 int bi_model_end(bi_ctx* ctx);
 
+/* Bin-sharded models (a tensor too large for one GPU: every rank holds a slice of the bins of every row and
+ * the per-rank log likelihoods add up).  Everything is additive over bins except the Beeston-Barlow
+ * normalisation N_c = sum over ALL bins of n_model[c, bb_source, :] (likelihood.py:645): read the local sums,
+ * all-reduce them across ranks, and write the global ones back before evaluating.  totals: [A]. */
+int bi_get_bb_totals(bi_ctx* ctx, double* totals);
+int bi_set_bb_totals(bi_ctx* ctx, const double* totals);
+
 /* per-source `allow_negative` flags (likelihood.py:82-83,397-415); default all 0 */
 int bi_set_allow_negative(bi_ctx* ctx, const int32_t* allow /*[S]*/);
 

@@ -111,3 +111,51 @@ def test_two_gloo_ranks_equal_single_process():
         np.testing.assert_array_equal(ll, want)            # every rank holds the full gathered vector
         np.testing.assert_array_equal(lt, want_t)
         assert 17 <= n_eval <= 20                          # each rank evaluated about half of the 37 points
+
+
+def _bins_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from blueice_amd.sharding import bin_sharded_eval, split_range
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        m = SyntheticModel.named('mini3')
+        dense, counts = m.dense_model(), m.counts(dense=True)
+        lo, hi = split_range(m.B, rank, world)
+        local = dict(anchor_z=dense['anchor_z'], ps=dense['ps'][..., lo:hi], mus=dense['mus'], n_model=None)
+
+        class SliceCtx:                       # stands where a DeviceContext holding this rank's bins would
+            bb_source = -1
+
+            def eval(self, z, r):
+                return orc.loglikelihood_batch(local, counts[lo:hi], z, r), np.zeros(len(z), np.int32)
+
+        z, r = m.random_points(9, seed=3)
+        ll, _ = bin_sharded_eval(SliceCtx(), z, r, dist)
+        q.put((rank, ll))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bin_sharding_allreduce_two_gloo_ranks():
+    import torch.multiprocessing as mp
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bins_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = SyntheticModel.named('mini3')
+    z, r = m.random_points(9, seed=3)
+    want = orc.loglikelihood_batch(m.dense_model(), m.counts(dense=True), z, r)
+    for rank, ll in got:
+        np.testing.assert_allclose(ll, want, rtol=1e-12)

@@ -109,3 +109,37 @@ def test_results_land_in_a_torch_device_tensor(tmp_path):
     script.write_text(_TORCH_SCRIPT)
     res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'TORCH_TENSOR_OK' in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize('bb', [-1, 0])
+def test_bin_sharded_partials_add_up(bb):
+    """Bin sharding (the fallback for tensors larger than one GPU's HBM): two contexts holding complementary bin
+    slices; their partial log likelihoods sum to the full one once the Beeston-Barlow totals are global."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini4bb' if bb >= 0 else 'mini3', bb_source=bb)
+    dense = m.dense_model()
+    counts = m.counts(dense=True)
+    z, r = m.random_points(25, seed=6)
+    full = DeviceContext(0)
+    full.upload_model(dense['anchor_z'], dense['ps'], dense['mus'], n_model=dense['n_model'], bb_source=bb)
+    full.upload_counts(counts)
+    want, _ = full.eval(z, r)
+    cut = m.B // 3 + 1
+    parts, ctxs = [], []
+    for sl in (slice(0, cut), slice(cut, m.B)):
+        c = DeviceContext(0)
+        c.upload_model(dense['anchor_z'], dense['ps'][..., sl], dense['mus'],
+                       n_model=None if bb < 0 else dense['n_model'][..., sl], bb_source=bb)
+        c.upload_counts(counts[sl])
+        ctxs.append(c)
+    if bb >= 0:
+        tot = sum(c.bb_totals() for c in ctxs)            # what the all-reduce does across ranks
+        np.testing.assert_allclose(tot, full.bb_totals(), rtol=1e-14)
+        for c in ctxs:
+            c.bb_totals(tot)
+    for c in ctxs:
+        parts.append(c.eval(z, r)[0])
+        c.close()
+    np.testing.assert_allclose(parts[0] + parts[1], want, rtol=1e-12)
+    full.close()
