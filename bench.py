@@ -98,6 +98,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     dist = None
     torch = None
+    if args.gpus != world:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d; N > 1 must be launched through torch.distributed.run '
+              '(one rank per GPU) -- running with %d rank(s)' % (args.gpus, world, world), file=sys.stderr)
     n_dev = 1
     if world > 1:
         import torch
