@@ -90,7 +90,7 @@ struct bi_ctx {
     std::vector<double> h_Tz;                 // [T][A*S] sum of every ps row over the EMPTY bins of the dataset
 
     // persistent single-point slot (the lf(**kw) call shape): no allocation, one H2D, one D2H per call
-    DevBuf slot_dev, slot_partial, slot_pflags;
+    DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
 
@@ -108,6 +108,8 @@ struct bi_ctx {
     // tunables
     int64_t blocks_per_cu = 8;
     int64_t max_group = kMaxG;
+    int64_t fuse_max_blocks = 64;                // finish inside the launch up to this many blocks
+    int64_t single_kernel = 1;                   // bi_eval(P = 1): one fused launch (0: two-kernel fallback)
     int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse
     int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent
     int64_t compact_budget = (int64_t)16 << 30;  // bytes of HBM the compacted templates may take

@@ -84,25 +84,14 @@ __device__ __forceinline__ double2 stream_load(const double* p) {
     }
 }
 
-// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
-// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
-// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
-// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
-template <int G, bool BB, bool NT, int MODE = 0>
-__global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
-    const int item = blockIdx.y;
-    const int NS = a.n0 + a.n1 + a.n2;
-    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
-    const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
-    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
-    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
-
-    double sum[G];
-    unsigned flg[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+// The accumulate + per-bin term loop shared by the batched kernel and the single-point kernel: tiles
+// tile0, tile0 + tile_step, ... of one work item.
+template <int G, bool BB, bool NT, int MODE>
+__device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* __restrict__ rowoff,
+                                            const double* __restrict__ coef, const double* __restrict__ aux_base,
+                                            const double* __restrict__ cnt, int n_tiles, int tile0, int tile_step,
+                                            double (&sum)[G], unsigned (&flg)[G]) {
+    for (int tile = tile0; tile < n_tiles; tile += tile_step) {
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
         double acc[G][2];
 #pragma unroll
@@ -170,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
                     ai[g][1] = fma(c, v.y, ai[g][1]);
                 }
             }
-            const double* __restrict__ aux = a.aux + (int64_t)item * G * 2;
+            const double* __restrict__ aux = aux_base;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const double p_cal = aux[g * 2 + 0];
@@ -196,6 +185,28 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
         }
     }
 
+}
+
+// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
+// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
+// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
+// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
+template <int G, bool BB, bool NT, int MODE = 0>
+__global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
+    const int item = blockIdx.y;
+    const int NS = a.n0 + a.n1 + a.n2;
+    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
+    const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
+    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
+    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
+
+    double sum[G];
+    unsigned flg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
+
+    morph_tiles<G, BB, NT, MODE>(a, rowoff, coef, a.aux + (int64_t)item * G * 2, cnt, n_tiles, (int)blockIdx.x, (int)gridDim.x, sum, flg);
+
     __shared__ double s_sum[kThreads / 64][G];
     __shared__ unsigned s_flg[kThreads / 64][G];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,6 +226,112 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
         const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * G + g;
         a.partial[o] = s;
         a.pflags[o] = f;
+    }
+}
+
+// ---- the single-point kernel: ONE launch from templates to scalar --------------------------------
+// The call shape of `lf(**kwargs)` inside a minimizer.  The point's stream descriptors (row offsets and
+// coefficients, <= kMaxSingleStreams of them) travel in the kernel-argument block, so the scalar loads hit the
+// kernarg segment and no host-to-device copy precedes the launch; and the reduction is finished inside the
+// launch: every block publishes its partial with an agent-scope release, draws a ticket, and the block that
+// draws the last one acquires and sums all partials in block order (fixed order => bitwise reproducible) and
+// writes {ll, status} straight into pinned host memory.  (Release / acquire exactly as the compiler lowers
+// __atomic_thread_fence at agent scope; MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".)
+constexpr int kMaxSingleStreams = 128;
+
+struct SingleDesc {
+    int64_t rowoff[kMaxSingleStreams];
+    double coef[kMaxSingleStreams];
+    double aux[2];        // Beeston-Barlow: p_cal, N
+    double slot_lg;       // constant subtracted from the sum (sum lgamma, empty-bin term, or sum of rates)
+    unsigned* counter;    // zero on entry, re-armed by the finishing block
+    double* out;          // pinned host
+    int32_t* status;      // pinned host
+};
+
+template <bool BB, bool NT, int MODE, bool FUSE>
+__global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleDesc d) {
+    double sum[1] = {0.0};
+    unsigned flg[1] = {0u};
+    morph_tiles<1, BB, NT, MODE>(a, d.rowoff, d.coef, d.aux, a.counts, a.n_tiles, (int)blockIdx.x, (int)gridDim.x, sum, flg);
+
+    __shared__ double s_sum[kThreads / 64];
+    __shared__ unsigned s_flg[kThreads / 64];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const double s = wave_sum(sum[0]);
+        const unsigned f = BB ? wave_or(flg[0]) : 0u;
+        if (lane == 0) { s_sum[wave] = s; s_flg[wave] = f; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = s_sum[0];
+        unsigned f = s_flg[0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w]; f |= s_flg[w]; }
+        a.partial[blockIdx.x] = s;
+        a.pflags[blockIdx.x] = f;
+        if constexpr (!FUSE) return;   // many blocks: a second, tiny launch sums the partials (k_finish_single)
+        // publish: drain this wave's stores, agent-scope release, then the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if constexpr (!FUSE) return;
+    __syncthreads();
+    if (!s_last) return;
+    // the last block to arrive: sum the partials of all blocks in block order
+    double s = 0.0;
+    unsigned f = 0u;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kThreads) {
+        s += a.partial[b];
+        f |= a.pflags[b];
+    }
+    s = wave_sum(s);
+    f = wave_or(f);
+    __syncthreads();   // s_sum / s_flg are reused
+    if (lane == 0) { s_sum[wave] = s; s_flg[wave] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_sum[0];
+        unsigned ff = s_flg[0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) { t += s_sum[w]; ff |= s_flg[w]; }
+        *d.out = t - d.slot_lg;
+        *d.status = (int32_t)ff;
+        *d.counter = 0u;   // re-arm for the next launch on this stream
+    }
+}
+
+// second launch of the single-point path when the grid is too large for in-launch finishing to pay
+// (an agent-scope release per block costs more than a kernel boundary once there are hundreds of blocks)
+__global__ __launch_bounds__(kThreads) void k_finish_single(const double* __restrict__ partial,
+                                                            const unsigned* __restrict__ pflags, int nbx, double slot_lg,
+                                                            double* __restrict__ out, int32_t* __restrict__ status) {
+    __shared__ double sh[kThreads / 64];
+    __shared__ unsigned shf[kThreads / 64];
+    double s = 0.0;
+    unsigned f = 0u;
+#pragma unroll 8
+    for (int b = threadIdx.x; b < nbx; b += kThreads) { s += partial[b]; f |= pflags[b]; }
+    s = wave_sum(s);
+    f = wave_or(f);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shf[threadIdx.x >> 6] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        unsigned ff = shf[0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; ff |= shf[w]; }
+        *out = t - slot_lg;
+        *status = (int32_t)ff;
     }
 }
 

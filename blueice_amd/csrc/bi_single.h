@@ -3,6 +3,107 @@
 
 namespace {
 
+
+// The fused form: descriptors in the kernel arguments, reduction finished inside the launch, result written
+// to pinned host memory -- one launch and one stream sync per call.
+int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_t ds, bool sparse, double* out, int32_t* status) {
+    const int S = c->S;
+    const bool bb = c->bb_source >= 0;
+    const int nc = (int)g.w.size();
+    const int n0 = bb ? nc * (S - 1) : nc * S, n1 = bb ? nc : 0, n2 = bb ? nc : 0;
+    const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
+    const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
+    const int tiles = (int)(row_stride / kTile);
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
+    const int nbx = (int)std::min<int64_t>(tiles, slots);
+    int rc;
+    if (!c->slot_host) {
+        HIP_TRY(c, hipHostMalloc(&c->slot_host, 4096, hipHostMallocDefault));
+        c->slot_host_bytes = 4096;
+    }
+    if (!c->slot_counter.p) {
+        if ((rc = dev_alloc(c, c->slot_counter, 64))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->slot_counter.p, 0, 64, c->stream));
+    }
+    if ((rc = dev_alloc(c, c->slot_partial, (size_t)slots * sizeof(double))) ||
+        (rc = dev_alloc(c, c->slot_pflags, (size_t)slots * sizeof(unsigned))))
+        return rc;
+    SingleDesc d;
+    const int64_t n_rows = c->A * S;
+    int k = 0;
+    double zsum = 0.0;
+    for (int corner = 0; corner < nc; ++corner) {
+        const int64_t a = g.cell_anchor + corner_offset(c, corner);
+        for (int s = 0; s < S; ++s) {
+            if (bb && s == c->bb_source) continue;
+            d.rowoff[k] = row_base + (a * S + s) * row_stride;
+            d.coef[k] = g.w[(size_t)corner] * rates[s];
+            if (sparse) zsum += d.coef[k] * c->h_Tz[(size_t)(ds * n_rows + a * S + s)];
+            ++k;
+        }
+    }
+    d.aux[0] = d.aux[1] = 1.0;
+    if (bb) {
+        double Ntot = 0.0;
+        for (int corner = 0; corner < nc; ++corner) {
+            const int64_t a = g.cell_anchor + corner_offset(c, corner);
+            d.rowoff[n0 + corner] = (a * S + c->bb_source) * c->Bp;
+            d.coef[n0 + corner] = g.w[(size_t)corner];
+            d.rowoff[n0 + n1 + corner] = a * c->Bp;
+            d.coef[n0 + n1 + corner] = g.w[(size_t)corner];
+            const double term = c->h_nm_tot[(size_t)a] * g.w[(size_t)corner];
+            Ntot = Ntot + term;
+        }
+        d.aux[0] = rates[c->bb_source] / Ntot;
+        d.aux[1] = Ntot;
+    }
+    d.slot_lg = c->h_lgsum[(size_t)ds] + zsum;
+    if (c->unbinned) {
+        double rsum = 0.0;
+        for (int s = 0; s < S; ++s) rsum += rates[s];
+        d.slot_lg = rsum;
+    }
+    char* res = (char*)c->slot_host;
+    *(double*)res = 0.0;
+    *(int64_t*)(res + 8) = 0;
+    d.counter = (unsigned*)c->slot_counter.p;
+    d.out = (double*)res;
+    d.status = (int32_t*)(res + 8);
+    LaunchArgs a{};
+    a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
+    a.nm = (const double*)c->nm.p;
+    a.counts = (sparse ? (const double*)c->cnt_c.p + c->h_cnt_off[(size_t)ds] : (const double*)c->counts.p + ds * c->Bp);
+    a.partial = (double*)c->slot_partial.p;
+    a.pflags = (unsigned*)c->slot_pflags.p;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
+    a.outlier = c->outlier;
+    const bool nt = !sparse && c->nt_loads != 0;
+    const bool fuse = nbx <= c->fuse_max_blocks;
+    const dim3 grid((unsigned)nbx), block(kThreads);
+    {
+        EventScope ev(c);
+#define BI_SINGLE(BBv, MODEv)                                                                                          \
+    do {                                                                                                               \
+        if (nt && fuse) hipLaunchKernelGGL((k_morph_single<BBv, true, MODEv, true>), grid, block, 0, c->stream, a, d);    \
+        else if (nt) hipLaunchKernelGGL((k_morph_single<BBv, true, MODEv, false>), grid, block, 0, c->stream, a, d);      \
+        else if (fuse) hipLaunchKernelGGL((k_morph_single<BBv, false, MODEv, true>), grid, block, 0, c->stream, a, d);    \
+        else hipLaunchKernelGGL((k_morph_single<BBv, false, MODEv, false>), grid, block, 0, c->stream, a, d);             \
+    } while (0)
+        if (c->unbinned) BI_SINGLE(false, 2);
+        else if (bb) BI_SINGLE(true, 0);
+        else BI_SINGLE(false, 0);
+#undef BI_SINGLE
+    }
+    if (!fuse)
+        hipLaunchKernelGGL(k_finish_single, dim3(1), block, 0, c->stream, (const double*)a.partial, (const unsigned*)a.pflags,
+                           nbx, d.slot_lg, d.out, d.status);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = *(double*)res;
+    if (status) *status = *(int32_t*)(res + 8);
+    return BI_OK;
+}
+
 // One point, synchronous: the call shape of `lf(**kwargs)` inside a minimizer (inference.py:111-122 makes
 // ~500 of them per fit).  Same kernels as the batched path, but the descriptors live in a persistent
 // device slot fed from pinned memory: one small H2D, two launches, one 16-byte D2H, one sync.
@@ -33,6 +134,9 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int nbx = (int)std::min<int64_t>(tiles, slots);
 
+    if (NS <= kMaxSingleStreams && c->single_kernel) return eval_single_fused(c, g, rates, ds, sparse, out, status);
+
+    // general fallback (more streams than fit the kernel-argument block):
     // slot layout (8-byte units): rowoff[NS] coef[NS] aux[2] cnt_off tiles perm slot_lg | result {ll, status}
     const size_t n_words = (size_t)NS * 2 + 2 + 4 + 2;
     const size_t bytes = n_words * 8;

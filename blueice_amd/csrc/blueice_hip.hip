@@ -108,7 +108,7 @@ void bi_destroy(bi_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
-    dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->space_edges);
+    dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
@@ -149,6 +149,8 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
         return BI_OK;
     }
     if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
+    if (!strcmp(name, "single_kernel")) { c->single_kernel = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
         c->nt_loads = v;
@@ -164,6 +166,8 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "tile_bins")) return kTile;
     if (!strcmp(name, "padded_bins")) return c->Bp;
     if (!strcmp(name, "sparse")) return c->sparse;
+    if (!strcmp(name, "single_kernel")) return c->single_kernel;
+    if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
