@@ -108,6 +108,7 @@ struct bi_ctx {
     // tunables
     int64_t blocks_per_cu = 8;
     int64_t max_group = kMaxG;
+    int64_t xcd_affine = 1;                      // multi-item launches: tile chunks keep their XCD across items
     int64_t fuse_max_blocks = 64;                // finish inside the launch up to this many blocks
     int64_t single_kernel = 1;                   // bi_eval(P = 1): one fused launch (0: two-kernel fallback)
     int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse

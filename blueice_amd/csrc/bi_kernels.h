@@ -20,6 +20,34 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
     return v;
 }
 
+// Natural logarithm for the per-bin terms: argument reduction x = m * 2^k with m in [sqrt(1/2), sqrt(2)), then
+// log(m) = 2 s + s * R(s^2) with s = f / (2 + f), f = m - 1 and a degree-7 minimax polynomial (the classic
+// Remez fit published with the fdlibm algorithm; error < 1 ulp).  About 35 fp64 instructions against ~75 for
+// the double-double library version -- the log is what bounds passes with several points per cell.
+// Zero, denormal, negative, infinite and nan arguments take the library path (wave-divergent but rare).
+__device__ __forceinline__ double bin_log(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x < __builtin_inf())) return log(x);
+    double m = __builtin_amdgcn_frexp_mant(x);       // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752440) { m += m; k -= 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+// self-test hook: out[i] = bin_log(x[i])
+__global__ void k_selftest_log(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bin_log(x[i]);
+}
+
 // Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
 // (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
 //   mu not >= 0 (negative or nan) or n nan -> nan
@@ -28,7 +56,7 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
 __device__ __forceinline__ double poisson_term(double n, double mu) {
     double t;
     if (n > 0.0) {
-        t = n * log(mu) - mu;  // mu = 0 -> -inf; mu < 0 -> nan
+        t = n * bin_log(mu) - mu;  // mu = 0 -> -inf; mu < 0 -> nan
     } else {
         t = -mu;
     }
@@ -120,7 +148,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                     if (bin0 + j < a.B) {
                         double lam = acc[g][j];
                         if (a.outlier != 0.0 && !(lam > 0.0)) lam = a.outlier;
-                        sum[g] += log(lam);
+                        sum[g] += bin_log(lam);
                     }
                 }
             }

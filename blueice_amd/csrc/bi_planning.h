@@ -204,6 +204,10 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         const int64_t max_tiles = sparse ? *std::max_element(h.tiles.begin(), h.tiles.end()) : n_tiles;
         int64_t nbx = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + total_items - 1) / total_items));
         if (total_items == 1) nbx = std::min<int64_t>(max_tiles, slots);
+        // Blocks are dealt round-robin over the 8 XCDs, so with nbx a multiple of 8 the tile chunk blockIdx.x of
+        // EVERY item lands on XCD x % 8: items that share template rows (same or neighbouring cell) then find
+        // them in that XCD's L2 instead of each XCD fetching every tile (speed only, never correctness).
+        if (c->xcd_affine && total_items > 1 && nbx > 4 && nbx < max_tiles) nbx = std::min<int64_t>(max_tiles, (nbx + 7) / 8 * 8);
         k.nbx = (int)nbx;
         if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
             (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_cnt, h.cnt_off)) ||

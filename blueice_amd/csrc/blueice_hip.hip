@@ -151,6 +151,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
     if (!strcmp(name, "single_kernel")) { c->single_kernel = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
+    if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
         c->nt_loads = v;
@@ -168,6 +169,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "sparse")) return c->sparse;
     if (!strcmp(name, "single_kernel")) return c->single_kernel;
     if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
+    if (!strcmp(name, "xcd_affine")) return c->xcd_affine;
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
@@ -1004,6 +1006,27 @@ int bi_eval_full(bi_ctx* c, const double* z, const double* rate_scale, int64_t d
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_full: %s", hipGetErrorString(e));
     mus_out[i] = tot * p_cal;  // likelihood.py:658
+    return BI_OK;
+}
+
+// ---- self-tests of device math ---------------------------------------------------------------
+
+int bi_selftest_log(bi_ctx* c, int64_t n, const double* x, double* out) {
+    if (!c || n < 0 || (n > 0 && (!x || !out))) return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf dx, dy;
+    int rc;
+    if ((rc = dev_alloc(c, dx, (size_t)std::max<int64_t>(n, 1) * sizeof(double))) ||
+        (rc = dev_alloc(c, dy, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) { dev_free(dx); dev_free(dy); return rc; }
+    hipError_t e = n ? hipMemcpyAsync(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_selftest_log, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)dx.p, n, (double*)dy.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && n) e = hipMemcpyAsync(out, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(dx); dev_free(dy);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_selftest_log: %s", hipGetErrorString(e));
     return BI_OK;
 }
 

@@ -184,6 +184,9 @@ void bi_plan_destroy(bi_ctx* ctx, bi_plan* plan);
 int bi_sync(bi_ctx* ctx);
 void* bi_stream(bi_ctx* ctx); /* the hipStream_t the context launches on */
 
+/* self-test of the device logarithm used in the per-bin terms: out[i] = log(x[i]) as the kernels compute it */
+int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * While enabled, every morph+reduce launch is bracketed by HIP events on the context stream;
  * bi_profile_read drains them: number of launches and summed GPU time in milliseconds. */

@@ -141,3 +141,23 @@ def test_device_histogram_equals_numpy_histogramdd(ctx):
     assert ctx.download_counts(0).sum() == 0
     with pytest.raises(ValueError):
         ctx.set_analysis_space([np.array([0., 1.])])                    # bin count mismatch
+
+
+def test_device_log_accuracy(ctx):
+    """The lean logarithm of the per-bin terms against numpy (glibc) over the whole double range:
+    <= 1 ulp on normal arguments, library behaviour on 0 / denormal / negative / inf / nan."""
+    from blueice_amd._capi import ptr
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-307, 308, 200000), rng.uniform(0.5, 2.0, 200000),
+                        1.0 + rng.uniform(-1e-6, 1e-6, 50000), np.array([1.0, 2.0, 0.5, np.e, 0.70710678118654752, 1e-320,
+                        0.0, -1.0, np.inf, np.nan, 2.2250738585072014e-308, 1.7976931348623157e308])])
+    out = np.empty_like(x)
+    assert ctx._lib.bi_selftest_log(ctx._h, len(x), ptr(x), ptr(out)) == 0
+    with np.errstate(all='ignore'):
+        ref = np.log(x)
+    fin = np.isfinite(ref)
+    ulp = np.abs(out[fin] - ref[fin]) / np.spacing(np.abs(ref[fin]))
+    assert ulp.max() <= 1.0, ulp.max()
+    assert np.mean(ulp == 0) > 0.85
+    assert out[-6] == -np.inf and np.isnan(out[-5]) and out[-4] == np.inf and np.isnan(out[-3])
+    assert out[len(x) - 12] == 0.0            # log(1) exactly
