@@ -93,6 +93,12 @@ def main():
                     'rehearsals on a box with fewer GPUs than ranks)')
     args = ap.parse_args()
 
+    # stdout must carry exactly one JSON line: native libraries (RCCL's banner, gloo) write to fd 1 too, so fd 1
+    # points at stderr until the line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -102,7 +108,8 @@ def main():
         print('bench.py: --gpus %d but WORLD_SIZE=%d; N > 1 must be launched through torch.distributed.run '
               '(one rank per GPU) -- running with %d rank(s)' % (args.gpus, world, world), file=sys.stderr)
     n_dev = 1
-    if world > 1:
+    force_dist = bool(os.environ.get('BLUEICE_BENCH_FORCE_DIST'))      # rehearse the N > 1 code path with one rank
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -113,14 +120,15 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(args.backend)
-    use_cuda_tensors = world > 1 and args.backend == 'nccl'
+    multi = world > 1 or force_dist
+    use_cuda_tensors = multi and args.backend == 'nccl'
 
     from blueice_amd.device import DeviceContext
     from blueice_amd.synthetic import SyntheticModel
 
     K, W = args.steps, args.warmup
     model = SyntheticModel.named(args.config)
-    ctx = DeviceContext(local_rank % n_dev if world > 1 else local_rank)
+    ctx = DeviceContext(local_rank % n_dev if multi else local_rank)
     info = ctx.info()
     model.upload(ctx)
     counts = model.counts()
@@ -141,13 +149,13 @@ def main():
         out = torch.empty(K * PPS, dtype=torch.float64, device='cuda')
         gathered = [torch.empty(K * PPS, dtype=torch.float64, device='cuda') for _ in range(world)]
         out_ptr = out.data_ptr()
-    elif world > 1:
+    elif multi:
         out = torch.empty(K * PPS, dtype=torch.float64)
         gathered = [torch.empty(K * PPS, dtype=torch.float64) for _ in range(world)]
 
     def barrier():
         ctx.sync()
-        if world > 1:
+        if multi:
             if use_cuda_tensors:
                 torch.cuda.synchronize()
             dist.barrier()
@@ -167,7 +175,7 @@ def main():
     t0 = time.perf_counter()
     run_steps(K)
     ctx.sync()
-    if world > 1:
+    if multi:
         if not use_cuda_tensors:               # rehearsal backend: last step's results via the host
             last, _ = plans[(K - 1) % POOL].read()
             out[-PPS:] = torch.from_numpy(last)
@@ -176,7 +184,7 @@ def main():
             torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if use_cuda_tensors else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -330,11 +338,14 @@ def main():
         result['cpu_baseline'] = None
 
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(result), flush=True)
+        os.dup2(2, 1)
     for p in plans:
         p.close()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
