@@ -167,7 +167,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
             double pi[G][2], ai[G][2];
 #pragma unroll
             for (int g = 0; g < G; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < a.n1; ++k) {
                 const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
 #pragma unroll
@@ -177,7 +177,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                     pi[g][1] = fma(c, v.y, pi[g][1]);
                 }
             }
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < a.n2; ++k) {
                 const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
 #pragma unroll
