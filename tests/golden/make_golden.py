@@ -24,6 +24,8 @@ Each fixture `<case>.npz` holds
     bb_source                       -1 or the Beeston-Barlow source index
     livetime_base                   pdf_base_config['livetime_days'] or nan
     call_z [N, d], call_mult [N, S], call_livetime [N] (nan = not given), call_ll [N]
+    call_scale [N, S]               rate multiplier x livetime scaling x efficiency: what multiplies mus
+    allow_negative [S]              the sources' allow_negative flags
     call_asserts_<j>                present when the reference raised AssertionError on call j
     full_<j>_mus / full_<j>_ps      `full_output=True` results for call j (a few calls)
 fit_c1_like.npz additionally holds bestfit_scipy results (names, values, max logL).
@@ -99,7 +101,7 @@ def tensors_of(lf):
 def dump(name, lf, calls, full=()):
     t = tensors_of(lf)
     shape_names = list(lf.shape_parameters.keys())
-    zs, mults, lts, lls = [], [], [], []
+    zs, mults, lts, lls, scales = [], [], [], [], []
     for j, kw in enumerate(calls):
         kw = dict(kw)
         lt = kw.get('livetime_days', np.nan)
@@ -111,6 +113,13 @@ def dump(name, lf, calls, full=()):
         mult, settings = lf._kwargs_to_settings(**{k: v for k, v in kw.items() if k != 'livetime_days'})
         zs.append([settings[n] for n in shape_names])
         mults.append(mult)
+        sc = np.array(mult, dtype=float)
+        if not (isinstance(lt, float) and np.isnan(lt)):
+            sc = sc * (lt / lf.pdf_base_config['livetime_days'])
+        for i_s, (use, en) in enumerate(zip(lf.source_apply_efficiency, lf.source_efficiency_names)):
+            if use:
+                sc[i_s] *= settings.get(en, 1)
+        scales.append(sc)
         lts.append(lt)
         lls.append(ll)
         if j in full and np.isfinite(ll):
@@ -121,6 +130,8 @@ def dump(name, lf, calls, full=()):
     t['call_mult'] = np.asarray(mults, dtype=float)
     t['call_livetime'] = np.asarray(lts, dtype=float)
     t['call_ll'] = np.asarray(lls, dtype=float)
+    t['call_scale'] = np.asarray(scales, dtype=float)      # multiplier x livetime x efficiency (likelihood.py:366-393)
+    t['allow_negative'] = np.array([1 if a else 0 for a in lf.source_allowed_negative])
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **t)
     print('%-28s d=%d S=%d bins=%s calls=%d  ll[0]=%r' % (
         name, t['d'], t['S'], [int(b) for b in t['bins']], len(calls), float(lls[0])))

@@ -30,6 +30,7 @@ def load_case(name):
     case = dict(name=name, d=d, S=int(f['S']), bins=tuple(int(b) for b in f['bins']),
                 model=model, counts=f['counts'], bb_source=int(f['bb_source']),
                 livetime_base=float(f['livetime_base']),
+                allow_negative=[bool(a) for a in f['allow_negative']] if 'allow_negative' in f.files else None,
                 kind=int(f['kind']) if 'kind' in f.files else 0,
                 outlier=float(f['outlier']) if 'outlier' in f.files else 0.0,
                 call_z=f['call_z'], call_mult=f['call_mult'], call_livetime=f['call_livetime'],
@@ -39,6 +40,8 @@ def load_case(name):
 
 def rate_scale_of(case, j):
     """rate multiplier x livetime scaling of call j (likelihood.py:366-382)."""
+    if 'call_scale' in case['raw'].files:
+        return np.array(case['raw']['call_scale'][j], dtype=float)
     rs = np.array(case['call_mult'][j], dtype=float)
     lt = case['call_livetime'][j]
     if not np.isnan(lt):

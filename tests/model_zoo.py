@@ -300,6 +300,51 @@ def bb_d2(ns):
     return lf, calls, (4, 12)
 
 
+def neg_allowed(ns):
+    """A source that may have a negative rate (config 'allow_negative', likelihood.py:82-83,397-415): finite
+    while every bin's total stays positive, nan once a bin goes negative, -inf when the summed rate does."""
+    rng = np.random.default_rng(41)
+    space = [['x', np.linspace(-3, 3, 9)]]
+    conf = dict(sources=[dict(name='bkg', events_per_day=200., data=sample(rng, 3000, space), strength=0.3),
+                         dict(name='sig', events_per_day=20., data=sample(rng, 1500, space), strength=-1.0,
+                              allow_negative=True)],
+                default_source_class=morphed_source_class(ns), analysis_space=space,
+                force_recalculation=True, never_save_to_cache=True, shift=0., stretch=0., tilt=0.)
+    lf = ns.BinnedLogLikelihood(conf)
+    lf.add_rate_parameter('bkg')
+    lf.add_rate_parameter('sig')
+    lf.add_shape_parameter('shift', (-1., 0., 1.))
+    lf.prepare()
+    lf.set_data(sample(rng, 230, space))
+    calls = [{}, dict(sig_rate_multiplier=-0.5), dict(sig_rate_multiplier=-2., shift=0.4),
+             dict(sig_rate_multiplier=-9.), dict(sig_rate_multiplier=-30.), dict(bkg_rate_multiplier=-0.1),
+             dict(sig_rate_multiplier=-1., bkg_rate_multiplier=0.), dict(shift=-0.7, sig_rate_multiplier=3.)]
+    return lf, calls, (1,)
+
+
+def efficiency_param(ns):
+    """Sources scaled by an efficiency that is itself a shape parameter (likelihood.py:84-87,385-393)."""
+    rng = np.random.default_rng(42)
+    space = [['x', np.linspace(-3, 3, 7)], ['y', np.linspace(0, 5, 4)]]
+    conf = dict(sources=[dict(name='a', events_per_day=50., data=sample(rng, 2000, space), strength=1.0),
+                         dict(name='b', events_per_day=30., data=sample(rng, 2000, space), strength=-0.5,
+                              apply_efficiency=True, efficiency_name='eff'),
+                         dict(name='c', events_per_day=10., data=sample(rng, 2000, space), strength=0.2,
+                              apply_efficiency=True, efficiency_name='eff2')],
+                default_source_class=morphed_source_class(ns), analysis_space=space,
+                force_recalculation=True, never_save_to_cache=True, shift=0., stretch=0., tilt=0., eff=1.0)
+    lf = ns.BinnedLogLikelihood(conf)
+    for n in 'abc':
+        lf.add_rate_parameter(n)
+    lf.add_shape_parameter('shift', (-1., 0., 1.))
+    lf.add_shape_parameter('eff', (0.5, 1.0, 1.5))
+    lf.prepare()
+    lf.set_data(sample(rng, 120, space))
+    calls = [{}, dict(eff=0.5), dict(eff=1.3, shift=0.2), dict(eff=0.8, b_rate_multiplier=2., c_rate_multiplier=0.5),
+             dict(eff=1.5, shift=-1., a_rate_multiplier=0.)]
+    return lf, calls, (2,)
+
+
 def fit_c1_like(ns):
     rng = np.random.default_rng(21)
     space = [['x', np.linspace(-4, 4, 41)]]
@@ -367,4 +412,4 @@ UNBINNED_CASES = OrderedDict((f.__name__, f) for f in (unb_ref_value, unb_shape_
 CASES = OrderedDict((f.__name__, f) for f in (
     ref_single_bin, ref_zero_bin, ref_multi_bin_single_dim, ref_multi_bin, ref_bb_single_bin,
     ref_bb_multi_bin, ref_bb_second_source, bb_two_shape, c1_like, d2_nonuniform, d3_small,
-    d0_multi_source, edge_mu_zero_hit, edge_mu_zero_ok, edge_empty_data, bb_d2))
+    d0_multi_source, edge_mu_zero_hit, edge_mu_zero_ok, edge_empty_data, bb_d2, neg_allowed, efficiency_param))

@@ -24,6 +24,8 @@ def upload_case(ctx, c):
     bb = c['bb_source']
     ctx.upload_model(c['model']['anchor_z'], c['model']['ps'], c['model']['mus'],
                      n_model=c['model']['n_model'] if bb >= 0 else None, bb_source=bb)
+    if c.get('allow_negative') is not None:
+        ctx.set_allow_negative([1 if a else 0 for a in c['allow_negative']])
     ctx.upload_counts(c['counts'])
 
 
@@ -40,6 +42,7 @@ def test_eval_matches_reference_goldens(ctx, name, sparse):
     if sparse:
         assert ctx.get_param('csr_ready') == 1
         assert ctx.get_param('compact_ready') == (1 if c['bb_source'] < 0 else 0)
+    uses_sparse = bool(sparse) and c['bb_source'] < 0 and not any(c['allow_negative'] or [])
     n = len(c['call_ll'])
     rs = np.array([rate_scale_of(c, j) for j in range(n)])
     # one by one (the lf(**kw) form) ...

@@ -93,3 +93,19 @@ def test_bestfit_with_gradient_reaches_the_reference_optimum():
     assert ll >= float(f['fit_all_ll']) - 1e-6 * abs(ll)           # at least as good as the reference's optimum
     assert abs(ll - float(f['fit_all_ll'])) < 1e-4 * abs(ll)
     assert 0 < calls['n'] < 200                                      # vs ~500 objective calls by differencing
+
+
+def test_gradient_with_efficiency_parameter():
+    """A shape parameter that also scales the rates of some sources (efficiency) enters the gradient twice."""
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf, _, _ = model_zoo.efficiency_param(ns)
+    kw = dict(eff=1.2, shift=0.3, a_rate_multiplier=0.9, b_rate_multiplier=1.4, c_rate_multiplier=0.6)
+    ll, grads = lf.value_and_gradient(**kw)
+    assert abs(ll - lf(**kw)) <= 1e-12 * abs(ll)
+    for name, g in grads.items():
+        h = 1e-6
+        up, dn = dict(kw), dict(kw)
+        up[name] += h
+        dn[name] -= h
+        fd = (lf(**up) - lf(**dn)) / (2 * h)
+        assert abs(g - fd) <= 2e-5 * max(1.0, abs(fd)), (name, g, fd)

@@ -103,8 +103,7 @@ def test_uploaded_tensors_equal_reference_tensors(ns, name):
             continue
         assert prior == 0
         np.testing.assert_array_equal(zs, z_ref)
-        want = c['call_mult'][j] * (1.0 if lt is None else lt / c['livetime_base'])
-        np.testing.assert_array_equal(scale, want)
+        np.testing.assert_array_equal(scale, c['raw']['call_scale'][j])
     assert shape_names == list(lf.shape_parameters)
 
 
@@ -220,7 +219,7 @@ def test_unbinned_uploads_equal_reference_tensors(ns, name):
         if prior is None:
             continue
         np.testing.assert_array_equal(zs, c['call_z'][j])
-        np.testing.assert_array_equal(scale, c['call_mult'][j] * (1.0 if lt is None else lt / c['livetime_base']))
+        np.testing.assert_array_equal(scale, c['raw']['call_scale'][j])
 
 
 def test_likelihood_sum_host_logic():

@@ -19,7 +19,8 @@ def test_oracle_matches_reference_goldens(name):
         bb = c['bb_source'] if c['bb_source'] >= 0 else None
         asserts = ('call_asserts_%d' % j) in c['raw'].files
         try:
-            ll = orc.loglikelihood(c['model'], c['counts'], c['call_z'][j], rate_scale_of(c, j), bb_source=bb)
+            ll = orc.loglikelihood(c['model'], c['counts'], c['call_z'][j], rate_scale_of(c, j), bb_source=bb,
+                                   allow_negative=c['allow_negative'])
         except AssertionError:
             assert asserts, "oracle asserted where the reference did not (call %d)" % j
             continue
