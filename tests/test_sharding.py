@@ -95,7 +95,7 @@ def test_two_gloo_ranks_equal_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in procs]
+    got = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -150,7 +150,7 @@ def test_bin_sharding_allreduce_two_gloo_ranks():
     procs = [ctx.Process(target=_bins_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in procs]
+    got = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

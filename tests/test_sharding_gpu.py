@@ -50,7 +50,7 @@ def test_two_ranks_on_gpu_equal_single_process():
     procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in procs]
+    got = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
