@@ -83,7 +83,9 @@ def corner_terms(anchor_z_arrays, z):
 
 
 def interpolate(anchor_z_arrays, values, z):
-    """Multilinear interpolation of the anchor tensor `values[A_0..A_{d-1}, *extra]` at z[d]."""
+    """Multilinear interpolation of the anchor tensor `values[A_0..A_{d-1}, *extra]` at z[d]: what the closure
+    returned by GridInterpolator.make_interpolator computes (blueice/pdf_morphers.py:67-70, i.e. scipy
+    RegularGridInterpolator.__call__ with method='linear', bounds_error=True; `_rgi.py:_evaluate_linear`)."""
     values = np.asarray(values)
     z = np.asarray(z, dtype=float)
     d = len(anchor_z_arrays)
@@ -114,7 +116,8 @@ def poisson_logpmf(k, mu):
 
 
 def compute_likelihood(mus, pmfs, counts):
-    """a5: sum_b poisson.logpmf(n_b | sum_s mus_s pmfs_{s,b})."""
+    """a5: BinnedLogLikelihood._compute_likelihood (blueice/likelihood.py:662-675):
+    sum_b poisson.logpmf(n_b | sum_s mus_s pmfs_{s,b}), rows scaled in place then np.sum(axis=0)."""
     expected = np.array(pmfs, dtype=float, copy=True)
     for mu, row in zip(mus, expected):
         row *= mu
@@ -128,10 +131,12 @@ def _bb_disc(a, p, U, d):
 
 
 def beeston_barlow_root1(a, p, U, d):
+    """blueice/likelihood.py:693-700 (the root the reference asserts to be <= 0)."""
     return ((-U*p - U + a*p + d*p - np.sqrt(_bb_disc(a, p, U, d))) / (2*p*(p + 1)))
 
 
 def beeston_barlow_root2(a, p, U, d):
+    """blueice/likelihood.py:703-708 (the physical root)."""
     return ((-U*p - U + a*p + d*p + np.sqrt(_bb_disc(a, p, U, d))) / (2*p*(p + 1)))
 
 
@@ -171,7 +176,8 @@ def in_bounds(anchor_z_arrays, z):
 
 
 def rates_at(model, z, rate_scale):
-    """a4: r_s = mus_interpolator(z)_s * rate_scale_s (rate multiplier * livetime * efficiency)."""
+    """a4: r_s = mus_interpolator(z)_s * rate_scale_s, rate_scale = rate multiplier * livetime scaling *
+    efficiency (blueice/likelihood.py:355,366-393)."""
     mus = interpolate(model['anchor_z'], model['mus'], z)
     return mus * np.asarray(rate_scale, dtype=float)
 
