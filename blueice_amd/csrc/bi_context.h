@@ -35,6 +35,7 @@ struct bi_plan {
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
     int64_t bytes = 0;         // algorithmic HBM bytes per run
@@ -93,6 +94,12 @@ struct bi_ctx {
     DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
+
+    // device mirrors of the small tables the planning kernels read (bi_planning_device.h)
+    DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz;
+    int64_t plan_tables_epoch = -1;
+    bool plan_tables_sparse = false;
+    int64_t device_plan_min = 16384;             // batches at least this large are planned on the device
 
     // scratch
     DevBuf scratch, scratch2, logmu;

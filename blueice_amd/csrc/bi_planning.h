@@ -27,6 +27,9 @@ struct PlanItem {
 
 constexpr int kClassG[5] = {1, 2, 4, 8, 16};
 
+int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
+                       bi_plan** out);
+
 int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bi_plan** out) {
     int rc = check_ready(c, true);
     if (rc) return rc;
@@ -49,6 +52,15 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     if (!sparse && !c->dense_counts)
         return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
                                      "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
+
+    // large plain batches are planned on the device (bi_planning_device.h) unless groups would be tiny
+    // (every device-planned item has 16 slots): expected points per (cell, dataset) group >= 8
+    if (!bb && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
+        int64_t cells = 1;
+        for (int ax : c->eff_axes) cells *= c->n_anchor[(size_t)ax] - 1;
+        const int64_t groups = cells * (dataset ? c->T : 1);
+        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out);
+    }
 
     // ---- phase 1: per point geometry, rates, early exits (parallel) ---------------------------------
     std::vector<int32_t> st((size_t)P, 0);

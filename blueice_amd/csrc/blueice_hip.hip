@@ -44,6 +44,7 @@
 #include "bi_sparse.h"
 #include "bi_single.h"
 #include "bi_planning.h"
+#include "bi_planning_device.h"
 
 namespace {
 
@@ -111,6 +112,8 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
+    dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
+    dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz);
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
     c->cache.clear();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -152,6 +155,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "single_kernel")) { c->single_kernel = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
     if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
         c->nt_loads = v;
@@ -170,6 +174,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "single_kernel")) return c->single_kernel;
     if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
     if (!strcmp(name, "xcd_affine")) return c->xcd_affine;
+    if (!strcmp(name, "device_plan_min")) return c->device_plan_min;
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
@@ -478,7 +483,10 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
                                (int32_t*)plan->status.p);
         }
     }
-    if (plan->n_bad > 0)
+    if (plan->n_bad > 0 && plan->device_planned)
+        hipLaunchKernelGGL(k_fill_bad_by_status, dim3((unsigned)((plan->P + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                           (const int32_t*)plan->status.p, plan->P, out);
+    else if (plan->n_bad > 0)
         hipLaunchKernelGGL(k_fill_const, dim3((unsigned)((plan->n_bad + 255) / 256)), dim3(256), 0, c->stream, out,
                            (const int64_t*)plan->bad_idx.p, plan->n_bad, -std::numeric_limits<double>::infinity());
     HIP_TRY(c, hipGetLastError());

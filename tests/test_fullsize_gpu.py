@@ -144,3 +144,53 @@ def test_c3_toy_batch(c2):
     want = orc.loglikelihood(m.cell_model(z), toys[5], z, r)
     assert abs(res[0][5] - want) <= 1e-10 * abs(want)
     ctx.set_param('sparse', 1)
+
+
+def test_device_planning_equals_host_planning():
+    """Large batches are planned on the device (geometry, radix sort by (cell, dataset), item chopping,
+    descriptor fill): same numbers as the host planner, including rejected points, several datasets, both
+    data forms."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    toys = np.stack([m.counts(dense=False, dataset=t, scale=0.02) for t in range(3)])
+    rng = np.random.default_rng(3)
+    P = 40000
+    z, r = m.random_points(P, seed=12)
+    z[::97, 0] = 5.0                      # out of the box
+    z[5::131, 1] = np.nan
+    r[7::89, 2] = -1.0                    # unphysical
+    ds = rng.integers(0, 3, P)
+    ds[11::203] = 7                       # bad dataset
+    for sparse in (0, 2):
+        ctx.set_param('sparse', sparse)
+        ctx.upload_counts(toys)
+        ctx.set_param('device_plan_min', 0)                 # host planner
+        host, hst = ctx.eval(z, r, dataset=ds)
+        ctx.set_param('device_plan_min', 1000)              # device planner
+        dev, dst = ctx.eval(z, r, dataset=ds)
+        np.testing.assert_array_equal(dst, hst)
+        assert np.array_equal(np.isneginf(dev), np.isneginf(host)) and np.isneginf(dev).sum() > 800
+        fin = np.isfinite(host)
+        np.testing.assert_allclose(dev[fin], host[fin], rtol=1e-13)
+        plan = ctx.plan(z, r, dataset=ds)
+        plan.run()
+        again, _ = plan.read()
+        np.testing.assert_array_equal(again, dev)
+        plan.close()
+    # no shape parameters at all (one "cell")
+    solo = DeviceContext(0)
+    solo.begin_model([], m.S, m.B)
+    solo.set_anchor(0, m.anchor_ps(0), m.anchor_mus(0))
+    solo.end_model()
+    solo.upload_counts(m.counts(dense=True))
+    rr = rng.uniform(0.5, 1.5, size=(20000, m.S))
+    solo.set_param('device_plan_min', 0)
+    a, _ = solo.eval(None, rr)
+    solo.set_param('device_plan_min', 1000)
+    b, _ = solo.eval(None, rr)
+    np.testing.assert_allclose(b, a, rtol=1e-13)
+    solo.close()
+    ctx.close()
