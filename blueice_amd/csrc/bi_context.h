@@ -35,6 +35,9 @@ struct bi_plan {
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    bool use_scan = false;        // evaluated by the matrix-core scan kernel (groups of items per cell)
+    int64_t n_groups = 0;
+    DevBuf grp_first, grp_items;
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
@@ -99,6 +102,8 @@ struct bi_ctx {
     DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz;
     int64_t plan_tables_epoch = -1;
     bool plan_tables_sparse = false;
+    int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
+    int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
     int64_t device_plan_min = 16384;             // batches at least this large are planned on the device
 
     // scratch
@@ -215,7 +220,7 @@ void free_plan_buffers(bi_plan* p) {
         dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
     }
-    dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status);
+    dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
 }
 
 }  // namespace

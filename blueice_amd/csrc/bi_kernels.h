@@ -886,3 +886,146 @@ __global__ void k_dataset_finish(const double* __restrict__ partial, int nbx, co
 }
 
 }  // namespace
+
+namespace {
+
+// ---- the scan kernel: many points per grid cell, fp64 matrix cores ---------------------------------------
+// For a batch whose points pile up in few grid cells (likelihood scans), mu[point][bin] = sum_k coef[point][k] *
+// row[k][bin] is a [points x streams] x [streams x bins] product.  One wave owns a 64-bin strip of the cell's
+// 2^d*S template rows, holds it in registers in v_mfma_f64_16x16x4 B-operand layout (k = lane >> 4,
+// bin = lane & 15; loaded once, every 128-byte cache line fully used) and loops over ALL 16-point work items of
+// the cell: per item 8 coalesced A-operand loads (coef[k][point], point = lane & 15) and, for the 4 column blocks
+// of the strip, K/4 MFMAs each.  The Poisson epilogue runs on the VALU while the matrix pipe works on the next
+// block; a 16-lane row reduction leaves the 16 per-point sums in 4 lanes, which add them (no-return fp64
+// atomics) into a partial slot that only this wave ever touches, so the result is deterministic.
+// Rate: 78.6 TFLOP/s fp64 matrix peak / (2 * 2^d*S * B flop per evaluation) = 1.2 M evaluations/s at C2.
+// Plain binned likelihood, up to 32 streams (K <= 32); everything else takes k_morph_reduce.
+typedef double bi_double4 __attribute__((ext_vector_type(4)));
+
+struct ScanArgs {
+    const double* ps;
+    const double* counts;
+    const int64_t* rowoff;      // [items][NS]   (rows of a group = rows of its first item)
+    const double* coef;         // [items][NS][16]
+    const int64_t* item_cnt;    // [items]
+    const int32_t* item_tiles;  // [items] 512-bin tiles of the item's rows
+    const int64_t* grp_first;   // [groups] first item of the group
+    const int32_t* grp_items;   // [groups] items in the group
+    double* partial;            // [items][nslots][16], zero on entry
+    int NS;
+    int nslots;                 // waves per group = gridDim.x * 4
+};
+
+// the rare branch of the scan epilogue, kept out of line so that it does not inflate the register budget
+__device__ __noinline__ double bin_log_call(double x) { return bin_log(x); }
+
+__global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
+    constexpr int KG = 8, CB = 4;                   // K groups of 4 streams, column blocks of 16 bins
+    const int grp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    const int64_t item0 = a.grp_first[grp];
+    const int n_items = a.grp_items[grp];
+    const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
+    const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
+    const int n_strips = a.item_tiles[item0] * (kTile / 64);
+    const int kq = lane >> 4, col = lane & 15;
+
+    // row offsets of this lane's K rows (clamped: streams beyond NS get a zero coefficient)
+    int64_t row[KG];
+    int aoff[KG];                                   // element offset of this lane's A operand inside an item
+    double amask[KG];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        const int k = kg * 4 + kq;
+        row[kg] = rowoff[min(k, a.NS - 1)];
+        aoff[kg] = min(k, a.NS - 1) * 16 + col;
+        amask[kg] = k < a.NS ? 1.0 : 0.0;
+    }
+
+    for (int strip = slot; strip < n_strips; strip += a.nslots) {
+        const int64_t bin0 = (int64_t)strip * 64 + col;
+        double b[KG][CB], n[CB];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row[kg] + bin0 + cb * 16];
+        // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
+        // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
+        int kind[CB];
+        bool special[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const double v = cnt[bin0 + cb * 16];
+            n[cb] = v;
+            kind[cb] = (v != v) ? 3 : ((v < 0.0 || v != floor(v)) ? 2 : (v > 0.0 ? 1 : 0));
+            special[cb] = __ballot(kind[cb] != 0) != 0ull;      // wave-uniform: does any bin of this block need more
+        }
+
+        // A operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
+        double av[KG];
+        {
+            const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) av[kg] = coef[aoff[kg]] * amask[kg];
+        }
+        for (int it = 0; it < n_items; ++it) {
+            const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
+            double an[KG];
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            double mn[4] = {0.0, 0.0, 0.0, 0.0};     // running minimum of mu: a negative expectation makes the result nan
+            bi_double4 acc[CB];
+            // software pipeline: the matrix pipe gets block cb + 1 before the VALU looks at block cb, and the next
+            // item's A operands are requested right behind the first chain, so they arrive under the other three
+#define BI_CHAIN(cb)                                                                                               \
+    do {                                                                                                           \
+        acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
+        _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
+            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], b[kg][cb], acc[cb], 0, 0, 0);                   \
+    } while (0)
+#define BI_EPILOGUE(cb)                                                                                            \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { /* point (lane >> 4) + 4 r, bin cb * 16 + col */           \
+            s[r] -= acc[cb][r];                                                                                    \
+            mn[r] = fmin(mn[r], acc[cb][r]);                                                                       \
+        }                                                                                                          \
+        if (special[cb]) {                                                                                         \
+            if (kind[cb] == 1) {                                                                                   \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log_call(acc[cb][r]);            \
+            } else if (kind[cb] != 0) {                                                                            \
+                const double v = kind[cb] == 2 ? -__builtin_inf() : __builtin_nan("");                             \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += v;                                           \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+            BI_CHAIN(0);
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) an[kg] = coef_next[aoff[kg]];
+            BI_CHAIN(1);
+            BI_EPILOGUE(0);
+            BI_CHAIN(2);
+            BI_EPILOGUE(1);
+            BI_CHAIN(3);
+            BI_EPILOGUE(2);
+            BI_EPILOGUE(3);
+#undef BI_CHAIN
+#undef BI_EPILOGUE
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (mn[r] < 0.0) s[r] = __builtin_nan("");
+                // sum over the 16 bins held by the 16 lanes of a row
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off, 64);
+            }
+            if (col == 0) {
+                double* __restrict__ dst = a.partial + ((item0 + it) * a.nslots + slot) * 16 + kq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + 4 * r, s[r]);
+            }
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg] * amask[kg];
+        }
+    }
+}
+
+}  // namespace

@@ -156,6 +156,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
     if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
+    if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
         c->nt_loads = v;
@@ -175,6 +176,8 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
     if (!strcmp(name, "xcd_affine")) return c->xcd_affine;
     if (!strcmp(name, "device_plan_min")) return c->device_plan_min;
+    if (!strcmp(name, "scan_mfma")) return c->scan_mfma;
+    if (!strcmp(name, "n_scan_launches")) return c->n_scan_launches;
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
@@ -461,7 +464,29 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     a.n1 = bb ? nc : 0; a.n2 = bb ? nc : 0;
     a.n_tiles = n_tiles_of(c);
     const int NS = a.n0 + a.n1 + a.n2;
+    if (plan->use_scan) {
+        bi_plan::Class& k = plan->classes[0];
+        ScanArgs sa{};
+        sa.ps = a.ps; sa.counts = a.counts;
+        sa.rowoff = (const int64_t*)k.rowoff.p; sa.coef = (const double*)k.coef.p;
+        sa.item_cnt = (const int64_t*)k.item_cnt.p; sa.item_tiles = (const int32_t*)k.item_tiles.p;
+        sa.grp_first = (const int64_t*)plan->grp_first.p; sa.grp_items = (const int32_t*)plan->grp_items.p;
+        sa.partial = (double*)k.partial.p; sa.NS = NS; sa.nslots = k.nbx;
+        HIP_TRY(c, hipMemsetAsync(k.partial.p, 0, (size_t)k.n_items * k.nbx * k.G * sizeof(double), c->stream));
+        {
+            EventScope ev(c);
+            ++c->n_scan_launches;
+            hipLaunchKernelGGL(k_scan_mfma, dim3((unsigned)(k.nbx / 4), (unsigned)plan->n_groups), dim3(kThreads), 0, c->stream, sa);
+        }
+        const int64_t n_slots = k.n_items * k.G;
+        const int lanes = k.nbx > 64 ? kThreads : 64;
+        const int per_block = kThreads / lanes;
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
+                           (const double*)k.partial.p, (const unsigned*)k.pflags.p, k.nbx, k.G, lanes, n_slots,
+                           (const int64_t*)k.perm.p, (const double*)k.slot_lg.p, out, (int32_t*)plan->status.p);
+    }
     for (auto& k : plan->classes) {
+        if (plan->use_scan) break;
         for (int64_t i0 = 0; i0 < k.n_items; i0 += 65535) {
             const int64_t ni = std::min<int64_t>(65535, k.n_items - i0);
             LaunchArgs b = a;

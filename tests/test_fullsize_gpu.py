@@ -194,3 +194,47 @@ def test_device_planning_equals_host_planning():
     np.testing.assert_allclose(b, a, rtol=1e-13)
     solo.close()
     ctx.close()
+
+
+def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
+    """Scans with many points per grid cell run on the fp64 matrix cores (k_scan_mfma): same numbers as the
+    vector kernel (k_morph_reduce) and as the oracle, including -inf / nan bins."""
+    from oracle import blueice_oracle as orc
+    m, ctx = c2
+    counts = m.counts()
+    counts[12345] = 2.5           # non-integer count -> -inf for every point of that dataset
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(counts)
+    rng = np.random.default_rng(8)
+    n1 = 20000
+    z = np.stack([rng.uniform(-0.9, -0.1, n1), rng.uniform(0.1, 0.9, n1), rng.uniform(1.1, 1.9, n1)], 1)   # one cell
+    r = rng.uniform(0.5, 1.5, (n1, m.S))
+    z = np.concatenate([z, m.random_points(30000, seed=2)[0]])
+    r = np.concatenate([r, m.random_points(30000, seed=2)[1]])
+    ctx.set_param('scan_mfma', 1)
+    before = ctx.get_param('n_scan_launches')
+    vec, _ = ctx.eval(z, r)
+    assert ctx.get_param('n_scan_launches') == before + 1 and np.all(np.isneginf(vec))
+    ctx.set_param('scan_mfma', 0)
+    counts[12345] = 3.0
+    ctx.upload_counts(counts)
+    vec, _ = ctx.eval(z, r)
+    ctx.set_param('scan_mfma', 1)
+    before = ctx.get_param('n_scan_launches')
+    plan = ctx.plan(z, r)
+    plan.run()
+    mat, st = plan.read()
+    plan.close()
+    assert ctx.get_param('n_scan_launches') == before + 1          # the matrix-core kernel really ran
+    assert not st.any()
+    np.testing.assert_allclose(mat, vec, rtol=1e-13)
+    for i in (0, 700, 19999):
+        want = orc.loglikelihood(m.cell_model(z[i]), counts, z[i], r[i])
+        assert abs(mat[i] - want) <= 1e-10 * abs(want)
+    counts[777] = np.nan
+    ctx.upload_counts(counts)
+    before = ctx.get_param('n_scan_launches')
+    bad, _ = ctx.eval(z[:n1], r[:n1])
+    assert ctx.get_param('n_scan_launches') == before + 1
+    assert np.all(np.isnan(bad))
+    ctx.set_param('sparse', 1)
