@@ -37,6 +37,7 @@ struct bi_plan {
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
     bool use_scan = false;        // evaluated by the matrix-core scan kernel (groups of items per cell)
     int64_t n_groups = 0;
+    int scan_cb = 4;              // its strip width in 16-bin blocks
     DevBuf grp_first, grp_items;
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
@@ -103,8 +104,11 @@ struct bi_ctx {
     int64_t plan_tables_epoch = -1;
     bool plan_tables_sparse = false;
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
+    int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
+    int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
+    int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
-    int64_t device_plan_min = 16384;             // batches at least this large are planned on the device
+    int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
     // scratch
     DevBuf scratch, scratch2, logmu;

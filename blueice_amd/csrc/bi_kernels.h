@@ -20,30 +20,66 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
     return v;
 }
 
-// Natural logarithm for the per-bin terms: argument reduction x = m * 2^k with m in [sqrt(1/2), sqrt(2)), then
-// log(m) = 2 s + s * R(s^2) with s = f / (2 + f), f = m - 1 and a degree-7 minimax polynomial (the classic
-// Remez fit published with the fdlibm algorithm; error < 1 ulp).  About 35 fp64 instructions against ~75 for
-// the double-double library version -- the log is what bounds passes with several points per cell.
-// Zero, denormal, negative, infinite and nan arguments take the library path (wave-divergent but rare).
+// Natural logarithm for the per-bin terms, table-driven (the scheme of Tang's table-driven log as used by modern
+// libms, laid out for this hardware): x = 2^k z with z in [0.6875, 1.375); the 7 leading mantissa bits pick a
+// subinterval with centre c from a 128-entry {1/c, log c} table held in LDS (bi_log_table.h); then
+//     log x = k ln2 + log c + log1p(r),   r = z / c - 1   (one fma, |r| <= 2^-7)
+// with log1p as its Taylor polynomial through r^8 and the leading terms summed as a hi/lo pair.  ~27 full-rate
+// instructions and one 16-byte LDS read per call, no division and no transcendental-rate instruction; worst
+// error measured 0.74 ulp (tools/micro/log_variants.hip), 1.55x the throughput of the fdlibm-style version with
+// its IEEE division.  The log is what bounds passes with several points per cell.
+// Every kernel that calls bin_log fills the LDS table first: log_table_load(), or the overlapped form in morph_tiles.
+__shared__ double2 s_log_table[128];
+
+__device__ __forceinline__ void log_table_load() {
+    if (threadIdx.x < 128) s_log_table[threadIdx.x] = kLogTable[threadIdx.x];
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
+
+// the core: x must be a positive normal number (anything else gives a meaningless but harmless value);
+// k_adjust is added to the binary exponent
+__device__ __forceinline__ double log_core(double x, int k_adjust) {
+    const unsigned long long ix = __double_as_longlong(x);
+    const int hi = (int)(ix >> 32);
+    const int t = hi - 0x3FE60000;                  // bits(x) - bits(0.6875), high word
+    const int k = (t >> 20) + k_adjust;
+    const double z = __longlong_as_double(((unsigned long long)(unsigned)(hi - (t & 0xFFF00000)) << 32) | (ix & 0xFFFFFFFFull));
+    const double2 e = s_log_table[(t >> 13) & 127];
+    const double kd = (double)k;
+    const double r = fma(z, e.x, -1.0);
+    const double w = fma(kd, kLn2Hi, e.y);
+    const double h = w + r;
+    double lo = (w - h) + r;
+    lo += fma(kd, kLn2Hi, -w) + e.y;               // what rounding w lost
+    lo = fma(kd, kLn2Lo, lo);
+    double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
+    p = fma(r, p, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    return fma(r * r, p, lo) + h;
+}
+
+// for arguments known to be positive normal numbers
+__device__ __forceinline__ double bin_log_fast(double x) { return log_core(x, 0); }
+
+// for any argument, still without a branch: denormals are scaled by 2^54 first; log 0 = -inf, log of a negative
+// number or nan = nan, log inf = inf (numpy.log's values)
 __device__ __forceinline__ double bin_log(double x) {
-    if (!(x >= 2.2250738585072014e-308 && x < __builtin_inf())) return log(x);
-    double m = __builtin_amdgcn_frexp_mant(x);       // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
-    if (m < 0.70710678118654752440) { m += m; k -= 1; }
-    const double f = m - 1.0;
-    const double s = f / (2.0 + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-                              6.666666666666735130e-01);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+    const bool tiny = x < 2.2250738585072014e-308;
+    double y = log_core(tiny ? x * 18014398509481984.0 : x, tiny ? -54 : 0);
+    if (x == 0.0) y = -__builtin_inf();
+    if (!(x >= 0.0)) y = __builtin_nan("");
+    if (x == __builtin_inf()) y = x;
+    return y;
 }
 
 // self-test hook: out[i] = bin_log(x[i])
 __global__ void k_selftest_log(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    log_table_load();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bin_log(x[i]);
 }
@@ -60,6 +96,27 @@ __device__ __forceinline__ double poisson_term(double n, double mu) {
     } else {
         t = -mu;
     }
+    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
+    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
+    return t;
+}
+
+// The same term without a branch, for unrolled loops (the compiler can then batch the table reads of many terms).
+// Only valid where n > 0 implies that mu is a positive normal number -- the caller checks that for the whole wave
+// (needs_checked_term) and takes poisson_term otherwise.  Same operations, same bits.
+__device__ __forceinline__ bool needs_checked_term(double n, double mu) { return n > 0.0 && !pos_normal(mu); }
+
+__device__ __forceinline__ double poisson_term_fast(double n, double mu) {
+    const double lg = bin_log_fast(mu);            // not used where n <= 0
+    double t = (n > 0.0) ? n * lg - mu : -mu;
+    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
+    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
+    return t;
+}
+
+// ... for a bin column in which no lane has n > 0
+__device__ __forceinline__ double poisson_term_nolog(double n, double mu) {
+    double t = -mu;
     if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
     else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
     return t;
@@ -119,7 +176,12 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                                             const double* __restrict__ coef, const double* __restrict__ aux_base,
                                             const double* __restrict__ cnt, int n_tiles, int tile0, int tile_step,
                                             double (&sum)[G], unsigned (&flg)[G]) {
-    for (int tile = tile0; tile < n_tiles; tile += tile_step) {
+    // the log table travels global -> registers -> LDS; the request goes out first and lands under the first tile's
+    // row loads, so a block that lives for only a few tiles does not wait for it separately
+    double2 tab = {0.0, 0.0};
+    if (threadIdx.x < 128) tab = kLogTable[threadIdx.x];
+    bool tab_pending = true;
+    for (int tile = tile0; tile < n_tiles; tile += tile_step) {     // (the trip count is the same for a whole block)
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
         double acc[G][2];
 #pragma unroll
@@ -137,19 +199,31 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
         }
         double2 nv;
         if constexpr (MODE == 2) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
+        if (tab_pending) {
+            if (threadIdx.x < 128) s_log_table[threadIdx.x] = tab;
+            __syncthreads();
+            tab_pending = false;
+        }
 
         if constexpr (MODE == 2) {
             // extended unbinned likelihood (blueice/likelihood.py:678-690): the "bins" are the events,
             // the term is log(sum_s mu_s p_s(x_e)) with the outlier clamp; -sum_s mu_s is added by the host
+            bool checked = false;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (bin0 + j < a.B) {
-                        double lam = acc[g][j];
-                        if (a.outlier != 0.0 && !(lam > 0.0)) lam = a.outlier;
-                        sum[g] += bin_log(lam);
-                    }
+                    if (a.outlier != 0.0 && !(acc[g][j] > 0.0)) acc[g][j] = a.outlier;
+                    checked |= bin0 + j < a.B && !pos_normal(acc[g][j]);
+                }
+            }
+            const bool fast = __ballot(checked) == 0ull;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double lg = fast ? bin_log_fast(acc[g][j]) : bin_log(acc[g][j]);   // (wave-uniform choice)
+                    if (bin0 + j < a.B) sum[g] += lg;
                 }
             }
         } else if constexpr (MODE == 1) {
@@ -159,9 +233,24 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
 #pragma unroll
             for (int g = 1; g < G; ++g) sum[g] += f0 * acc[g][0] + f1 * acc[g][1];
         } else if constexpr (!BB) {
+            // per bin column of the wave: no lane has counts -> no logarithm at all (the usual case with sparse data);
+            // every lane that needs one has a positive normal mu -> the branch-free form; else the checked form
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                sum[g] += poisson_term(nv.x, acc[g][0]) + poisson_term(nv.y, acc[g][1]);
+            for (int j = 0; j < 2; ++j) {
+                const double n = j ? nv.y : nv.x;
+                bool checked = false;
+#pragma unroll
+                for (int g = 0; g < G; ++g) checked |= needs_checked_term(n, acc[g][j]);
+                if (__ballot(n > 0.0) == 0ull) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sum[g] += poisson_term_nolog(n, acc[g][j]);
+                } else if (__ballot(checked) == 0ull) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sum[g] += poisson_term_fast(n, acc[g][j]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sum[g] += poisson_term(n, acc[g][j]);
+                }
             }
         } else {
             double pi[G][2], ai[G][2];
@@ -803,6 +892,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* 
     const double* __restrict__ coef = a.coef;
     double sum = 0.0;
     unsigned bad = 0u;
+    log_table_load();
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
         double m0 = 0.0, m1 = 0.0;
@@ -818,8 +908,8 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* 
             l.x = m0;
             l.y = m1;
         } else {
-            l.x = (m0 >= 0.0) ? log(m0) : __builtin_nan("");
-            l.y = (m1 >= 0.0) ? log(m1) : __builtin_nan("");
+            l.x = (m0 >= 0.0) ? bin_log(m0) : __builtin_nan("");
+            l.y = (m1 >= 0.0) ? bin_log(m1) : __builtin_nan("");
         }
         if (!(m0 >= 0.0) || !(m1 >= 0.0)) bad = 1u;
         *reinterpret_cast<double2*>(logmu + bin0) = l;
@@ -916,11 +1006,29 @@ struct ScanArgs {
     int nslots;                 // waves per group = gridDim.x * 4
 };
 
-// the rare branch of the scan epilogue, kept out of line so that it does not inflate the register budget
-__device__ __noinline__ double bin_log_call(double x) { return bin_log(x); }
+// sum of a double over the 16 lanes of a DPP row (lanes 16r .. 16r+15): four rotate-and-add steps on the
+// cross-lane data path, no LDS round trip; every lane of the row ends up with the total
+__device__ __forceinline__ double row16_sum(double v) {
+#define BI_ROR_ADD(N)                                                                                              \
+    do {                                                                                                           \
+        const unsigned long long u = __double_as_longlong(v);                                                      \
+        const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x120 + N, 0xF, 0xF, true);           \
+        const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x120 + N, 0xF, 0xF, true);   \
+        v += __longlong_as_double(((unsigned long long)hi << 32) | lo);                                            \
+    } while (0)
+    BI_ROR_ADD(8);
+    BI_ROR_ADD(4);
+    BI_ROR_ADD(2);
+    BI_ROR_ADD(1);
+#undef BI_ROR_ADD
+    return v;
+}
 
-__global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
-    constexpr int KG = 8, CB = 4;                   // K groups of 4 streams, column blocks of 16 bins
+// CB: 16-bin column blocks per strip (strip = CB * 16 bins).  KG: groups of 4 streams (4 KG >= NS).  MASK: NS < 4 KG,
+// the A operands of the padding streams must be zeroed.
+template <int CB, int KG, bool MASK>
+__global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
+    constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.x * 4 + wave;
@@ -928,28 +1036,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
     const int n_items = a.grp_items[grp];
     const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
     const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
-    const int n_strips = a.item_tiles[item0] * (kTile / 64);
+    const int n_strips = a.item_tiles[item0] * (kTile / STRIP);
+    log_table_load();
     const int kq = lane >> 4, col = lane & 15;
-
-    // row offsets of this lane's K rows (clamped: streams beyond NS get a zero coefficient)
-    int64_t row[KG];
-    int aoff[KG];                                   // element offset of this lane's A operand inside an item
-    double amask[KG];
-#pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-        const int k = kg * 4 + kq;
-        row[kg] = rowoff[min(k, a.NS - 1)];
-        aoff[kg] = min(k, a.NS - 1) * 16 + col;
-        amask[kg] = k < a.NS ? 1.0 : 0.0;
-    }
+    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // A operand of K group kg sits at aoff0 + kg * 64 (clamped)
 
     for (int strip = slot; strip < n_strips; strip += a.nslots) {
-        const int64_t bin0 = (int64_t)strip * 64 + col;
+        const int64_t bin0 = (int64_t)strip * STRIP + col;
         double b[KG][CB], n[CB];
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
+        for (int kg = 0; kg < KG; ++kg) {
+            const int64_t row = rowoff[min(kg * 4 + kq, a.NS - 1)];   // streams beyond NS: a valid row times a zero coefficient
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row[kg] + bin0 + cb * 16];
+            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16];
+        }
         // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
         int kind[CB];
@@ -967,7 +1067,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
         {
             const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = coef[aoff[kg]] * amask[kg];
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 4 + kq;
+                av[kg] = coef[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) av[kg] = 0.0;
+            }
         }
         for (int it = 0; it < n_items; ++it) {
             const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
@@ -976,7 +1080,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
             double mn[4] = {0.0, 0.0, 0.0, 0.0};     // running minimum of mu: a negative expectation makes the result nan
             bi_double4 acc[CB];
             // software pipeline: the matrix pipe gets block cb + 1 before the VALU looks at block cb, and the next
-            // item's A operands are requested right behind the first chain, so they arrive under the other three
+            // item's A operands are requested right behind the first chain, so they arrive under the others
 #define BI_CHAIN(cb)                                                                                               \
     do {                                                                                                           \
         acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
@@ -990,9 +1094,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
             mn[r] = fmin(mn[r], acc[cb][r]);                                                                       \
         }                                                                                                          \
         if (special[cb]) {                                                                                         \
-            if (kind[cb] == 1) {                                                                                   \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log_call(acc[cb][r]);            \
-            } else if (kind[cb] != 0) {                                                                            \
+            bool checked = false;                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
+            if (__ballot(checked && kind[cb] == 1) == 0ull) {                                                      \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                    \
+                    const double lg = bin_log_fast(acc[cb][r]);                                                    \
+                    if (kind[cb] == 1) s[r] += n[cb] * lg;                                                         \
+                }                                                                                                  \
+            } else if (kind[cb] == 1) {                                                                            \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log(acc[cb][r]);            \
+            }                                                                                                      \
+            if (kind[cb] > 1) {                                                                            \
                 const double v = kind[cb] == 2 ? -__builtin_inf() : __builtin_nan("");                             \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += v;                                           \
             }                                                                                                      \
@@ -1000,22 +1112,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
     } while (0)
             BI_CHAIN(0);
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) an[kg] = coef_next[aoff[kg]];
-            BI_CHAIN(1);
-            BI_EPILOGUE(0);
-            BI_CHAIN(2);
-            BI_EPILOGUE(1);
-            BI_CHAIN(3);
-            BI_EPILOGUE(2);
-            BI_EPILOGUE(3);
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 4 + kq;
+                an[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) an[kg] = 0.0;
+            }
+#pragma unroll
+            for (int cb = 1; cb < CB; ++cb) {
+                BI_CHAIN(cb);
+                BI_EPILOGUE(cb - 1);
+            }
+            BI_EPILOGUE(CB - 1);
 #undef BI_CHAIN
 #undef BI_EPILOGUE
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (mn[r] < 0.0) s[r] = __builtin_nan("");
-                // sum over the 16 bins held by the 16 lanes of a row
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off, 64);
+                s[r] = row16_sum(s[r]);              // over the 16 bins held by the 16 lanes of a row
             }
             if (col == 0) {
                 double* __restrict__ dst = a.partial + ((item0 + it) * a.nslots + slot) * 16 + kq;
@@ -1023,7 +1136,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scan_mfma(ScanArgs a) {
                 for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + 4 * r, s[r]);
             }
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg] * amask[kg];
+            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg];
         }
     }
 }

@@ -327,11 +327,13 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
-        // the matrix-core scan kernel pays when many items share a cell and most bins are empty (its epilogue then
-        // rarely needs the logarithm): measured 1.2-1.4x over k_morph_reduce at >= 32 items per cell, slower on dense data
+        // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
+        // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
+        // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
+        // larger part of the work)
         const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
         const bool scan_ok = c->scan_mfma && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535 &&
-                             n_items >= 32 * n_groups && mostly_empty;
+                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups;
         if (scan_ok) {
             if ((rc = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
                 return abort_plan(rc);
@@ -340,10 +342,11 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             hipLaunchKernelGGL(k_plan_group_items, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                                (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p);
             // ~12 waves per CU over all groups; every wave owns one partial slot per item
-            const int64_t strips = max_tiles * (kTile / 64);
-            int64_t blocks = std::max<int64_t>(1, (12 * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
+            const int64_t strips = max_tiles * (kTile / 64);   // (at least; narrower strips only add more)
+            int64_t blocks = std::max<int64_t>(1, (c->scan_waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, strips / 4));
             plan->use_scan = true;
+            plan->scan_cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
             plan->n_groups = n_groups;
             k.nbx = (int)(blocks * 4);
             dev_free(k.partial);

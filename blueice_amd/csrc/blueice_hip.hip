@@ -38,6 +38,7 @@
 #define BI_VERSION "blueice_hip 0.1 (gfx950)"
 
 #include "bi_context.h"
+#include "bi_log_table.h"
 #include "bi_kernels.h"
 #include "bi_geometry.h"
 #include "bi_launch.h"
@@ -157,6 +158,9 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "scan_cb")) { c->scan_cb = (v == 2 || v == 4) ? v : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
         c->nt_loads = v;
@@ -476,7 +480,20 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
         {
             EventScope ev(c);
             ++c->n_scan_launches;
-            hipLaunchKernelGGL(k_scan_mfma, dim3((unsigned)(k.nbx / 4), (unsigned)plan->n_groups), dim3(kThreads), 0, c->stream, sa);
+            const dim3 sgrid((unsigned)(k.nbx / 4), (unsigned)plan->n_groups);
+            const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
+#define BI_SCAN(CB, KG)                                                                                           \
+    do {                                                                                                          \
+        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+        else hipLaunchKernelGGL((k_scan_mfma<CB, KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
+    } while (0)
+#define BI_SCAN_KG(CB)                                                                                            \
+    do {                                                                                                          \
+        if (kg == 1) BI_SCAN(CB, 1); else if (kg == 2) BI_SCAN(CB, 2); else if (kg == 4) BI_SCAN(CB, 4); else BI_SCAN(CB, 8); \
+    } while (0)
+            if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
+#undef BI_SCAN_KG
+#undef BI_SCAN
         }
         const int64_t n_slots = k.n_items * k.G;
         const int lanes = k.nbx > 64 ? kThreads : 64;

@@ -238,3 +238,43 @@ def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
     assert ctx.get_param('n_scan_launches') == before + 1
     assert np.all(np.isnan(bad))
     ctx.set_param('sparse', 1)
+
+
+@pytest.mark.parametrize('S,n_anchor,bins', [
+    (3, (), (2000,)),              # no shape parameter: 3 streams  (1 K group, masked)
+    (4, (), (1500,)),              # 4 streams                       (1 K group)
+    (3, (3,), (40, 30)),           # 6 streams                       (2 K groups, masked)
+    (4, (2,), (1100,)),            # 8 streams                       (2 K groups)
+    (3, (3, 2), (37, 41)),         # 12 streams                      (4 K groups, masked)
+    (4, (2, 3), (50, 21)),         # 16 streams                      (4 K groups)
+    (5, (2, 2, 3), (13, 11, 9)),   # 40 streams: beyond the kernel's 32 -> the vector kernel takes it
+    (3, (2, 3, 2), (12, 10, 9)),   # 24 streams                      (8 K groups, masked)
+])
+def test_matrix_core_scan_small_stream_counts(S, n_anchor, bins):
+    """Every (K groups, padding mask, strip width) variant of k_scan_mfma against the oracle on small models."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel(S, n_anchor, bins, seed=77)
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.set_param('sparse', 0)
+    model = m.dense_model()
+    z, r = m.random_points(3000, seed=5)
+    for dense in (False, True):
+        counts = m.counts(dense=dense)
+        ctx.upload_counts(counts)
+        want = np.array([orc.loglikelihood(model, counts, z[i], r[i]) for i in range(0, len(z), 50)])
+        for cb in (2, 4):
+            ctx.set_param('scan_cb', cb)
+            before = ctx.get_param('n_scan_launches')
+            got, st = ctx.eval(z, r)
+            ran = ctx.get_param('n_scan_launches') - before
+            assert ran == (1 if S * 2 ** len(n_anchor) <= 32 else 0)
+            assert not st.any()
+            np.testing.assert_allclose(got[::50], want, rtol=1e-10)
+            ctx.set_param('scan_mfma', 0)
+            vec, _ = ctx.eval(z, r)
+            ctx.set_param('scan_mfma', 1)
+            np.testing.assert_allclose(got, vec, rtol=1e-12)
+    ctx.close()

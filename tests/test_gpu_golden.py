@@ -152,6 +152,9 @@ def test_device_log_accuracy(ctx):
     from blueice_amd._capi import ptr
     rng = np.random.default_rng(0)
     x = np.concatenate([10.0 ** rng.uniform(-307, 308, 200000), rng.uniform(0.5, 2.0, 200000),
+                        10.0 ** rng.uniform(-323, -307, 20000),        # denormals
+                        rng.uniform(0.98, 1.02, 100000),               # where log changes sign
+                        2.0 ** rng.integers(-1000, 1000, 2000) * np.repeat([0.6875, 1.375], 1000),   # table interval edges
                         1.0 + rng.uniform(-1e-6, 1e-6, 50000), np.array([1.0, 2.0, 0.5, np.e, 0.70710678118654752, 1e-320,
                         0.0, -1.0, np.inf, np.nan, 2.2250738585072014e-308, 1.7976931348623157e308])])
     out = np.empty_like(x)

@@ -9,15 +9,16 @@ m.upload(ctx)
 ctx.set_param('sparse', 0)
 for dense in (False, True):
     ctx.upload_counts(m.counts(dense=dense))
-    for P in (16384, 65536, 131072):
+    for P in (1024, 2048, 4096, 8192):
         zz, rr = m.random_points(P, seed=7)
         res = {}
         for mf in (0, 1):
-            ctx.set_param('scan_mfma', mf)
+            ctx.set_param('scan_mfma', mf); ctx.set_param('scan_min_items', 1); ctx.set_param('device_plan_min', 1024)
             p = ctx.plan(zz, rr); p.run(); ctx.sync()
+            reps = max(2, 65536 // P)
             t = time.perf_counter()
-            for _ in range(2): p.run()
-            ctx.sync(); res[mf] = (2 * P / (time.perf_counter() - t), p.read()[0]); p.close()
-        err = np.max(np.abs(res[1][1] - res[0][1]) / np.abs(res[0][1]))
-        print('dense_data=%d P=%6d: vector kernel %8.0f evals/s   matrix-core scan %8.0f evals/s  (%.2fx)  max rel diff %.1e' % (
-            dense, P, res[0][0], res[1][0], res[1][0] / res[0][0], err))
+            for _ in range(reps): p.run()
+            ctx.sync(); res[mf] = (reps * P / (time.perf_counter() - t), p.read()[0]); p.close()
+        print('dense_data=%d P=%6d (%4.0f items per cell): vector %8.0f/s  matrix-core %8.0f/s (%.2fx, %.0e)' % (
+            dense, P, P / 64 / 16, res[0][0], res[1][0], res[1][0] / res[0][0],
+            np.max(np.abs(res[1][1] - res[0][1]) / np.abs(res[0][1]))), flush=True)
