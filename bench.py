@@ -116,8 +116,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29500')
         n_dev = max(torch.cuda.device_count(), 1)
         if args.backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            torch.cuda.set_device(local_rank % n_dev)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % n_dev))
         else:
             dist.init_process_group(args.backend)
     multi = world > 1 or force_dist
@@ -171,6 +171,8 @@ def main():
                 plans[i % POOL].run()
 
     run_steps(W)
+    if multi:
+        dist.all_gather(gathered, out)         # warm-up of the collective as well (communicator, channels, kernels)
     barrier()
     t0 = time.perf_counter()
     run_steps(K)
@@ -211,6 +213,14 @@ def main():
     except Exception:
         traffic = None
 
+    # the device's read-only streaming ceiling, measured live: a plain sum over the same resident tensor
+    stream_ceiling = None
+    if rank == 0:
+        try:
+            stream_ceiling = max(ctx.read_bandwidth(nontemporal=True, blocks_per_cu=b, reps=3) for b in (16, 32))
+        except Exception as e:                       # a measurement aid only: never fail the bench line over it
+            print('bench.py: read-bandwidth probe failed: %s' % e, file=sys.stderr)
+
     result = None
     if rank == 0:
         result = {
@@ -228,7 +238,10 @@ def main():
                          'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                            'bytes per launch)' if traffic else None,
                          'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads)', 'bytes_per_launch': bytes_per_launch,
-                         'avg_launch_us': ms / max(launches, 1) * 1e3},
+                         'avg_launch_us': ms / max(launches, 1) * 1e3,
+                         'stream_ceiling': stream_ceiling,
+                         'stream_ceiling_note': 'GB/s of a plain 16-byte-load sum over the resident 4 GB tensor '
+                                                '(nontemporal loads, best of 16 / 32 blocks per CU), same process'},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:

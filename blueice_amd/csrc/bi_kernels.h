@@ -84,6 +84,37 @@ __global__ void k_selftest_log(const double* __restrict__ x, int64_t n, double* 
     if (i < n) out[i] = bin_log(x[i]);
 }
 
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double* p) {
+    if constexpr (NT) {
+        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
+        double2 v;
+        v.x = __builtin_nontemporal_load(p);
+        v.y = __builtin_nontemporal_load(p + 1);
+        return v;
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+
+// measurement probe: a plain sum over n2 16-byte elements -- the read-only streaming ceiling the morph kernel is
+// compared with (bi_measure_read_bandwidth)
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_read_sum(const double* __restrict__ p, int64_t n2, double* __restrict__ sink) {
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 7 * stride < n2; i += 8 * stride) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = stream_load<NT>(p + 2 * (i + u * stride));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u].x + v[u].y;
+    }
+    for (; i < n2; i += stride) s += p[2 * i] + p[2 * i + 1];
+    if (s == 0.123456789) sink[0] = s;      // keeps the loads alive, practically never stores
+}
+
 // Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
 // (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
 //   mu not >= 0 (negative or nan) or n nan -> nan
@@ -156,18 +187,6 @@ struct LaunchArgs {
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
 // blockIdx.x strides over 512-bin tiles.
-template <bool NT>
-__device__ __forceinline__ double2 stream_load(const double* p) {
-    if constexpr (NT) {
-        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
-        double2 v;
-        v.x = __builtin_nontemporal_load(p);
-        v.y = __builtin_nontemporal_load(p + 1);
-        return v;
-    } else {
-        return *reinterpret_cast<const double2*>(p);
-    }
-}
 
 // The accumulate + per-bin term loop shared by the batched kernel and the single-point kernel: tiles
 // tile0, tile0 + tile_step, ... of one work item.

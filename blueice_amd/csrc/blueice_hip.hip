@@ -1082,6 +1082,37 @@ int bi_selftest_log(bi_ctx* c, int64_t n, const double* x, double* out) {
 
 // ---- measurement ---------------------------------------------------------------------------
 
+int bi_measure_read_bandwidth(bi_ctx* c, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || reps < 1 || blocks_per_cu < 1) return BI_ERR_INVALID;
+    if (!c->model_ready || !c->ps.p) return fail(c, BI_ERR_STATE, "bi_measure_read_bandwidth: no model resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf sink;
+    int rc = dev_alloc(c, sink, 8);
+    if (rc) return rc;
+    const int64_t n2 = c->A * c->S * c->Bp / 2;       // the whole template tensor, in 16-byte elements
+    const dim3 grid((unsigned)(c->prop.multiProcessorCount * blocks_per_cu));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; e == hipSuccess && r <= reps; ++r) {      // the first pass is the warm-up
+        e = hipEventRecord(e0, c->stream);
+        if (nontemporal) hipLaunchKernelGGL(k_read_sum<true>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, n2, (double*)sink.p);
+        else hipLaunchKernelGGL(k_read_sum<false>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, n2, (double*)sink.p);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r > 0 && ms > 0.f) best = std::max(best, (double)n2 * 16.0 / (ms * 1e6));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dev_free(sink);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_measure_read_bandwidth: %s", hipGetErrorString(e));
+    *gb_per_s = best;
+    return BI_OK;
+}
+
 int bi_profile_enable(bi_ctx* c, int on) {
     if (!c) return BI_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

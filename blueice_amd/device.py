@@ -261,6 +261,13 @@ class DeviceContext:
     def profile(self, on):
         self._check(self._lib.bi_profile_enable(self._h, 1 if on else 0))
 
+    def read_bandwidth(self, nontemporal=True, blocks_per_cu=32, reps=5):
+        """GB/s of a plain streaming sum over the resident template tensor: the device's read-only ceiling."""
+        out = C.c_double()
+        self._check(self._lib.bi_measure_read_bandwidth(self._h, 1 if nontemporal else 0, int(blocks_per_cu), int(reps),
+                                                        C.byref(out)))
+        return out.value
+
     def profile_read(self):
         n = C.c_int64()
         ms = C.c_double()

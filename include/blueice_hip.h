@@ -189,7 +189,11 @@ int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * While enabled, every morph+reduce launch is bracketed by HIP events on the context stream;
- * bi_profile_read drains them: number of launches and summed GPU time in milliseconds. */
+ * bi_profile_read drains them: number of launches and summed GPU time in milliseconds.
+ * bi_measure_read_bandwidth: the read-only streaming ceiling of the device (SURVEY.md 8d asks for it beside the
+ * 8 TB/s vendor figure) -- a plain 16-byte-load sum over the resident template tensor, best of `reps` passes,
+ * in GB/s; `nontemporal` selects the load hint, `blocks_per_cu` the grid. */
+int bi_measure_read_bandwidth(bi_ctx* ctx, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s);
 int bi_profile_enable(bi_ctx* ctx, int on);
 int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
 /* tunables: "tile_bins" is fixed at build time; "blocks_per_cu", "max_group" (points per pass) */
