@@ -13,7 +13,9 @@ import itertools
 
 import numpy as np
 
-__all__ = ['SyntheticModel', 'CONFIGS']
+from .source import Source
+
+__all__ = ['SyntheticModel', 'CONFIGS', 'TemplateSource']
 
 _MU_SLOPES = (0.02, -0.01, 0.005, 0.0025, -0.00125, 0.0006, 0.0003, 0.0001)
 
@@ -45,6 +47,9 @@ class SyntheticModel:
                 self.anchor_z.append(full[lo:lo + n].copy())
             else:
                 self.anchor_z.append(np.linspace(-2., 2., n))
+
+    def __deepcopy__(self, memo):
+        return self                 # immutable in effect; configs holding one are deep-copied per anchor model
 
     @classmethod
     def named(cls, name, **kw):
@@ -180,3 +185,69 @@ class SyntheticModel:
             if nm is not None:
                 nm[loc][self.bb_source] = self.anchor_n_model(a)
         return dict(anchor_z=self.anchor_z, ps=ps, mus=mus, n_model=nm)
+
+
+# -- the same synthetic model behind the Source / Model / LogLikelihood API -------------------------------
+
+class TemplateSource(Source):
+    """Source number `source_index` of a SyntheticModel at the anchor given by the shape-parameter settings in
+    its config (`shape_names`): lets a BinnedLogLikelihood of any size be built through the ordinary plug-in
+    route (config['sources'] / default_source_class, blueice/model.py:29-33) without a physics model behind it.
+    The PMF grid is generated on demand (nothing of template size stays on the host)."""
+
+    def __init__(self, config, *args, **kwargs):
+        synth = config['synthetic_model']
+        z = [float(config[name]) for name in config['shape_names']]
+        index = []
+        for g, zi in zip(synth.anchor_z, z):
+            hit = np.flatnonzero(g == zi)
+            if len(hit) != 1:
+                raise ValueError("TemplateSource exists on the anchors only; got %s" % (z,))
+            index.append(int(hit[0]))
+        self.synth = synth
+        self.anchor = int(np.ravel_multi_index(tuple(index), synth.n_anchor)) if synth.d else 0
+        self.index = int(config['source_index'])
+        config = dict(config, events_per_day=float(synth.anchor_mus(self.anchor)[self.index]), livetime_days=1)
+        super().__init__(config, *args, **kwargs)
+
+    def get_pmf_grid(self):
+        ps = self.synth.anchor_ps_cached(self.anchor)[self.index].reshape(self.synth.bins)
+        if self.synth.bb_source >= 0:
+            return ps, self.synth.anchor_n_model(self.anchor).reshape(self.synth.bins)
+        return ps, np.full(self.synth.bins, np.inf)
+
+    def simulate(self, n_events):
+        raise NotImplementedError("draw toys with BinnedLogLikelihood.simulate_toys (device side)")
+
+
+def _anchor_ps_cached(self, a):
+    """anchor_ps with a one-entry cache: the S sources of one anchor model ask for the same array in turn."""
+    if getattr(self, '_ps_cache', (None, None))[0] != a:
+        self._ps_cache = (a, self.anchor_ps(a))
+    return self._ps_cache[1]
+
+
+def _likelihood(self, likelihood_config=None, device=0, **kwargs):
+    """A prepared blueice_amd.likelihood.BinnedLogLikelihood of this model: one rate parameter per source, one
+    shape parameter per axis ('shape0', ...), analysis space = unit-width bins per axis.  No data set yet."""
+    from .likelihood import BinnedLogLikelihood
+    names = ['shape%d' % i for i in range(self.d)]
+    config = dict(
+        analysis_space=[('x%d' % i, np.arange(b + 1, dtype=float)) for i, b in enumerate(self.bins)],
+        default_source_class=TemplateSource, synthetic_model=self, shape_names=names,
+        sources=[dict(name='s%d' % s, source_index=s) for s in range(self.S)],
+        **{name: float(g[len(g) // 2]) for name, g in zip(names, self.anchor_z)})
+    lc = dict(likelihood_config or {}, device=device)
+    if self.bb_source >= 0:
+        lc.update(model_statistical_uncertainty_handling='bb_single', bb_single_source=self.bb_source)
+    lf = BinnedLogLikelihood(config, likelihood_config=lc, **kwargs)
+    for s in range(self.S):
+        lf.add_rate_parameter('s%d' % s)
+    for name, g in zip(names, self.anchor_z):
+        lf.add_shape_parameter(name, tuple(float(v) for v in g))
+    lf.prepare()
+    return lf
+
+
+SyntheticModel.anchor_ps_cached = _anchor_ps_cached
+SyntheticModel.likelihood = _likelihood

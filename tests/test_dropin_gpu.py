@@ -220,3 +220,36 @@ def test_intervals_and_scans_match_reference(ns):
     prof = lf.likelihood_ratio_scan(('shift', sh[:4]), s1_rate_multiplier=0.)
     want = np.array([lf.bestfit_scipy(shift=b, s1_rate_multiplier=0.)[1] for b in sh[:4]])
     np.testing.assert_allclose(prof, want.max() - want, atol=1e-6)
+
+
+def test_synthetic_model_through_the_plugin_api():
+    """SyntheticModel.likelihood(): the synthetic tensors behind Source / Model / BinnedLogLikelihood (the route a
+    user's sources take), against the oracle on the dense tensors and against a fit started elsewhere."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    lf = m.likelihood()
+    counts = m.counts(dense=True)
+    lf.set_binned_data(counts.reshape(m.bins))
+    model = m.dense_model()
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        z = rng.uniform(-1, 1, m.d)
+        r = rng.uniform(0.5, 1.5, m.S)
+        kw = {'shape%d' % i: z[i] for i in range(m.d)}
+        kw.update({'s%d_rate_multiplier' % s: r[s] for s in range(m.S)})
+        want = orc.loglikelihood(model, counts, z, r)
+        got = lf(**kw)
+        assert abs(got - want) <= 1e-10 * abs(want)
+    assert lf(shape0=1.5) == -np.inf                      # outside the anchor box (mini3 has anchors -1, 0, 1)
+    # the four synthetic sources are the same noise, so their rates are degenerate: float one rate and one shape
+    fixed = dict(s1_rate_multiplier=1, s2_rate_multiplier=1, s3_rate_multiplier=1, shape1=0.2, shape2=-0.3)
+    best, ll = lf.bestfit_scipy(**fixed)
+    best_g, ll_g = lf.bestfit_scipy(use_gradient=True, **fixed)
+    assert set(best) == {'s0_rate_multiplier', 'shape0'}
+    assert abs(ll - ll_g) <= 1e-6 * abs(ll)
+    assert all(abs(best[k] - best_g[k]) < 5e-3 for k in best)
+    assert ll >= lf(**fixed)
+    z = np.array([best['shape0'], 0.2, -0.3])
+    r = np.array([best['s0_rate_multiplier'], 1, 1, 1])
+    assert abs(ll - orc.loglikelihood(model, counts, z, r)) <= 1e-10 * abs(ll)
