@@ -183,6 +183,7 @@ struct LaunchArgs {
     double outlier;         // MODE 2: likelihood given to events with a non-positive density (0 = none)
     int n0, n1, n2;         // streams into U (or mu), into P_i, into a
     int n_tiles;
+    int chunks;             // > 1: consecutive blocks work in `chunks` far-apart regions of the rows
 };
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
@@ -200,7 +201,14 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
     double2 tab = {0.0, 0.0};
     if (threadIdx.x < 128) tab = kLogTable[threadIdx.x];
     bool tab_pending = true;
-    for (int tile = tile0; tile < n_tiles; tile += tile_step) {     // (the trip count is the same for a whole block)
+    // XCD-aware tile order: with 8 chunks block b -- dispatched to XCD b % 8 -- streams the b % 8-th contiguous region of
+    // every row instead of every 8th tile (measured +6 % on the 113-stream BB pass, +1 % on C2); short rows keep the
+    // plain order, where the padded chunk count would cost some blocks a second tile
+    const int chunks = (a.chunks > 1 && n_tiles >= 64 * a.chunks) ? a.chunks : 1;
+    const int per_chunk = (n_tiles + chunks - 1) / chunks;
+    for (int lt = tile0; lt < per_chunk * chunks; lt += tile_step) {     // (the trip count is the same for a whole block)
+        const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
+        if (tile >= n_tiles) continue;
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
         double acc[G][2];
 #pragma unroll
@@ -949,32 +957,52 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* 
     }
 }
 
-// pass 2: for dataset t: sum_b xlogy(n_tb, mu_b) ; blockIdx.y = dataset, x strides tiles
+// pass 2: for dataset t: sum_b xlogy(n_tb, mu_b).  blockIdx.y = group of kDotGroup datasets, x strides tiles: the
+// log mu tile is loaded once per group (it stays in L2 / Infinity Cache: 8 MB), the counts rows stream through once
+// with the nontemporal hint; XCD-aware tile order as in morph_tiles.
+constexpr int kDotGroup = 8;
+
+__device__ __forceinline__ double xlogy_term(double n, double l) {
+    double t = (n > 0.0) ? n * l : 0.0;
+    if (n != n) t = __builtin_nan("");
+    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
+    return t;
+}
+
 __global__ __launch_bounds__(kThreads) void k_dataset_dot(const double* __restrict__ counts,
                                                           const double* __restrict__ logmu, int64_t Bp, int n_tiles,
-                                                          int64_t t0, double* __restrict__ partial) {
-    const double* __restrict__ c = counts + (t0 + blockIdx.y) * Bp;
-    double s = 0.0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+                                                          int64_t t0, int64_t n_sets, double* __restrict__ partial) {
+    const int64_t d0 = (int64_t)blockIdx.y * kDotGroup;
+    const double* __restrict__ c[kDotGroup];
+#pragma unroll
+    for (int g = 0; g < kDotGroup; ++g) c[g] = counts + (t0 + min(d0 + g, n_sets - 1)) * Bp;   // tail group: repeats the last row
+    double s[kDotGroup];
+#pragma unroll
+    for (int g = 0; g < kDotGroup; ++g) s[g] = 0.0;
+    const int chunks = n_tiles >= 64 * 8 ? 8 : 1;
+    const int per_chunk = (n_tiles + chunks - 1) / chunks;
+    for (int lt = blockIdx.x; lt < per_chunk * chunks; lt += gridDim.x) {
+        const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
+        if (tile >= n_tiles) continue;
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        const double2 n = *reinterpret_cast<const double2*>(c + bin0);
+        double2 n[kDotGroup];
+#pragma unroll
+        for (int g = 0; g < kDotGroup; ++g) n[g] = stream_load<true>(c[g] + bin0);
         const double2 l = *reinterpret_cast<const double2*>(logmu + bin0);
-        double t0v = (n.x > 0.0) ? n.x * l.x : 0.0;
-        double t1v = (n.y > 0.0) ? n.y * l.y : 0.0;
-        if (n.x != n.x) t0v = __builtin_nan("");
-        else if (n.x < 0.0 || n.x != floor(n.x)) t0v = -__builtin_inf();
-        if (n.y != n.y) t1v = __builtin_nan("");
-        else if (n.y < 0.0 || n.y != floor(n.y)) t1v = -__builtin_inf();
-        s += t0v + t1v;
+#pragma unroll
+        for (int g = 0; g < kDotGroup; ++g) s[g] += xlogy_term(n[g].x, l.x) + xlogy_term(n[g].y, l.y);
     }
-    __shared__ double sh[kThreads / 64];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __shared__ double sh[kThreads / 64][kDotGroup];
+#pragma unroll
+    for (int g = 0; g < kDotGroup; ++g) {
+        const double w = wave_sum(s[g]);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][g] = w;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0];
-        for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
-        partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x < kDotGroup && d0 + threadIdx.x < n_sets) {
+        double t = sh[0][threadIdx.x];
+        for (int w = 1; w < kThreads / 64; ++w) t += sh[w][threadIdx.x];
+        partial[(d0 + threadIdx.x) * gridDim.x + blockIdx.x] = t;
     }
 }
 

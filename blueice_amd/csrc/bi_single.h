@@ -75,7 +75,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     a.counts = (sparse ? (const double*)c->cnt_c.p + c->h_cnt_off[(size_t)ds] : (const double*)c->counts.p + ds * c->Bp);
     a.partial = (double*)c->slot_partial.p;
     a.pflags = (unsigned*)c->slot_pflags.p;
-    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
     const bool nt = !sparse && c->nt_loads != 0;
     const bool fuse = nbx <= c->fuse_max_blocks;
@@ -212,7 +212,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     a.item_tiles = (const int32_t*)(dev + (o + 1) * 8);
     a.partial = (double*)c->slot_partial.p;
     a.pflags = (unsigned*)c->slot_pflags.p;
-    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
     launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
     const int lanes = nbx > 64 ? kThreads : 64;

@@ -159,6 +159,8 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "row_pad_bins")) { c->row_pad_bins = v < 0 ? 0 : v / 2 * 2; return BI_OK; }
     if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "scan_cb")) { c->scan_cb = (v == 2 || v == 4) ? v : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
@@ -205,7 +207,7 @@ int bi_model_begin(bi_ctx* c, int d, const int32_t* n_anchor, const double* anch
     c->data_ready = false;  // a new model invalidates the data (likelihood.py:253)
     ++c->epoch;
     c->d = d; c->S = S; c->B = B; c->bb_source = bb_source;
-    c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile);
+    c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile) + c->row_pad_bins;
     c->unbinned = false;
     c->n_anchor.assign(d, 0);
     c->grid.assign(d, {});
@@ -467,6 +469,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     a.n0 = bb ? nc * (c->S - 1) : nc * c->S;
     a.n1 = bb ? nc : 0; a.n2 = bb ? nc : 0;
     a.n_tiles = n_tiles_of(c);
+    a.chunks = (int)c->tile_chunks;
     const int NS = a.n0 + a.n1 + a.n2;
     if (plan->use_scan) {
         bi_plan::Class& k = plan->classes[0];
@@ -767,7 +770,7 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     const bool csr = (c->sparse && c->csr_ready) || !c->dense_counts;
     if (csr && !c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
     const int64_t chunk = csr ? 1048576 : 16384;
-    const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, std::min(n, chunk))));
+    const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
     if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
         (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
@@ -796,8 +799,8 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
                                    (const int32_t*)c->nz_idx.p, (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p,
                                    (const double*)c->logmu.p, t0 + s0, (double*)c->scratch2.p);
             else
-                hipLaunchKernelGGL(k_dataset_dot, dim3((unsigned)nbx, (unsigned)ni), dim3(kThreads), 0, c->stream,
-                                   (const double*)c->counts.p, (const double*)c->logmu.p, c->Bp, n_tiles, t0 + s0,
+                hipLaunchKernelGGL(k_dataset_dot, dim3((unsigned)nbx, (unsigned)((ni + kDotGroup - 1) / kDotGroup)), dim3(kThreads), 0,
+                                   c->stream, (const double*)c->counts.p, (const double*)c->logmu.p, c->Bp, n_tiles, t0 + s0, ni,
                                    (double*)c->scratch2.p);
         }
         hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
