@@ -94,3 +94,67 @@ def test_random_configurations_match_oracle(seed):
                 else:
                     assert toys[0] == want[0] or (np.isnan(toys[0]) and np.isnan(want[0]))
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_large_batches_device_planner_and_scan_kernel(seed):
+    """Batches large enough for the device-side planner and the matrix-core scan kernel, on random small models:
+    several datasets, counts with nan / negative / non-integer entries, sources allowed to go negative (mu < 0 ->
+    nan), switched-off sources, points outside the box, nan coordinates, unphysical rates, bad dataset numbers."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(5000 + seed)
+    ctx = DeviceContext(0)
+    scan_runs = 0
+    for rep in range(3):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 3, 4, 5, 8]))
+        B = int(rng.choice([40, 511, 512, 700, 1300]))
+        model, counts0 = random_case(rng, d, S, B, -1)
+        T = int(rng.integers(1, 4))
+        counts = np.stack([rng.poisson(counts0 * rng.uniform(0.5, 2)).astype(float) for _ in range(T)])
+        if rng.random() < 0.5:
+            counts[rng.integers(T), rng.integers(B)] = rng.choice([np.nan, -1.0, 2.5])
+        allow_negative = None
+        if rng.random() < 0.4:
+            allow_negative = np.zeros(S, dtype=bool)
+            allow_negative[rng.integers(S)] = True
+        P = int(rng.integers(600, 1500))
+        z, r = random_points(rng, model, P, S)
+        if allow_negative is not None:
+            neg = rng.random(P) < 0.2
+            r[neg, np.flatnonzero(allow_negative)[0]] = -rng.uniform(0.5, 3.0, neg.sum())
+        ds = rng.integers(0, T, P)
+        bad = rng.random(P)
+        if d:
+            z[bad < 0.02, 0] = 99.0
+            z[(bad > 0.02) & (bad < 0.03), d - 1] = np.nan
+        r[(bad > 0.03) & (bad < 0.05), 0] = -0.5 if allow_negative is None or not allow_negative[0] else np.inf
+        ds[(bad > 0.05) & (bad < 0.06)] = T + 3
+        want = np.empty(P)
+        for i in range(P):
+            if not 0 <= ds[i] < T:
+                want[i] = np.nan
+                continue
+            want[i] = orc.loglikelihood(model, counts[ds[i]], z[i], r[i], allow_negative=allow_negative)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        if allow_negative is not None:
+            ctx.set_allow_negative(allow_negative)
+        for sparse in (0, 1):
+            ctx.set_param('sparse', sparse)
+            ctx.upload_counts(counts)
+            before = ctx.get_param('n_scan_launches')
+            got, st = ctx.eval(z if d else None, r, dataset=ds)
+            used_scan = ctx.get_param('n_scan_launches') > before
+            scan_runs += used_scan
+            bad_ds = ~((ds >= 0) & (ds < T))
+            assert np.all((st[bad_ds] & 16) != 0) and not np.any(st[~bad_ds] & 16)
+            for i in np.flatnonzero(~bad_ds):
+                w, g = want[i], got[i]
+                ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
+                assert ok, (seed, rep, d, S, B, T, sparse, used_scan, i, g, w, st[i])
+        if allow_negative is not None:
+            ctx.set_allow_negative(np.zeros(S, dtype=bool))
+    print('matrix-core scan kernel used in %d of 6 batches' % scan_runs)
+    assert scan_runs >= 1
+    ctx.close()
