@@ -341,12 +341,16 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                                (const int64_t*)d_keys.p, n_valid, (int64_t*)plan->grp_first.p);
             hipLaunchKernelGGL(k_plan_group_items, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                                (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p);
-            // ~12 waves per CU over all groups; every wave owns one partial slot per item
-            const int64_t strips = max_tiles * (kTile / 64);   // (at least; narrower strips only add more)
+            // scan_waves_per_cu waves per CU over all groups, evened out so that every wave gets the same number of
+            // strips (a block lasts as long as its busiest wave); every wave owns one partial slot per item
+            const int cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
+            const int64_t strips = max_tiles * (kTile / (16 * cb));
             int64_t blocks = std::max<int64_t>(1, (c->scan_waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, strips / 4));
+            const int64_t per_wave = (strips + 4 * blocks - 1) / (4 * blocks);
+            blocks = (strips + 4 * per_wave - 1) / (4 * per_wave);
             plan->use_scan = true;
-            plan->scan_cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
+            plan->scan_cb = cb;
             plan->n_groups = n_groups;
             k.nbx = (int)(blocks * 4);
             dev_free(k.partial);
