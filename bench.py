@@ -365,6 +365,13 @@ def main():
             lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
         ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
         ex['api_bestfit_max_loglikelihood'] = ll
+        # BASELINE.json configs[3] on one GPU: a profile scan of 10^6 parameter points through lf.eval_points
+        g = np.random.default_rng(5)
+        pts = dict(shape0=g.uniform(-2, 2, 10 ** 6), shape1=g.uniform(-2, 2, 10 ** 6), s0_rate_multiplier=g.uniform(0.8, 1.2, 10 ** 6))
+        lf.eval_points(pts)
+        t = time.perf_counter()
+        lf.eval_points(pts)
+        ex['api_eval_points_1e6_s'] = time.perf_counter() - t
         del lf
         result['extras'] = ex
         # BASELINE.json's north star names two targets; where each one is met

@@ -205,6 +205,18 @@ class LogLikelihoodBase:
         return prior, np.asarray(zs, dtype=float), scale
 
 
+def _prior_of(log_prior, values):
+    """log_prior over an array of parameter values: one vectorised call when the callable takes arrays (scipy's
+    frozen distributions do), the reference's one call per value otherwise."""
+    try:
+        out = np.asarray(log_prior(values), dtype=float)
+        if out.shape == values.shape:
+            return out
+    except Exception:
+        pass
+    return np.array([log_prior(v) for v in values], dtype=float)
+
+
 class DeviceLogLikelihood(LogLikelihoodBase):
     """What the binned and the unbinned likelihood share: one DeviceContext holding the anchor tensor, and
     evaluation = host bookkeeping + one fused device call."""
@@ -326,7 +338,7 @@ class DeviceLogLikelihood(LogLikelihoodBase):
         for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
             z[:, i] = cols[names.index(name)] if name in names else defaults[name]
             if log_prior is not None:
-                prior += np.array([log_prior(v) for v in z[:, i]])
+                prior += _prior_of(log_prior, z[:, i])
         scale = np.ones((P, len(self.source_name_list)))
         for s, name in enumerate(self.source_name_list):
             key = name + '_rate_multiplier'
@@ -334,7 +346,7 @@ class DeviceLogLikelihood(LogLikelihoodBase):
                 scale[:, s] = cols[names.index(key)]
             log_prior = self.rate_parameters.get(name)
             if log_prior is not None:
-                prior += np.array([log_prior(v) for v in scale[:, s]])
+                prior += _prior_of(log_prior, scale[:, s])
         if livetime_days is not None:
             if 'livetime_days' not in self.pdf_base_config:
                 raise ValueError("Cannot scale live-time, base value absent")

@@ -31,3 +31,11 @@ if '--check' in sys.argv:
     r = np.array([best.get('s%d_rate_multiplier' % s, 1.0) for s in range(m.S)])
     want = orc.loglikelihood(m.cell_model(z), counts, z, r)
     print('oracle at the best-fit point: %.6f   (device %.6f, rel diff %.1e)' % (want, ll, abs(want - ll) / abs(want)))
+for P in (10**4, 10**5, 10**6):
+    pts = dict(shape0=np.random.default_rng(1).uniform(-2, 2, P), shape1=np.random.default_rng(2).uniform(-2, 2, P),
+               s0_rate_multiplier=np.random.default_rng(3).uniform(0.8, 1.2, P))
+    lf.eval_points(pts)
+    t = time.perf_counter()
+    ll = lf.eval_points(pts)
+    dt = time.perf_counter() - t
+    print('lf.eval_points, %7d points: %.1f ms  (%.2f M evaluations/s end to end)' % (P, dt * 1e3, P / dt / 1e6), flush=True)
