@@ -106,7 +106,6 @@ struct bi_ctx {
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
     int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
     int64_t tile_chunks = 8;                     // blocks walk the tiles in this many far-apart regions: block b (XCD b % 8) streams region b % 8
-    int64_t row_pad_bins = 0;                    // extra bins between rows (decorrelates the row streams' channels)
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell

@@ -160,7 +160,6 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
-    if (!strcmp(name, "row_pad_bins")) { c->row_pad_bins = v < 0 ? 0 : v / 2 * 2; return BI_OK; }
     if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "scan_cb")) { c->scan_cb = (v == 2 || v == 4) ? v : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
@@ -207,7 +206,7 @@ int bi_model_begin(bi_ctx* c, int d, const int32_t* n_anchor, const double* anch
     c->data_ready = false;  // a new model invalidates the data (likelihood.py:253)
     ++c->epoch;
     c->d = d; c->S = S; c->B = B; c->bb_source = bb_source;
-    c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile) + c->row_pad_bins;
+    c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile);
     c->unbinned = false;
     c->n_anchor.assign(d, 0);
     c->grid.assign(d, {});

@@ -196,7 +196,19 @@ int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
 int bi_measure_read_bandwidth(bi_ctx* ctx, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s);
 int bi_profile_enable(bi_ctx* ctx, int on);
 int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
-/* tunables: "tile_bins" is fixed at build time; "blocks_per_cu", "max_group" (points per pass) */
+/* Tunables (bi_set_param; all have measured defaults) and read-only counters (bi_get_param):
+ *   sparse            0 every bin visited | 1 non-empty-bin form when exact (templates >= 0, default) | 2 force
+ *   max_group         points per cell pass: 1, 2, 4, 8, 16 (default 16)
+ *   blocks_per_cu     resident blocks per CU the launch shapes aim for (8)
+ *   nt_loads          0 never | 1 always | 2 nontemporal template loads when no two items share an anchor (default)
+ *   tile_chunks       XCD-aware tile order: contiguous regions per row (8; 1 = plain order)
+ *   single_kernel, fuse_max_blocks   one-launch path of single evaluations, in-launch finish up to this many blocks
+ *   xcd_affine        round block counts to multiples of 8
+ *   device_plan_min   batches of at least this many points are planned on the device (512)
+ *   scan_mfma, scan_min_items, scan_cb, scan_waves_per_cu   the matrix-core scan kernel: on/off, items per cell from
+ *                     which it is used (4; x2 for dense data), strip width (0 = by the data), launch width
+ *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
+ * read-only: tile_bins, padded_bins, n_scan_launches, csr_ready, compact_ready, ps_nonneg, nnz_total */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
 int64_t bi_get_param(bi_ctx* ctx, const char* name);
 
