@@ -33,6 +33,8 @@ def main(rnd):
     shutil.copy(os.path.join(SRC, 'bench.json'), os.path.join(dst, tag + '_bench.json'))
     shutil.copy(os.path.join(SRC, 'bench_under_rocprof.json'), os.path.join(dst, tag + '_bench_under_rocprof.json'))
     shutil.copy(os.path.join(SRC, 'kt', 'kt_kernel_stats.csv'), os.path.join(dst, tag + '_bench_kernel_stats.csv'))
+    if os.path.exists(os.path.join(SRC, 'extras', 'extras_kernel_stats.csv')):
+        shutil.copy(os.path.join(SRC, 'extras', 'extras_kernel_stats.csv'), os.path.join(dst, tag + '_extras_kernel_stats.csv'))
     bench = json.load(open(os.path.join(SRC, 'bench_under_rocprof.json')))
     algo = bench['roofline']['bytes_per_launch']
     fetch = counter(os.path.join(SRC, 'fetch', 'fetch_counter_collection.csv'), 'FETCH_SIZE')
