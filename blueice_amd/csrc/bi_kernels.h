@@ -784,24 +784,22 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // uniform on
     return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-__device__ double poisson_draw(double lam, uint64_t seed, int64_t t, int64_t b) {
-    if (!(lam > 0.0)) return 0.0;  // mu = 0 (or invalid) -> no events
+// lam < 10: inversion by sequential search with one 53-bit uniform; p0 = exp(-lam) comes from a per-bin table (it is
+// the same for every toy)
+__device__ __forceinline__ double poisson_small(double lam, double p0, double u) {
+    double p = p0, F = p, n = 0.0;
+    while (u > F && n < 1000.0) {
+        n += 1.0;
+        p *= lam / n;
+        F += p;
+    }
+    return n;
+}
+
+// lam >= 10: PTRS, Hoermann (1993): transformed rejection with squeeze, as in numpy's random_poisson_ptrs
+__device__ double poisson_ptrs(double lam, uint64_t seed, int64_t t, int64_t b) {
     uint32_t r[4];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (lam < 10.0) {
-        // inversion by sequential search (one uniform)
-        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, k0, k1, r);
-        const double u = u53(r[0], r[1]);
-        double p = exp(-lam), F = p;
-        double n = 0.0;
-        while (u > F && n < 1000.0) {
-            n += 1.0;
-            p *= lam / n;
-            F += p;
-        }
-        return n;
-    }
-    // PTRS, Hoermann (1993): transformed rejection with squeeze, as in numpy's random_poisson_ptrs
     const double slam = sqrt(lam), loglam = log(lam);
     const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb;
     const double invalpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
@@ -817,14 +815,44 @@ __device__ double poisson_draw(double lam, uint64_t seed, int64_t t, int64_t b) 
     return floor(lam);  // unreachable in practice (acceptance > 0.9 per attempt)
 }
 
-__global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
-                                                        int32_t* __restrict__ cnt, int nchunks) {
+// The draws of bins b (even) and b + 1 of toy t: one Philox block gives both their uniforms.
+__device__ __forceinline__ void poisson_draw_pair(const double* __restrict__ mu, const double* __restrict__ p0, int64_t B,
+                                                  uint64_t seed, int64_t t, int64_t b, double& n0, double& n1) {
+    n0 = n1 = 0.0;
+    if (b >= B) return;
+    const double2 lam = *reinterpret_cast<const double2*>(mu + b);      // rows are padded to an even length
+    const double2 e = *reinterpret_cast<const double2*>(p0 + b);
+    const bool has1 = b + 1 < B;
+    const bool small0 = lam.x > 0.0 && lam.x < 10.0, small1 = has1 && lam.y > 0.0 && lam.y < 10.0;
+    if (small0 || small1) {
+        uint32_t r[4];
+        const int64_t pair = b >> 1;
+        philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), r);
+        if (small0) n0 = poisson_small(lam.x, e.x, u53(r[0], r[1]));
+        if (small1) n1 = poisson_small(lam.y, e.y, u53(r[2], r[3]));
+    }
+    if (lam.x >= 10.0) n0 = poisson_ptrs(lam.x, seed, t, b);            // mu = 0 or invalid -> no events
+    if (has1 && lam.y >= 10.0) n1 = poisson_ptrs(lam.y, seed, t, b + 1);
+}
+
+// p0[b] = exp(-mu[b]): once per bin, shared by all toys
+__global__ void k_exp_neg(const double* __restrict__ mu, int64_t n, double* __restrict__ p0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p0[i] = exp(-mu[i]);
+}
+
+__global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict__ mu, const double* __restrict__ p0, int64_t B,
+                                                        uint64_t seed, int64_t t0, int32_t* __restrict__ cnt, int nchunks) {
     const int64_t t = t0 + blockIdx.y;
     const int64_t b0 = (int64_t)blockIdx.x * kNzChunk + threadIdx.x * kNzPerThread;
     int k = 0;
 #pragma unroll 1
-    for (int j = 0; j < kNzPerThread; ++j)
-        if (b0 + j < B && poisson_draw(mu[b0 + j], seed, t, b0 + j) != 0.0) ++k;
+    for (int j = 0; j < kNzPerThread; j += 2) {
+        double n0, n1;
+        poisson_draw_pair(mu, p0, B, seed, t, b0 + j, n0, n1);
+        k += (n0 != 0.0) + (n1 != 0.0);
+    }
     __shared__ int sh[kThreads / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, 64);
@@ -833,7 +861,8 @@ __global__ __launch_bounds__(kThreads) void k_toy_count(const double* __restrict
     if (threadIdx.x == 0) cnt[(int64_t)blockIdx.y * nchunks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restrict__ mu, int64_t B, uint64_t seed, int64_t t0,
+__global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restrict__ mu, const double* __restrict__ p0, int64_t B,
+                                                          uint64_t seed, int64_t t0,
                                                           const int64_t* __restrict__ chunk_off, int nchunks,
                                                           int32_t* __restrict__ nz_idx, double* __restrict__ nz_n,
                                                           double* __restrict__ lg_partial) {
@@ -842,10 +871,12 @@ __global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restri
     double v[kNzPerThread];
     int k = 0;
     double lg = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < kNzPerThread; ++j) {
-        v[j] = (b0 + j < B) ? poisson_draw(mu[b0 + j], seed, t, b0 + j) : 0.0;
-        if (v[j] != 0.0) { ++k; if (v[j] > 1.0) lg += lgamma(v[j] + 1.0); }
+#pragma unroll
+    for (int j = 0; j < kNzPerThread; j += 2) {
+        poisson_draw_pair(mu, p0, B, seed, t, b0 + j, v[j], v[j + 1]);
+#pragma unroll
+        for (int q = j; q < j + 2; ++q)
+            if (v[q] != 0.0) { ++k; if (v[q] > 1.0) lg += lgamma(v[q] + 1.0); }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = k;

@@ -851,10 +851,10 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int nmu = (int)std::min<int64_t>(n_tiles, slots);
     const int64_t B = c->B;
     const int nchunks = (int)((B + kNzChunk - 1) / kNzChunk);
-    DevBuf d_row, d_coef, d_cnt, d_off, d_lgp;
-    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_off); dev_free(d_lgp); };
+    DevBuf d_row, d_coef, d_cnt, d_off, d_lgp, d_p0;
+    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_off); dev_free(d_lgp); dev_free(d_p0); };
     if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
-        (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
+        (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) || (rc = dev_alloc(c, d_p0, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
         (rc = dev_alloc(c, d_cnt, (size_t)T * nchunks * sizeof(int32_t))) ||
         (rc = dev_alloc(c, d_lgp, (size_t)T * nchunks * sizeof(double))) || (rc = dev_alloc(c, c->lgsum, (size_t)T * sizeof(double)))) {
@@ -870,10 +870,12 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles;
     hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p, 1);
     const double* mu = (const double*)c->logmu.p;
+    const double* p0 = (const double*)d_p0.p;
+    hipLaunchKernelGGL(k_exp_neg, dim3((unsigned)((c->Bp + 255) / 256)), dim3(256), 0, c->stream, mu, c->Bp, (double*)d_p0.p);
     const int64_t tchunk = 32768;
     for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
         const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_toy_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, B, seed, t0,
+        hipLaunchKernelGGL(k_toy_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed, t0,
                            (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
     }
     std::vector<int32_t> h_cnt((size_t)T * nchunks);
@@ -896,7 +898,7 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     }
     for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
         const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_toy_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, B, seed, t0,
+        hipLaunchKernelGGL(k_toy_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed, t0,
                            (const int64_t*)d_off.p + t0 * nchunks, nchunks, (int32_t*)c->nz_idx.p, (double*)c->nz_n.p,
                            (double*)d_lgp.p + t0 * nchunks);
         hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
