@@ -42,11 +42,11 @@ POOL = 8
 
 
 def cpu_baseline_all_cores(config, n_procs, budget_s=10.0):
-    """N independent host processes (tools/cpu_worker.py), each evaluating its own point with the oracle
+    """N independent host processes (oracle/cpu_worker.py), each evaluating its own point with the oracle
     (BASELINE.md section 4, step 2).  Plain subprocesses: nothing is forked from this GPU-initialised process."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
-    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_worker.py'), config]
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_worker.py'), config]
     procs = [subprocess.Popen(cmd + [str(500 + i), str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                               env=env, text=True) for i in range(n_procs)]
     rate, done = 0.0, 0
