@@ -252,3 +252,30 @@ def test_likelihood_sum_host_logic():
     assert tot.split_results(dict(x=1, y=2, s1_rate_multiplier=3)) == [dict(x=1, y=2), dict(x=1, s1_rate_multiplier=3)]
     objective, names, guess, bounds = tot.make_objective()
     assert names == ['s0_rate_multiplier', 's1_rate_multiplier', 'x', 'y']
+
+
+@pytest.mark.parametrize('name,bb', [('mini3', -1), ('mini4bb', 0)])
+def test_synthetic_model_through_the_plugin_route(monkeypatch, name, bb):
+    """SyntheticModel.likelihood() builds the model from Source plug-ins (TemplateSource) through the ordinary
+    config -> Model -> prepare() route: what reaches the device is exactly the synthetic tensor, anchor by anchor."""
+    import blueice_amd.likelihood as lk
+    from blueice_amd.synthetic import SyntheticModel, TemplateSource
+    monkeypatch.setattr(lk, 'DeviceContext', RecordingContext)
+    RecordingContext.instances.clear()
+    m = SyntheticModel.named(name, bb_source=bb)
+    lf = m.likelihood()
+    rec = RecordingContext.instances[-1]
+    assert rec.S == m.S and rec.B == m.B and rec.bb_source == bb and len(rec.anchors) == m.A
+    for g, want in zip(rec.anchor_z, m.anchor_z):
+        np.testing.assert_array_equal(g, want)
+    for a in range(m.A):
+        ps, mus, nm = rec.anchors[a]
+        np.testing.assert_array_equal(ps, m.anchor_ps(a))
+        np.testing.assert_array_equal(mus, m.anchor_mus(a))
+        if bb >= 0:
+            np.testing.assert_array_equal(nm, m.anchor_n_model(a))
+    assert list(lf.shape_parameters) == ['shape%d' % i for i in range(m.d)]
+    assert all(isinstance(s, TemplateSource) for s in lf.base_model.sources)
+    assert lf.get_bounds('shape0') == (float(m.anchor_z[0][0]), float(m.anchor_z[0][-1]))
+    with pytest.raises(ValueError):                       # a TemplateSource exists on the anchors only
+        lf._compute_single_model(shape0=0.123)
