@@ -98,6 +98,7 @@ struct bi_ctx {
     DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
+    unsigned long long slot_seq = 0;  // sequence number of single-point calls (the kernel echoes it when done)
 
     // device mirrors of the small tables the planning kernels read (bi_planning_device.h)
     DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz;
@@ -105,6 +106,7 @@ struct bi_ctx {
     bool plan_tables_sparse = false;
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
     int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
+    int64_t poll_result = 1;                     // single evaluations: poll the pinned result word instead of a stream sync
     int64_t tile_chunks = 8;                     // blocks walk the tiles in this many far-apart regions: block b (XCD b % 8) streams region b % 8
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data

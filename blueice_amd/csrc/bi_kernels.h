@@ -391,6 +391,8 @@ struct SingleDesc {
     unsigned* counter;    // zero on entry, re-armed by the finishing block
     double* out;          // pinned host
     int32_t* status;      // pinned host
+    unsigned long long* done;   // pinned host: receives `seq` after out / status (the host polls it)
+    unsigned long long seq;
 };
 
 template <bool BB, bool NT, int MODE, bool FUSE>
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
         *d.out = t - d.slot_lg;
         *d.status = (int32_t)ff;
         *d.counter = 0u;   // re-arm for the next launch on this stream
+        __hip_atomic_store(d.done, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
 // (an agent-scope release per block costs more than a kernel boundary once there are hundreds of blocks)
 __global__ __launch_bounds__(kThreads) void k_finish_single(const double* __restrict__ partial,
                                                             const unsigned* __restrict__ pflags, int nbx, double slot_lg,
-                                                            double* __restrict__ out, int32_t* __restrict__ status) {
+                                                            double* __restrict__ out, int32_t* __restrict__ status,
+                                                            unsigned long long* done, unsigned long long seq) {
     __shared__ double sh[kThreads / 64];
     __shared__ unsigned shf[kThreads / 64];
     double s = 0.0;
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(kThreads) void k_finish_single(const double* __rest
         for (int w = 1; w < kThreads / 64; ++w) { t += sh[w]; ff |= shf[w]; }
         *out = t - slot_lg;
         *status = (int32_t)ff;
+        __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -69,6 +69,8 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     d.counter = (unsigned*)c->slot_counter.p;
     d.out = (double*)res;
     d.status = (int32_t*)(res + 8);
+    d.done = (unsigned long long*)(res + 16);
+    d.seq = ++c->slot_seq;
     LaunchArgs a{};
     a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
     a.nm = (const double*)c->nm.p;
@@ -96,9 +98,23 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     }
     if (!fuse)
         hipLaunchKernelGGL(k_finish_single, dim3(1), block, 0, c->stream, (const double*)a.partial, (const unsigned*)a.pflags,
-                           nbx, d.slot_lg, d.out, d.status);
+                           nbx, d.slot_lg, d.out, d.status, d.done, d.seq);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // The finishing thread stores {ll, status} and then, with a system-scope release, the call's sequence number
+    // into pinned host memory: poll that word instead of paying the runtime's stream-synchronise latency.  Falls back
+    // to the stream sync (which also reports a faulted kernel) if the word does not arrive in time.
+    bool arrived = false;
+    if (c->poll_result && !c->profiling) {
+        const volatile unsigned long long* done = (const volatile unsigned long long*)(res + 16);
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        for (unsigned spin = 0; !(arrived = (*done == d.seq)); ++spin) {
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    // (every 256th call synchronises anyway, so the runtime retires its completed commands at a steady pace)
+    if (!arrived || (d.seq & 255ull) == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
     *out = *(double*)res;
     if (status) *status = *(int32_t*)(res + 8);
     return BI_OK;
