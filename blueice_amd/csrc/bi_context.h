@@ -17,6 +17,7 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     struct ::bi_ctx* owner = nullptr;  // context whose recycle cache takes the buffer back on dev_free
+    bool view = false;                 // a window into somebody else's allocation: dev_free only forgets it
 };
 
 }  // namespace
@@ -35,6 +36,8 @@ struct bi_plan {
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
+    DevBuf slab;                  // transient small plans: every descriptor array is a view into this one buffer
+    bool host_results = false;    // ... and out / status are views into the context's pinned block
     bool use_scan = false;        // evaluated by the matrix-core scan kernel (groups of items per cell)
     int64_t n_groups = 0;
     int scan_cb = 4;              // its strip width in 16-bin blocks
@@ -96,6 +99,9 @@ struct bi_ctx {
 
     // persistent single-point slot (the lf(**kw) call shape): no allocation, one H2D, one D2H per call
     DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
+    void* pack_host = nullptr;  // pinned staging of packed_upload (small-batch descriptors in, results out)
+    size_t pack_host_bytes = 0;
+    DevBuf pack_dev;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
     unsigned long long slot_seq = 0;  // sequence number of single-point calls (the kernel echoes it when done)
@@ -166,7 +172,7 @@ constexpr size_t kCacheMaxTotal = (size_t)1 << 30;    // at most 1 GiB parked
 constexpr size_t kCacheMaxEntries = 256;
 
 void dev_free(DevBuf& b) {
-    if (b.p) {
+    if (b.p && !b.view) {
         bi_ctx* c = b.owner;
         if (c && b.bytes <= kCacheMaxBuf && c->cache.size() < kCacheMaxEntries && c->cache_bytes + b.bytes <= kCacheMaxTotal) {
             c->cache.push_back(b);
@@ -177,6 +183,7 @@ void dev_free(DevBuf& b) {
     }
     b.p = nullptr;
     b.bytes = 0;
+    b.view = false;
 }
 
 int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
@@ -222,12 +229,56 @@ int dev_upload(bi_ctx* c, DevBuf& b, const std::vector<T>& h) {
     return BI_OK;
 }
 
+// Several small host arrays -> the device with ONE copy: they are laid out back to back (64-byte aligned) in the
+// context's pinned staging block and moved with a single hipMemcpyAsync into one device slab.  `out_bytes` more
+// bytes of the pinned block are reserved behind them for results a kernel writes straight to host memory.
+// Sub-pointers: dev(i), host_out().  The block is owned by the context and reused by the next call, so the caller
+// synchronises the stream before returning.
+struct PackedUpload {
+    std::vector<size_t> off;
+    size_t in_bytes = 0, out_off = 0;
+    char* dev_base = nullptr;
+    char* host_base = nullptr;
+    template <typename T>
+    const T* dev(size_t i) const { return reinterpret_cast<const T*>(dev_base + off[i]); }
+    void* host_out() const { return host_base + out_off; }
+};
+
+inline int packed_upload(bi_ctx* c, const std::vector<std::pair<const void*, size_t>>& parts, size_t out_bytes, PackedUpload& pu,
+                         DevBuf* slab = nullptr) {   // slab: a caller-owned device buffer instead of the context's
+    pu.off.clear();
+    size_t total = 0;
+    for (const auto& part : parts) {
+        pu.off.push_back(total);
+        total += (part.second + 63) / 64 * 64;
+    }
+    pu.in_bytes = total;
+    pu.out_off = total;
+    const size_t need = total + (out_bytes + 63) / 64 * 64 + 64;
+    if (c->pack_host_bytes < need) {
+        if (c->pack_host) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(c->pack_host)); c->pack_host = nullptr; c->pack_host_bytes = 0; }
+        const size_t grow = std::max<size_t>(2 * need, 65536);
+        HIP_TRY(c, hipHostMalloc(&c->pack_host, grow, hipHostMallocDefault));
+        c->pack_host_bytes = grow;
+    }
+    DevBuf& dst = slab ? *slab : c->pack_dev;
+    int rc = dev_alloc(c, dst, std::max<size_t>(total, 64));
+    if (rc) return rc;
+    pu.host_base = (char*)c->pack_host;
+    pu.dev_base = (char*)dst.p;
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (parts[i].second) memcpy(pu.host_base + pu.off[i], parts[i].first, parts[i].second);
+    if (total) HIP_TRY(c, hipMemcpyAsync(pu.dev_base, pu.host_base, total, hipMemcpyHostToDevice, c->stream));
+    return BI_OK;
+}
+
 void free_plan_buffers(bi_plan* p) {
     for (auto& k : p->classes) {
         dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
     }
     dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
+    dev_free(p->slab);
 }
 
 }  // namespace

@@ -30,7 +30,10 @@ constexpr int kClassG[5] = {1, 2, 4, 8, 16};
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
                        bi_plan** out);
 
-int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bi_plan** out) {
+// transient: the plan is run once and destroyed inside the calling entry point (bi_eval); small ones then travel in
+// one packed copy and deliver their results to pinned host memory.
+int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bi_plan** out,
+                bool transient = false) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!out) return fail(c, BI_ERR_INVALID, "out is NULL");
@@ -206,6 +209,14 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     const int n_tiles = n_tiles_of(c);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int64_t total_items = (int64_t)items.size();
+    size_t small_bytes = (size_t)P * 16 + bad.size() * 8;
+    for (int ci = 0; ci < 5; ++ci) {
+        const HostClass& h = hc[ci];
+        small_bytes += h.rowoff.size() * 8 + h.coef.size() * 8 + h.aux.size() * 8 + h.cnt_off.size() * 8 + h.tiles.size() * 4 +
+                       h.perm.size() * 8 + h.slot_lg.size() * 8 + 7 * 64;
+    }
+    const bool packed = transient && small_bytes <= (size_t)256 * 1024;
+    std::vector<std::pair<const void*, size_t>> parts;
     for (int ci = 0; ci < 5; ++ci) {
         HostClass& h = hc[ci];
         if (h.tiles.empty()) continue;
@@ -221,17 +232,56 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         // them in that XCD's L2 instead of each XCD fetching every tile (speed only, never correctness).
         if (c->xcd_affine && total_items > 1 && nbx > 4 && nbx < max_tiles) nbx = std::min<int64_t>(max_tiles, (nbx + 7) / 8 * 8);
         k.nbx = (int)nbx;
-        if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
-            (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_cnt, h.cnt_off)) ||
-            (rc = dev_upload(c, k.item_tiles, h.tiles)) || (rc = dev_upload(c, k.perm, h.perm)) ||
-            (rc = dev_upload(c, k.slot_lg, h.slot_lg)) ||
-            (rc = dev_alloc(c, k.partial, (size_t)k.n_items * k.nbx * k.G * sizeof(double))) ||
+        if (packed) {
+            parts.push_back({h.rowoff.data(), h.rowoff.size() * sizeof(int64_t)});
+            parts.push_back({h.coef.data(), h.coef.size() * sizeof(double)});
+            parts.push_back({h.aux.data(), h.aux.size() * sizeof(double)});
+            parts.push_back({h.cnt_off.data(), h.cnt_off.size() * sizeof(int64_t)});
+            parts.push_back({h.tiles.data(), h.tiles.size() * sizeof(int32_t)});
+            parts.push_back({h.perm.data(), h.perm.size() * sizeof(int64_t)});
+            parts.push_back({h.slot_lg.data(), h.slot_lg.size() * sizeof(double)});
+        } else if ((rc = dev_upload(c, k.rowoff, h.rowoff)) || (rc = dev_upload(c, k.coef, h.coef)) ||
+                   (rc = dev_upload(c, k.aux, h.aux)) || (rc = dev_upload(c, k.item_cnt, h.cnt_off)) ||
+                   (rc = dev_upload(c, k.item_tiles, h.tiles)) || (rc = dev_upload(c, k.perm, h.perm)) ||
+                   (rc = dev_upload(c, k.slot_lg, h.slot_lg)))
+            return abort_plan(rc);
+        if ((rc = dev_alloc(c, k.partial, (size_t)k.n_items * k.nbx * k.G * sizeof(double))) ||
             (rc = dev_alloc(c, k.pflags, (size_t)k.n_items * k.nbx * k.G * sizeof(unsigned))))
             return abort_plan(rc);
         for (int32_t t : h.tiles) plan->bytes += (int64_t)sizeof(double) * ((int64_t)NS + 1) * (sparse ? (int64_t)t * kTile : c->B);
         plan->launches += (k.n_items + 65534) / 65535;
     }
     plan->n_bad = (int64_t)bad.size();
+    if (packed) {
+        // one copy for every descriptor array; out and status live in the pinned block behind them, where the finish
+        // kernel writes them directly (the caller reads them there after its stream sync)
+        parts.push_back({bad.data(), bad.size() * sizeof(int64_t)});
+        const size_t out_bytes = ((size_t)std::max<int64_t>(P, 1) * sizeof(double) + 63) / 64 * 64;
+        PackedUpload pu;
+        if ((rc = packed_upload(c, parts, out_bytes + (size_t)std::max<int64_t>(P, 1) * sizeof(int32_t), pu, &plan->slab)))
+            return abort_plan(rc);
+        auto view = [&](DevBuf& b, size_t part) {
+            b.p = pu.dev_base + pu.off[part];
+            b.bytes = parts[part].second;
+            b.view = true;
+        };
+        size_t part = 0;
+        for (auto& k : plan->classes) {
+            view(k.rowoff, part++); view(k.coef, part++); view(k.aux, part++); view(k.item_cnt, part++);
+            view(k.item_tiles, part++); view(k.perm, part++); view(k.slot_lg, part++);
+        }
+        view(plan->bad_idx, part);
+        plan->host_results = true;
+        plan->out.p = pu.host_out();
+        plan->out.bytes = out_bytes;
+        plan->out.view = true;
+        plan->status.p = (char*)pu.host_out() + out_bytes;
+        plan->status.bytes = (size_t)std::max<int64_t>(P, 1) * sizeof(int32_t);
+        plan->status.view = true;
+        if (P) memcpy(plan->status.p, plan->h_status.data(), (size_t)P * sizeof(int32_t));
+        *out = plan;
+        return BI_OK;
+    }
     if ((rc = dev_upload(c, plan->bad_idx, bad)) || (rc = dev_alloc(c, plan->out, (size_t)std::max<int64_t>(P, 1) * sizeof(double))) ||
         (rc = dev_upload(c, plan->status, plan->h_status)))
         return abort_plan(rc);

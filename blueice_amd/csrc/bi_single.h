@@ -66,6 +66,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     char* res = (char*)c->slot_host;
     *(double*)res = 0.0;
     *(int64_t*)(res + 8) = 0;
+    *(unsigned long long*)(res + 16) = 0ull;
     d.counter = (unsigned*)c->slot_counter.p;
     d.out = (double*)res;
     d.status = (int32_t*)(res + 8);

@@ -114,6 +114,8 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
+    if (c->pack_host) (void)hipHostFree(c->pack_host);
+    dev_free(c->pack_dev);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
     dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz);
@@ -564,10 +566,19 @@ int bi_eval(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, con
         return eval_single(c, z, rate_scale, dataset ? dataset[0] : 0, out, status);
     }
     bi_plan* plan = nullptr;
-    int rc = bi_plan_points(c, P, z, rate_scale, dataset, &plan);
+    int rc = plan_points(c, P, z, rate_scale, dataset, &plan, /*transient=*/true);
     if (rc) return rc;
     rc = bi_run_plan(c, plan, nullptr);
-    if (!rc) rc = bi_plan_read(c, plan, out, status);
+    if (!rc && plan->host_results) {   // small batch: the finish kernel wrote out / status into pinned host memory
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, BI_ERR_HIP, "bi_eval: %s", hipGetErrorString(e));
+        if (!rc && P) {
+            memcpy(out, plan->out.p, (size_t)P * sizeof(double));
+            if (status) memcpy(status, plan->status.p, (size_t)P * sizeof(int32_t));
+        }
+    } else if (!rc) {
+        rc = bi_plan_read(c, plan, out, status);
+    }
     bi_plan_destroy(c, plan);
     return rc;
 }
@@ -676,29 +687,33 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     if (n_items == 0) return BI_OK;
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int nbx = (int)std::min<int64_t>(max_tiles, n_items == 1 ? slots : std::max<int64_t>(1, (4 * slots + n_items - 1) / n_items));
-    DevBuf d_row, d_coef, d_cnt, d_tiles, d_perm, d_lg, d_part, d_flag, d_out;
-    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_tiles); dev_free(d_perm);
-                           dev_free(d_lg); dev_free(d_part); dev_free(d_flag); dev_free(d_out); };
-    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) || (rc = dev_upload(c, d_cnt, cnt_off)) ||
-        (rc = dev_upload(c, d_tiles, tiles)) || (rc = dev_upload(c, d_perm, perm)) || (rc = dev_upload(c, d_lg, slot_lg)) ||
+    // descriptors: one packed copy; results: k_finish writes them straight into pinned host memory
+    DevBuf d_part, d_flag;
+    auto cleanup = [&]() { dev_free(d_part); dev_free(d_flag); };
+    PackedUpload pu;
+    const size_t out_bytes = (size_t)n_items * W * sizeof(double);
+    if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)},
+                                {cnt_off.data(), cnt_off.size() * sizeof(int64_t)}, {tiles.data(), tiles.size() * sizeof(int32_t)},
+                                {perm.data(), perm.size() * sizeof(int64_t)}, {slot_lg.data(), slot_lg.size() * sizeof(double)}},
+                            out_bytes, pu)) ||
         (rc = dev_alloc(c, d_part, (size_t)n_items * nbx * G * sizeof(double))) ||
-        (rc = dev_alloc(c, d_flag, (size_t)n_items * nbx * G * sizeof(unsigned))) ||
-        (rc = dev_alloc(c, d_out, (size_t)n_items * W * sizeof(double)))) {
+        (rc = dev_alloc(c, d_flag, (size_t)n_items * nbx * G * sizeof(unsigned)))) {
         cleanup();
         return rc;
     }
+    double* h_out = (double*)pu.host_out();
     LaunchArgs a{};
     a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
     a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
-    a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = max_tiles;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = max_tiles; a.chunks = (int)c->tile_chunks;
     const bool nt = !sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && n_items == 1));
     for (int64_t i0 = 0; i0 < n_items; i0 += 65535) {
         const int64_t ni = std::min<int64_t>(65535, n_items - i0);
         LaunchArgs b = a;
-        b.rowoff = (const int64_t*)d_row.p + i0 * NS;
-        b.coef = (const double*)d_coef.p + i0 * NS * G;
-        b.item_cnt = (const int64_t*)d_cnt.p + i0;
-        b.item_tiles = (const int32_t*)d_tiles.p + i0;
+        b.rowoff = pu.dev<int64_t>(0) + i0 * NS;
+        b.coef = pu.dev<double>(1) + i0 * NS * G;
+        b.item_cnt = pu.dev<int64_t>(2) + i0;
+        b.item_tiles = pu.dev<int32_t>(3) + i0;
         b.partial = (double*)d_part.p + i0 * nbx * G;
         b.pflags = (unsigned*)d_flag.p + i0 * nbx * G;
         launch_morph_grad(c, G, b, dim3((unsigned)nbx, (unsigned)ni), nt);
@@ -707,12 +722,9 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
         const int per_block = kThreads / lanes;
         hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
                            (const double*)b.partial, (const unsigned*)b.pflags, nbx, G, lanes, n_slots,
-                           (const int64_t*)d_perm.p + i0 * G, (const double*)d_lg.p + i0 * G, (double*)d_out.p,
-                           (int32_t*)nullptr);
+                           pu.dev<int64_t>(4) + i0 * G, pu.dev<double>(5) + i0 * G, h_out, (int32_t*)nullptr);
     }
-    std::vector<double> h_out((size_t)n_items * W);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_grad: %s", hipGetErrorString(e));
