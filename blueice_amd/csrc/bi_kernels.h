@@ -1042,17 +1042,30 @@ __global__ __launch_bounds__(kThreads) void k_dataset_dot(const double* __restri
     }
 }
 
-// out[t] = sum_blocks partial[t][:] - summu - lgsum[t0 + t]   (nan if any mu invalid)
-__global__ void k_dataset_finish(const double* __restrict__ partial, int nbx, const double* __restrict__ mu_partial,
-                                 const unsigned* __restrict__ mu_flags, int nmu, const double* __restrict__ lgsum,
-                                 int64_t t0, int64_t n, double* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// out[t] = sum_blocks partial[t][:] - summu - lgsum[t0 + t]   (nan if any mu invalid).  256 threads per block: the
+// block first sums the mu partials of pass 1 together (fixed tree), then every thread finishes one dataset.
+__global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __restrict__ partial, int nbx,
+                                                             const double* __restrict__ mu_partial,
+                                                             const unsigned* __restrict__ mu_flags, int nmu,
+                                                             const double* __restrict__ lgsum, int64_t t0, int64_t n,
+                                                             double* __restrict__ out) {
+    __shared__ double sh[kThreads / 64];
+    __shared__ unsigned shf[kThreads / 64];
+    double m = 0.0;
+    unsigned f = 0u;
+    for (int b = threadIdx.x; b < nmu; b += kThreads) { m += mu_partial[b]; f |= mu_flags[b]; }
+    m = wave_sum(m);
+    f = wave_or(f);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = m; shf[threadIdx.x >> 6] = f; }
+    __syncthreads();
+    m = sh[0];
+    f = shf[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) { m += sh[w]; f |= shf[w]; }
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (t >= n) return;
     double s = 0.0;
     for (int b = 0; b < nbx; ++b) s += partial[t * nbx + b];
-    double m = 0.0;
-    unsigned f = 0u;
-    for (int b = 0; b < nmu; ++b) { m += mu_partial[b]; f |= mu_flags[b]; }
     double r = (s - m) - lgsum[t0 + t];
     if (f) r = __builtin_nan("");
     out[t] = r;

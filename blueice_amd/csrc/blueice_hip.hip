@@ -779,24 +779,29 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int n_tiles = n_tiles_of(c);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int nmu = (int)std::min<int64_t>(n_tiles, slots);
-    DevBuf d_row, d_coef, d_out;
-    auto cleanup = [&]() { dev_free(d_row); dev_free(d_coef); dev_free(d_out); };
+    DevBuf d_out;
+    auto cleanup = [&]() { dev_free(d_out); };
     const bool csr = (c->sparse && c->csr_ready) || !c->dense_counts;
     if (csr && !c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
     const int64_t chunk = csr ? 1048576 : 16384;
     const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
-    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_coef, coef)) ||
+    // descriptors in one packed copy; up to 4 MB of results are written straight into pinned host memory
+    const bool host_out = (size_t)n * sizeof(double) <= ((size_t)4 << 20);
+    PackedUpload pu;
+    if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)}},
+                            host_out ? (size_t)n * sizeof(double) : 0, pu)) ||
         (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
         (rc = dev_alloc(c, c->scratch2, (size_t)std::min(n, chunk) * nbx * sizeof(double))) ||
-        (rc = dev_alloc(c, d_out, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) {
+        (!host_out && (rc = dev_alloc(c, d_out, (size_t)std::max<int64_t>(n, 1) * sizeof(double))))) {
         cleanup();
         return rc;
     }
+    double* res = host_out ? (double*)pu.host_out() : (double*)d_out.p;
     LaunchArgs a{};
     a.ps = (const double*)c->ps.p;
-    a.rowoff = (const int64_t*)d_row.p;
-    a.coef = (const double*)d_coef.p;
+    a.rowoff = pu.dev<int64_t>(0);
+    a.coef = pu.dev<double>(1);
     a.partial = (double*)c->scratch.p;
     a.pflags = (unsigned*)((char*)c->scratch.p + (((size_t)nmu * sizeof(double) + 63) / 64) * 64);
     a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles;
@@ -819,11 +824,12 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
         }
         hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
                            (const double*)c->scratch2.p, nbx, (const double*)a.partial, (const unsigned*)a.pflags, nmu,
-                           (const double*)c->lgsum.p, t0 + s0, ni, (double*)d_out.p + s0);
+                           (const double*)c->lgsum.p, t0 + s0, ni, res + s0);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && n) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && n && !host_out) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n && host_out) memcpy(out, res, (size_t)n * sizeof(double));
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets: %s", hipGetErrorString(e));
     return BI_OK;
