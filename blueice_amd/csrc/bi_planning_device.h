@@ -145,12 +145,16 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
     int k = 0;
     for (int corner = 0; corner < m.nc; ++corner) {
         const int64_t a = cell + m.corner_off[corner];
-        for (int s = 0; s < m.S; ++s, ++k) {
-            const double cf = w[corner] * r[s];
-            coef[(item * NS + k) * kDevG + g] = cf;
-            if (m.sparse) zsum += cf * m.Tz[ds * m.n_rows + a * m.S + s];
-            if (g == 0) rowoff[item * NS + k] = row_base + (a * m.S + s) * row_stride;
+        const double wc = w[corner];
+#pragma unroll 4
+        for (int s = 0; s < m.S; ++s) {                     // (unrolled: the Tz loads of a corner go out together)
+            const double cf = wc * r[s];
+            const double tz = m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0;
+            coef[(item * NS + k + s) * kDevG + g] = cf;
+            if (m.sparse) zsum += cf * tz;
+            if (g == 0) rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
         }
+        k += m.S;
     }
     for (int s = 0; s < m.S; ++s) rsum += r[s];
     if (g == 0) {
