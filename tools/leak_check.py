@@ -1,0 +1,30 @@
+"""Create / use / destroy many contexts and plans; device memory in use must return to where it started."""
+import sys, ctypes
+import numpy as np
+sys.path.insert(0, '.')
+from blueice_amd.device import DeviceContext
+from blueice_amd.synthetic import SyntheticModel
+hip = ctypes.CDLL('libamdhip64.so')
+def free_mem():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t))
+    return f.value
+m = SyntheticModel.named('mini3')
+ctx = DeviceContext(0); ctx.close()
+start = free_mem()
+for it in range(300):
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.upload_counts(np.stack([m.counts(dataset=i) for i in range(3)]))
+    z, r = m.random_points(700, seed=it)
+    ctx.eval(z, r)
+    ctx.eval(z[:3], r[:3])
+    ctx.eval(z[0], r[0])
+    ctx.eval_grad(z[:2], r[:2])
+    ctx.eval_datasets(z[0], r[0])
+    p = ctx.plan(z, r); p.run(); p.read(); p.close()
+    ctx.generate_toys(z[0], r[0], 5, seed=it)
+    ctx.eval_datasets(z[1], r[1])
+    ctx.close()
+    if it % 100 == 99:
+        print('after %d contexts: free device memory changed by %+d KB' % (it + 1, (free_mem() - start) // 1024), flush=True)
