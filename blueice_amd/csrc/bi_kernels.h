@@ -1077,14 +1077,16 @@ namespace {
 
 // ---- the scan kernel: many points per grid cell, fp64 matrix cores ---------------------------------------
 // For a batch whose points pile up in few grid cells (likelihood scans), mu[point][bin] = sum_k coef[point][k] *
-// row[k][bin] is a [points x streams] x [streams x bins] product.  One wave owns a 64-bin strip of the cell's
+// row[k][bin] is a [points x streams] x [streams x bins] product.  One wave owns a strip of 16 CB bins of the cell's
 // 2^d*S template rows, holds it in registers in v_mfma_f64_16x16x4 B-operand layout (k = lane >> 4,
 // bin = lane & 15; loaded once, every 128-byte cache line fully used) and loops over ALL 16-point work items of
-// the cell: per item 8 coalesced A-operand loads (coef[k][point], point = lane & 15) and, for the 4 column blocks
-// of the strip, K/4 MFMAs each.  The Poisson epilogue runs on the VALU while the matrix pipe works on the next
-// block; a 16-lane row reduction leaves the 16 per-point sums in 4 lanes, which add them (no-return fp64
-// atomics) into a partial slot that only this wave ever touches, so the result is deterministic.
-// Rate: 78.6 TFLOP/s fp64 matrix peak / (2 * 2^d*S * B flop per evaluation) = 1.2 M evaluations/s at C2.
+// the cell: per item KG coalesced A-operand loads (coef[k][point], point = lane & 15) and, for the CB column blocks
+// of the strip, KG MFMAs each; the Poisson epilogue of a block is issued behind the next block's MFMA chain.  A 16-lane
+// row reduction leaves the 16 per-point sums in 4 lanes, which add them (no-return fp64 atomics) into a partial slot
+// that only this wave ever touches, so the result is deterministic.
+// Bound: 78.6 TFLOP/s fp64 matrix peak / (2 * 2^d*S * B flop per evaluation) = 1.2 M evaluations/s at C2 for the
+// FMA work alone; fp64 MFMA and fp64 VALU share the same units on this chip (measured: tools/micro/
+// mfma_valu_overlap.hip), so the epilogue's logarithms add to that rather than hide under it.
 // Plain binned likelihood, up to 32 streams (K <= 32); everything else takes k_morph_reduce.
 typedef double bi_double4 __attribute__((ext_vector_type(4)));
 
