@@ -55,6 +55,8 @@ SIGNATURES = {
     'bi_plan_destroy': (None, [_p, _p]),
     'bi_sync': (C.c_int, [_p]),
     'bi_stream': (_p, [_p]),
+    'bi_eval_begin': (C.c_int, [_p, _p, _p, _i64]),
+    'bi_eval_end': (C.c_int, [_p, _p, _p]),
     'bi_selftest_log': (C.c_int, [_p, _i64, _p, _p]),
     'bi_measure_read_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p]),
     'bi_profile_enable': (C.c_int, [_p, C.c_int]),

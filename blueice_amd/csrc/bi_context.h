@@ -105,6 +105,10 @@ struct bi_ctx {
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
     unsigned long long slot_seq = 0;  // sequence number of single-point calls (the kernel echoes it when done)
+    int pending = 0;                  // bi_eval_begin without its bi_eval_end: 1 = launch in flight, 2 = answer parked
+    unsigned long long pending_seq = 0;
+    double pending_ll = 0.0;
+    int32_t pending_status = 0;
 
     // device mirrors of the small tables the planning kernels read (bi_planning_device.h)
     DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz;

@@ -66,6 +66,7 @@ void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, b
 
 int check_ready(bi_ctx* c, bool need_data) {
     if (!c) return BI_ERR_INVALID;
+    if (c->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding on this context: call bi_eval_end first");
     if (!c->model_ready) return fail(c, BI_ERR_STATE, "no model uploaded (prepare() first)");
     if (need_data && !c->data_ready) return fail(c, BI_ERR_STATE, "no data uploaded (set_data() first)");
     return BI_OK;

@@ -6,7 +6,32 @@ namespace {
 
 // The fused form: descriptors in the kernel arguments, reduction finished inside the launch, result written
 // to pinned host memory -- one launch and one stream sync per call.
-int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_t ds, bool sparse, double* out, int32_t* status) {
+// Wait for the single-point launch with sequence number `seq` and fetch {ll, status} from the pinned block.
+// The finishing thread stores them and then, with a system-scope release, the sequence number: poll that word
+// instead of paying the runtime's stream-synchronise latency.  Falls back to the stream sync (which also reports a
+// faulted kernel) if the word does not arrive in time; every 256th call synchronises anyway, so the runtime retires
+// its completed commands at a steady pace.
+int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status) {
+    char* res = (char*)c->slot_host;
+    bool arrived = false;
+    if (c->poll_result && !c->profiling) {
+        const volatile unsigned long long* done = (const volatile unsigned long long*)(res + 16);
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        for (unsigned spin = 0; !(arrived = (*done == seq)); ++spin) {
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived || (seq & 255ull) == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = *(double*)res;
+    if (status) *status = *(int32_t*)(res + 8);
+    return BI_OK;
+}
+
+// wait = false (bi_eval_begin): return right after the launch; bi_eval_end collects the result with single_wait.
+int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_t ds, bool sparse, double* out, int32_t* status,
+                      bool wait = true) {
     const int S = c->S;
     const bool bb = c->bb_source >= 0;
     const int nc = (int)g.w.size();
@@ -101,30 +126,27 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
         hipLaunchKernelGGL(k_finish_single, dim3(1), block, 0, c->stream, (const double*)a.partial, (const unsigned*)a.pflags,
                            nbx, d.slot_lg, d.out, d.status, d.done, d.seq);
     HIP_TRY(c, hipGetLastError());
-    // The finishing thread stores {ll, status} and then, with a system-scope release, the call's sequence number
-    // into pinned host memory: poll that word instead of paying the runtime's stream-synchronise latency.  Falls back
-    // to the stream sync (which also reports a faulted kernel) if the word does not arrive in time.
-    bool arrived = false;
-    if (c->poll_result && !c->profiling) {
-        const volatile unsigned long long* done = (const volatile unsigned long long*)(res + 16);
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
-        for (unsigned spin = 0; !(arrived = (*done == d.seq)); ++spin) {
-            __builtin_ia32_pause();
-            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+    if (!wait) {
+        c->pending = 1;
+        c->pending_seq = d.seq;
+        return BI_OK;
     }
-    // (every 256th call synchronises anyway, so the runtime retires its completed commands at a steady pace)
-    if (!arrived || (d.seq & 255ull) == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *out = *(double*)res;
-    if (status) *status = *(int32_t*)(res + 8);
-    return BI_OK;
+    return single_wait(c, d.seq, out, status);
 }
 
 // One point, synchronous: the call shape of `lf(**kwargs)` inside a minimizer (inference.py:111-122 makes
 // ~500 of them per fit).  Same kernels as the batched path, but the descriptors live in a persistent
 // device slot fed from pinned memory: one small H2D, two launches, one 16-byte D2H, one sync.
-int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds, double* out, int32_t* status) {
+// wait = false: launch only (bi_eval_begin).  Answers that need no launch -- and the rare fallback path, which then
+// runs synchronously -- are parked in the context (pending = 2) for bi_eval_end.
+int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds, double* out, int32_t* status, bool wait = true) {
+    double parked_ll = 0.0;
+    int32_t parked_st = 0;
+    if (!wait) { out = &parked_ll; status = &parked_st; c->pending = 2; }
+    struct Park {   // on every return path of a launch-less answer: keep it for bi_eval_end
+        bi_ctx* c; const bool on; double* ll; int32_t* st;
+        ~Park() { if (on && c->pending == 2) { c->pending_ll = *ll; c->pending_status = *st; } }
+    } park{c, !wait, &parked_ll, &parked_st};
     const int S = c->S;
     const double ninf = -std::numeric_limits<double>::infinity();
     if (ds < 0 || ds >= c->T) { *out = ninf; if (status) *status = BI_ST_BAD_DATASET; return BI_OK; }
@@ -151,7 +173,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int nbx = (int)std::min<int64_t>(tiles, slots);
 
-    if (NS <= kMaxSingleStreams && c->single_kernel) return eval_single_fused(c, g, rates, ds, sparse, out, status);
+    if (NS <= kMaxSingleStreams && c->single_kernel) return eval_single_fused(c, g, rates, ds, sparse, out, status, wait);
 
     // general fallback (more streams than fit the kernel-argument block):
     // slot layout (8-byte units): rowoff[NS] coef[NS] aux[2] cnt_off tiles perm slot_lg | result {ll, status}

@@ -586,6 +586,35 @@ int bi_eval(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, con
 
 // ---- value + analytic gradient in one pass ----------------------------------------------------
 
+// The two halves of bi_eval(P = 1), for callers that evaluate several contexts at once (a sum of likelihoods, one
+// context per term): begin on every context, then end on every context -- the launches overlap.
+int bi_eval_begin(bi_ctx* c, const double* z, const double* rate_scale, int64_t dataset) {
+    if (!c) return BI_ERR_INVALID;
+    if (c->pending) return fail(c, BI_ERR_STATE, "bi_eval_begin: the previous bi_eval_begin has not been collected with bi_eval_end");
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (c->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = eval_single(c, z, rate_scale, dataset, nullptr, nullptr, /*wait=*/false);
+    if (rc) c->pending = 0;
+    return rc;
+}
+
+int bi_eval_end(bi_ctx* c, double* out, int32_t* status) {
+    if (!c || !out) return BI_ERR_INVALID;
+    if (!c->pending) return fail(c, BI_ERR_STATE, "bi_eval_end without bi_eval_begin");
+    const int kind = c->pending;
+    c->pending = 0;
+    if (kind == 2) {
+        *out = c->pending_ll;
+        if (status) *status = c->pending_status;
+        return BI_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (status) *status = 0;
+    return single_wait(c, c->pending_seq, out, status);
+}
+
 int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
                  double* grad, int32_t* status) {
     int rc = check_ready(c, true);

@@ -208,6 +208,21 @@ class DeviceContext:
         self._check(self._lib.bi_eval(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), ptr(out), ptr(status)))
         return out, status
 
+    def eval_begin(self, z, rate_scale=None, dataset=0):
+        """First half of a one-point eval: launch and return.  Collect with eval_end(); in between, evaluate other
+        contexts (a sum of likelihoods overlaps its terms this way)."""
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        self._check(self._lib.bi_eval_begin(self._h, ptr(z), ptr(rate_scale), int(dataset)))
+
+    def eval_end(self):
+        """-> (ll, status) of the evaluation started by eval_begin()."""
+        out = C.c_double()
+        status = C.c_int32()
+        self._check(self._lib.bi_eval_end(self._h, C.byref(out), C.byref(status)))
+        return out.value, status.value
+
     def eval_grad(self, z, rate_scale=None, dataset=None):
         """Value and analytic gradient in one pass -> (ll [P], dll/dz [P, d], dll/drate_scale [P, S], status)."""
         P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)

@@ -292,12 +292,30 @@ class DeviceLogLikelihood(LogLikelihoodBase):
                 return ll
             return prior + ll, mus, ps.reshape((len(mus),) + tuple(self.bin_shape))
         ll, st = self.ctx.eval(zs if len(zs) else None, scale[None, :])
-        st = int(st[0])
+        return self._finish_call(prior, zs, scale, float(ll[0]), int(st[0]))
+
+    def _finish_call(self, prior, zs, scale, ll, st):
         if st:
             hint = self.ctx.interpolate('mus', zs) * scale if st & _capi.ST_UNPHYSICAL else None
-            ll0 = self._interpret(float(ll[0]), st, hint)
+            ll0 = self._interpret(ll, st, hint)
             return ll0 if ll0 == -float('inf') else prior + ll0
-        return prior + float(ll[0])
+        return prior + ll
+
+    # The plain call in two halves, for LogLikelihoodSum: begin() on every term, then end() on every term, so the
+    # device work of the terms (one context each) overlaps.
+    @_needs_data
+    def _call_begin(self, livetime_days=None, **kwargs):
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is not None:
+            self.ctx.eval_begin(zs if len(zs) else None, scale)
+        return prior, zs, scale
+
+    def _call_end(self, token):
+        prior, zs, scale = token
+        if prior is None:
+            return -float('inf')
+        ll, st = self.ctx.eval_end()
+        return self._finish_call(prior, zs, scale, ll, st)
 
     def _call_with_fresh_pdf(self, livetime_days, full_output, kwargs):
         """compute_pdf=True: build the model AT the requested settings instead of morphing
@@ -586,12 +604,32 @@ class LogLikelihoodSum:
             self.likelihood_parameters.append(names)
 
     def __call__(self, compute_pdf=False, livetime_days=None, **kwargs):
+        terms = list(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights))
+        lts = [livetime_days[i] if isinstance(livetime_days, list) else livetime_days for i in range(len(terms))]
+        kws = [{k: v for k, v in kwargs.items() if k in names} for _, names, _ in terms]
         total = 0.
-        for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters,
-                                                    self.likelihood_weights)):
-            lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
-            total += weight * ll(compute_pdf=compute_pdf, livetime_days=lt,
-                                 **{k: v for k, v in kwargs.items() if k in names})
+        if not compute_pdf and all(hasattr(ll, '_call_begin') for ll, _, _ in terms) and \
+                len({id(getattr(ll, 'ctx', None)) for ll, _, _ in terms}) == len(terms):
+            # every term is a device likelihood with its own context: launch them all, then collect them all
+            tokens = []
+            try:
+                for (ll, _, _), lt, kw in zip(terms, lts, kws):
+                    tokens.append(ll._call_begin(livetime_days=lt, **kw))
+            finally:                                  # whatever was launched is collected, also on an error
+                results = []
+                for (ll, _, _), token in zip(terms, tokens):
+                    try:
+                        results.append(ll._call_end(token))
+                    except BaseException as err:      # keep collecting; re-raised below
+                        results.append(err)
+            for r in results:
+                if isinstance(r, BaseException):
+                    raise r
+            for (_, _, weight), r in zip(terms, results):
+                total += weight * r
+            return total
+        for (ll, _, weight), lt, kw in zip(terms, lts, kws):
+            total += weight * ll(compute_pdf=compute_pdf, livetime_days=lt, **kw)
         return total
 
     def split_results(self, result_dict):

@@ -142,6 +142,13 @@ int bi_download_counts(bi_ctx* ctx, int64_t t, double* out);
 int bi_eval(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
             double* out, int32_t* status);
 
+/* bi_eval(P = 1) in two halves, for a caller that evaluates several contexts at once -- a sum of likelihoods with
+ * one context per term (LogLikelihoodSum, blueice/likelihood.py:867-955): bi_eval_begin on every context, then
+ * bi_eval_end on every context, and the launches overlap.  One bi_eval_begin may be outstanding per context; any
+ * other call on that context in between is a caller error, except bi_eval_end. */
+int bi_eval_begin(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t dataset);
+int bi_eval_end(bi_ctx* ctx, double* out, int32_t* status);
+
 /* Value and analytic gradient in ONE pass over the templates (no counterpart in the reference, whose
  * fits differentiate `make_objective`'s f numerically: blueice/inference.py:111-124,153-155).
  *   ll   [P]          as bi_eval

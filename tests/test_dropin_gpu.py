@@ -253,3 +253,50 @@ def test_synthetic_model_through_the_plugin_api():
     z = np.array([best['shape0'], 0.2, -0.3])
     r = np.array([best['s0_rate_multiplier'], 1, 1, 1])
     assert abs(ll - orc.loglikelihood(model, counts, z, r)) <= 1e-10 * abs(ll)
+
+
+def test_eval_in_two_halves_and_overlapped_sum():
+    """bi_eval_begin / bi_eval_end: the same numbers as bi_eval, parked answers for rejected points, state errors;
+    a LogLikelihoodSum of device likelihoods (one context per term) launches all terms before collecting any."""
+    from blueice_amd import LogLikelihoodSum
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.exceptions import NotPreparedException as StateError      # what BI_ERR_STATE raises
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.upload_counts(m.counts(dense=True))
+    z, r = m.random_points(20, seed=4)
+    for sparse in (0, 1):
+        ctx.set_param('sparse', sparse)
+        for i in range(len(z)):
+            want, st = ctx.eval(z[i], r[i])
+            ctx.eval_begin(z[i], r[i])
+            got, st2 = ctx.eval_end()
+            assert got == want[0] and st2 == st[0]
+    ctx.eval_begin(np.array([9.0, 0.0, 0.0]), r[0])              # outside the anchor box: nothing is launched
+    assert ctx.eval_end() == (-np.inf, 1)
+    ctx.eval_begin(z[0], -r[0])                                   # unphysical rates
+    assert ctx.eval_end() == (-np.inf, 2)
+    with pytest.raises(StateError):
+        ctx.eval_end()                                            # nothing outstanding
+    ctx.eval_begin(z[0], r[0])
+    with pytest.raises(StateError):
+        ctx.eval_begin(z[1], r[1])                                # one at a time
+    with pytest.raises(StateError):
+        ctx.eval(z[1], r[1])                                      # nor anything else in between
+    ll, _ = ctx.eval_end()
+    assert ll == ctx.eval(z[0], r[0])[0][0]
+    ctx.close()
+
+    terms = [SyntheticModel.named('mini3', seed=s).likelihood() for s in (1, 2, 3)]
+    for s, lf in zip((1, 2, 3), terms):
+        lf.set_binned_data(SyntheticModel.named('mini3', seed=s).counts(dense=True).reshape(m.bins))
+    tot = LogLikelihoodSum(terms, likelihood_weights=[1, 0.5, 2])
+    for kw in (dict(), dict(shape0=0.3, s1_rate_multiplier=1.2), dict(shape1=-0.7, shape2=0.9, s0_rate_multiplier=0.0)):
+        want = sum(w * lf(**kw) for w, lf in zip([1, 0.5, 2], terms))
+        assert tot(**kw) == want
+    assert tot(shape0=5.0) == -np.inf                             # one call outside the box: every term parks -inf
+    with pytest.raises(ValueError):                               # raised by the second half of the terms' host work
+        tot(shape0='not a number')
+    assert tot() == sum(w * lf() for w, lf in zip([1, 0.5, 2], terms))     # ... and nothing was left outstanding
