@@ -632,6 +632,28 @@ class LogLikelihoodSum:
             total += weight * ll(compute_pdf=compute_pdf, livetime_days=lt, **kw)
         return total
 
+    # -- batched / gradient forms (extensions, as on the single likelihoods) -------------------
+    def eval_points(self, points, livetime_days=None):
+        """Weighted sum of the terms' `eval_points` over the same dict of parameter arrays; every term sees the
+        parameters it knows (a term that knows none of them contributes its constant)."""
+        total = 0.
+        for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights)):
+            lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
+            total = total + weight * ll.eval_points({k: v for k, v in points.items() if k in names}, livetime_days=lt)
+        return total
+
+    def value_and_gradient(self, livetime_days=None, **kwargs):
+        """-> (ll, OrderedDict name -> d ll / d parameter): the weighted sum of the terms' values and gradients
+        (one device pass per term); lets `bestfit_scipy(use_gradient=True)` work on a sum."""
+        total, grads = 0., OrderedDict()
+        for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights)):
+            lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
+            v, g = ll.value_and_gradient(livetime_days=lt, **{k: x for k, x in kwargs.items() if k in names})
+            total += weight * v
+            for name, slope in g.items():
+                grads[name] = grads.get(name, 0.) + weight * slope
+        return total, grads
+
     def split_results(self, result_dict):
         return [{k: v for k, v in result_dict.items() if k in names} for names in self.likelihood_parameters]
 

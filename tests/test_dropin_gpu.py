@@ -300,3 +300,34 @@ def test_eval_in_two_halves_and_overlapped_sum():
     with pytest.raises(ValueError):                               # raised by the second half of the terms' host work
         tot(shape0='not a number')
     assert tot() == sum(w * lf() for w, lf in zip([1, 0.5, 2], terms))     # ... and nothing was left outstanding
+
+
+def test_sum_of_likelihoods_batched_and_gradient_forms():
+    """LogLikelihoodSum.eval_points / value_and_gradient = the weighted sums of the terms'; a gradient fit of the
+    sum lands on the plain fit's maximum."""
+    from blueice_amd import LogLikelihoodSum
+    from blueice_amd.synthetic import SyntheticModel
+    terms, weights = [], [1, 0.5]
+    for s in (1, 2):
+        m = SyntheticModel.named('mini3', seed=s)
+        lf = m.likelihood()
+        lf.set_binned_data(m.counts(dense=True).reshape(m.bins))
+        terms.append(lf)
+    tot = LogLikelihoodSum(terms, likelihood_weights=weights)
+    rng = np.random.default_rng(2)
+    pts = dict(shape0=rng.uniform(-1, 1, 50), s0_rate_multiplier=rng.uniform(0.5, 1.5, 50), shape2=0.25)
+    got = tot.eval_points(pts)
+    want = np.array([tot(shape0=a, s0_rate_multiplier=b, shape2=0.25) for a, b in zip(pts['shape0'], pts['s0_rate_multiplier'])])
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    kw = dict(shape0=0.3, shape1=-0.2, s0_rate_multiplier=1.1)
+    v, g = tot.value_and_gradient(**kw)
+    assert abs(v - tot(**kw)) <= 1e-12 * abs(v)
+    for name in ('shape0', 's0_rate_multiplier', 's2_rate_multiplier'):
+        h = 1e-6
+        up = tot(**dict(kw, **{name: kw.get(name, 1.0) + h}))
+        dn = tot(**dict(kw, **{name: kw.get(name, 1.0) - h}))
+        assert abs(g[name] - (up - dn) / (2 * h)) <= 1e-5 * max(1.0, abs(g[name]))
+    fixed = dict(s1_rate_multiplier=1, s2_rate_multiplier=1, s3_rate_multiplier=1, shape1=0.2, shape2=-0.3)
+    best, ll = tot.bestfit_scipy(**fixed)
+    best_g, ll_g = tot.bestfit_scipy(use_gradient=True, **fixed)
+    assert abs(ll - ll_g) <= 1e-6 * abs(ll) and all(abs(best[k] - best_g[k]) < 5e-3 for k in best)
