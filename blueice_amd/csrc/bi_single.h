@@ -18,7 +18,9 @@ int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status)
         const volatile unsigned long long* done = (const volatile unsigned long long*)(res + 16);
         const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
         for (unsigned spin = 0; !(arrived = (*done == seq)); ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
         }
         std::atomic_thread_fence(std::memory_order_acquire);
