@@ -337,7 +337,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // larger part of the work)
         const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
         const bool scan_ok = c->scan_mfma && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535 &&
-                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups;
+                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
+                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
         if (scan_ok) {
             if ((rc = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
                 return abort_plan(rc);
