@@ -146,17 +146,30 @@ class LogLikelihoodBase:
 
     # -- anchor models ---------------------------------------------------------------------
     def prepare(self, n_cores=1, ipp_client=None):
-        """Compute the model at every anchor point.  (Template building runs serially on the host;
-        the reference's process-pool / ipyparallel farms, likelihood.py:184-208, are out of scope.)"""
+        """Compute the model at every anchor point.  n_cores > 1 builds the anchor models on a pool of THREADS
+        (numpy-heavy sources release the interpreter lock while they histogram / sample); the reference's
+        process-pool / ipyparallel farms with their on-disk cache, likelihood.py:184-208, are out of scope --
+        `ipp_client` is accepted and ignored."""
         self.anchor_models = OrderedDict()
         if len(self.shape_parameters):
             self.morpher = MORPHERS[self.config['morpher']](self.config.get('morpher_config', {}),
                                                             self.shape_parameters)
-            for zs in self.morpher.get_anchor_points(bounds=self.get_bounds()):
+
+            def build(zs):
                 conf = deepcopy(self.pdf_base_config)
                 for z, (name, (anchors, _, _)) in zip(zs, self.shape_parameters.items()):
                     conf[name] = anchors[z]
-                self.anchor_models[tuple(zs)] = Model(conf)
+                return Model(conf)
+
+            points = [tuple(zs) for zs in self.morpher.get_anchor_points(bounds=self.get_bounds())]
+            if n_cores and n_cores > 1 and len(points) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=int(n_cores)) as pool:
+                    models = list(pool.map(build, points))
+            else:
+                models = [build(zs) for zs in points]
+            for zs, model in zip(points, models):          # anchor order, whatever order the pool finished in
+                self.anchor_models[zs] = model
         self.is_data_set = False
         self.is_prepared = True
 

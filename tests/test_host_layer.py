@@ -279,3 +279,16 @@ def test_synthetic_model_through_the_plugin_route(monkeypatch, name, bb):
     assert lf.get_bounds('shape0') == (float(m.anchor_z[0][0]), float(m.anchor_z[0][-1]))
     with pytest.raises(ValueError):                       # a TemplateSource exists on the anchors only
         lf._compute_single_model(shape0=0.123)
+
+
+def test_prepare_with_a_thread_pool_builds_the_same_anchor_models(ns):
+    """prepare(n_cores=4): anchor models built by a thread pool, same tensors in the same anchor order."""
+    lf, _, _ = model_zoo.CASES['d2_nonuniform'](ns)
+    first = dict(RecordingContext.instances[-1].anchors)
+    order = list(lf.anchor_models)
+    lf.prepare(n_cores=4)
+    again = RecordingContext.instances[-1].anchors
+    assert list(lf.anchor_models) == order and sorted(again) == sorted(first) and len(first) > 1
+    for k in first:
+        np.testing.assert_array_equal(again[k][0], first[k][0])
+        np.testing.assert_array_equal(again[k][1], first[k][1])
