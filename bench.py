@@ -214,9 +214,10 @@ def main():
         traffic = None
 
     # the device's read-only streaming ceiling, measured live: a plain sum over the same resident tensor
-    stream_ceiling = None
+    stream_ceiling = copy_ceiling = None
     if rank == 0:
         try:
+            copy_ceiling = ctx.copy_bandwidth(1 << 31, reps=3)
             stream_ceiling = max(ctx.read_bandwidth(nontemporal=True, blocks_per_cu=b, reps=3) for b in (16, 32))
         except Exception as e:                       # a measurement aid only: never fail the bench line over it
             print('bench.py: read-bandwidth probe failed: %s' % e, file=sys.stderr)
@@ -239,9 +240,10 @@ def main():
                                            'bytes per launch)' if traffic else None,
                          'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads)', 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_us': ms / max(launches, 1) * 1e3,
-                         'stream_ceiling': stream_ceiling,
+                         'stream_ceiling': stream_ceiling, 'copy_ceiling': copy_ceiling,
                          'stream_ceiling_note': 'GB/s of a plain 16-byte-load sum over the resident 4 GB tensor '
-                                                '(nontemporal loads, best of 16 / 32 blocks per CU), same process'},
+                                                '(nontemporal loads, best of 16 / 32 blocks per CU); copy_ceiling: bytes read + written '
+                                                'per second of a 2 GiB device-to-device hipMemcpy; same process'},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -59,6 +59,7 @@ SIGNATURES = {
     'bi_eval_end': (C.c_int, [_p, _p, _p]),
     'bi_selftest_log': (C.c_int, [_p, _i64, _p, _p]),
     'bi_measure_read_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p]),
+    'bi_measure_copy_bandwidth': (C.c_int, [_p, _i64, C.c_int, _p]),
     'bi_profile_enable': (C.c_int, [_p, C.c_int]),
     'bi_profile_read': (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_f64)]),
     'bi_set_param': (C.c_int, [_p, C.c_char_p, _i64]),

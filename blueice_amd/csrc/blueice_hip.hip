@@ -1167,6 +1167,35 @@ int bi_measure_read_bandwidth(bi_ctx* c, int nontemporal, int blocks_per_cu, int
     return BI_OK;
 }
 
+int bi_measure_copy_bandwidth(bi_ctx* c, int64_t bytes, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || reps < 1 || bytes < 1) return BI_ERR_INVALID;
+    if (!c->model_ready || !c->ps.p) return fail(c, BI_ERR_STATE, "bi_measure_copy_bandwidth: no model resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)std::min<int64_t>(bytes, c->A * c->S * c->Bp * (int64_t)sizeof(double));
+    void* dst = nullptr;
+    hipError_t e = hipMalloc(&dst, n);
+    if (e != hipSuccess) return fail(c, BI_ERR_NOMEM, "bi_measure_copy_bandwidth: %s", hipGetErrorString(e));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; e == hipSuccess && r <= reps; ++r) {      // the first pass is the warm-up
+        e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, c->ps.p, n, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n / (ms * 1e6));   // bytes read + bytes written
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_measure_copy_bandwidth: %s", hipGetErrorString(e));
+    *gb_per_s = best;
+    return BI_OK;
+}
+
 int bi_profile_enable(bi_ctx* c, int on) {
     if (!c) return BI_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));

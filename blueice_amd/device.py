@@ -283,6 +283,12 @@ class DeviceContext:
                                                         C.byref(out)))
         return out.value
 
+    def copy_bandwidth(self, nbytes=1 << 31, reps=3):
+        """GB/s (read + written) of a device-to-device copy of the first `nbytes` of the template tensor."""
+        out = C.c_double()
+        self._check(self._lib.bi_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)))
+        return out.value
+
     def profile_read(self):
         n = C.c_int64()
         ms = C.c_double()

@@ -199,8 +199,11 @@ int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
  * bi_profile_read drains them: number of launches and summed GPU time in milliseconds.
  * bi_measure_read_bandwidth: the read-only streaming ceiling of the device (SURVEY.md 8d asks for it beside the
  * 8 TB/s vendor figure) -- a plain 16-byte-load sum over the resident template tensor, best of `reps` passes,
- * in GB/s; `nontemporal` selects the load hint, `blocks_per_cu` the grid. */
+ * in GB/s; `nontemporal` selects the load hint, `blocks_per_cu` the grid.
+ * bi_measure_copy_bandwidth: the device-to-device copy rate (bytes read + bytes written per second, GB/s) of the runtime's
+ * own copy over the first `bytes` of the template tensor into a scratch buffer -- the other usual ceiling. */
 int bi_measure_read_bandwidth(bi_ctx* ctx, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s);
+int bi_measure_copy_bandwidth(bi_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
 int bi_profile_enable(bi_ctx* ctx, int on);
 int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
 /* Tunables (bi_set_param; all have measured defaults) and read-only counters (bi_get_param):
