@@ -48,3 +48,52 @@ def test_version_and_loud_failure_without_gpu(lib):
     from blueice_amd.exceptions import DeviceError
     with pytest.raises(DeviceError):
         DeviceContext(0)
+
+
+def _compile_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / 'c_abi_demo')
+    libdir = os.path.join(ROOT, 'blueice_amd', 'lib')
+    cmd = ['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-I' + os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'examples', 'c_abi_demo.c'), '-o', exe, '-L' + libdir, '-lblueice_hip', '-lm',
+           '-Wl,-rpath,' + libdir]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links(lib, tmp_path):
+    """include/blueice_hip.h compiles as C99 and a plain C caller links against the library (no C++ / HIP / torch
+    types in the boundary)."""
+    _compile_c_demo(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_program_against_the_oracle(lib, tmp_path):
+    """examples/c_abi_demo.c -- a C caller of the ABI, no Python in the loop -- reproduces the oracle on the model it
+    builds (BASELINE.json configs[0] shape: 2 sources, 3 anchors, 40 bins), including the out-of-box point."""
+    import subprocess
+    import numpy as np
+    from oracle import blueice_oracle as orc
+    exe = _compile_c_demo(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    rows = np.array([[float(v) for v in line.split()] for line in res.stdout.strip().splitlines()])
+    assert rows.shape == (6, 5)
+    S, B, anchor_z = 2, 40, np.array([-1.0, 0.0, 1.0])
+    x = (np.arange(B) + 0.5) / B * 10.0 - 5.0
+    ps = np.empty((3, S, B))
+    mus = np.empty((3, S))
+    for a, za in enumerate(anchor_z):
+        g = np.exp(-0.5 * (x - 0.8 * za) ** 2)
+        ps[a, 0] = g / g.sum()          # (the C program sums in index order; agreement is to rounding, see rtol)
+        ps[a, 1] = 1.0 / B
+        mus[a] = (1000.0 * (1.0 + 0.05 * za), 500.0)
+    counts = np.floor((0.75 * mus[1, 0] + 0.25 * mus[2, 0]) * (0.75 * ps[1, 0] + 0.25 * ps[2, 0]) + 500.0 / B + 0.5)
+    model = dict(anchor_z=[anchor_z], ps=ps, mus=mus, n_model=None)
+    for z, r0, r1, ll, st in rows:
+        want = orc.loglikelihood(model, counts, [z], [r0, r1])
+        if np.isfinite(want):
+            assert abs(ll - want) <= 1e-10 * abs(want) and st == 0
+        else:
+            assert ll == want and int(st) == 1
