@@ -140,10 +140,15 @@ def beeston_barlow_root2(a, p, U, d):
     return ((-U*p - U + a*p + d*p + np.sqrt(_bb_disc(a, p, U, d))) / (2*p*(p + 1)))
 
 
-def adjust_expectations_bb(mus, pmfs, n_model_events, counts, source_i):
+def adjust_expectations_bb(mus, pmfs, n_model_events, counts, source_i, forgive_zero_u=False):
     """a6: Beeston-Barlow single-source adjustment; returns (mus', pmfs').
 
-    Raises AssertionError exactly where the reference asserts (likelihood.py:649,655)."""
+    Raises AssertionError exactly where the reference asserts (likelihood.py:649,655).
+    forgive_zero_u=True is NOT the reference: in bins where the other sources expect exactly nothing (U_b == 0) the
+    first root is 0 analytically, and its floating-point value -- x - sqrt(x^2 (1 +- eps)) -- is negative, zero or
+    positive by rounding alone, so the reference's first assertion fires there on a coin flip.  The device code does
+    not count a positive (non-nan) first root in such a bin as a violation; tests use this switch to tell that one
+    documented deviation from a real disagreement."""
     mus = np.array(mus, dtype=float, copy=True)
     pmfs = np.array(pmfs, dtype=float, copy=True)
     assert pmfs.shape == n_model_events.shape
@@ -160,7 +165,10 @@ def adjust_expectations_bb(mus, pmfs, n_model_events, counts, source_i):
         w_cal = pmfs[source_i] / a_bins * n_model_events[source_i].sum()
         A1 = beeston_barlow_root1(a_bins, w_cal * p_cal, u_bins, counts)
         A2 = beeston_barlow_root2(a_bins, w_cal * p_cal, u_bins, counts)
-        assert np.all(A1 <= 0)
+        if forgive_zero_u:
+            assert np.all((A1 <= 0) | ((u_bins == 0) & ~np.isnan(A1)))
+        else:
+            assert np.all(A1 <= 0)
         A_special = (counts + a_bins) / (1. + p_cal)
         A = np.choose(u_bins == 0, [A2, A_special])
         assert np.all(0 <= A)
@@ -182,7 +190,7 @@ def rates_at(model, z, rate_scale):
     return mus * np.asarray(rate_scale, dtype=float)
 
 
-def loglikelihood(model, counts, z, rate_scale, bb_source=None, allow_negative=None):
+def loglikelihood(model, counts, z, rate_scale, bb_source=None, allow_negative=None, forgive_zero_u=False):
     """One evaluation of the hot path (a3 + a4 + [a6] + a5) on explicit tensors.
 
     model: dict(anchor_z=[d arrays], ps=[A.., S, *bins], mus=[A.., S], n_model=None or like ps)
@@ -206,7 +214,7 @@ def loglikelihood(model, counts, z, rate_scale, bb_source=None, allow_negative=N
     ps = interpolate(anchor_z, model['ps'], z)
     if bb_source is not None:
         n_model = interpolate(anchor_z, model['n_model'], z)
-        mus, ps = adjust_expectations_bb(mus, ps, n_model, np.asarray(counts, float), bb_source)
+        mus, ps = adjust_expectations_bb(mus, ps, n_model, np.asarray(counts, float), bb_source, forgive_zero_u)
     return float(compute_likelihood(mus, ps.reshape(S, -1), np.asarray(counts, float).ravel()))
 
 

@@ -2,12 +2,15 @@
 single-anchor axes), source count, ragged bin counts around the 512-bin tile, zero templates, empty bins,
 on-anchor / corner points, batch grouping (1..16 points per cell pass), both data forms, gradient, toys."""
 import itertools
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10
+# BLUEICE_FUZZ_SEEDS=first:count widens the campaign (default: the 12 + 8 seeds below)
+_FIRST, _COUNT = (int(v) for v in os.environ.get('BLUEICE_FUZZ_SEEDS', '0:0').split(':'))
 
 
 def random_case(rng, d, S, B, bb):
@@ -51,7 +54,7 @@ def random_points(rng, model, P, S):
 CONFIGS = list(itertools.product([0, 1, 2, 3, 4], [1, 3, 7], [1, 37, 511, 512, 513, 1300]))
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(12))
 def test_random_configurations_match_oracle(seed):
     from blueice_amd.device import DeviceContext
     from oracle import blueice_oracle as orc
@@ -77,7 +80,12 @@ def test_random_configurations_match_oracle(seed):
             one = np.array([ctx.eval(z[i] if d else None, r[i])[0][0] for i in range(min(P, 5))])
             for i in range(P):
                 if np.isnan(want[i]) and bb >= 0:               # the reference asserts there
-                    assert st[i] & 12, (seed, d, S, B, bb, i)
+                    if not st[i] & 12:
+                        # the one documented deviation: a first root of rounding-error size in a bin where the other
+                        # sources expect exactly nothing (oracle docstring of adjust_expectations_bb)
+                        relaxed = orc.loglikelihood(model, counts, z[i], r[i], bb_source=bb, forgive_zero_u=True)
+                        assert np.isfinite(relaxed) and abs(got[i] - relaxed) <= RTOL * max(1, abs(relaxed)), \
+                            (seed, d, S, B, bb, i, got[i], relaxed)
                     continue
                 ok = (got[i] == want[i]) if not np.isfinite(want[i]) else abs(got[i] - want[i]) <= RTOL * max(1, abs(want[i]))
                 assert ok, (seed, d, S, B, bb, sparse, maxg, i, got[i], want[i])
@@ -96,7 +104,7 @@ def test_random_configurations_match_oracle(seed):
     ctx.close()
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(8))
 def test_large_batches_device_planner_and_scan_kernel(seed):
     """Batches large enough for the device-side planner and the matrix-core scan kernel, on random small models:
     several datasets, counts with nan / negative / non-integer entries, sources allowed to go negative (mu < 0 ->
