@@ -318,10 +318,10 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                         const double w = pi[g][j] / ab * Ntot;
                         double r1, r2;
                         bb_roots(ab, w * p_cal, U, n, r1, r2);
-                        // likelihood.py:649 asserts root1 <= 0.  Where U_b == 0 exactly, that root is 0 analytically and its
-                        // floating-point value x - sqrt(x^2 (1 +- eps)) has either sign by rounding alone (the reference can
-                        // trip over it); there only a nan is a violation.  See DESIGN.md section 2.
-                        if (r1 != r1 || (r1 > 0.0 && U != 0.0)) flg[g] |= BI_ST_BB_ROOT1;
+                        // likelihood.py:649 asserts root1 <= 0 -- evaluated here in the reference's own operation order.
+                        // (Where U_b == 0 that root is 0 analytically and its sign is decided by the last bit of the
+                        // inputs; see DESIGN.md section 2 for what that means for parity.)
+                        if (!(r1 <= 0.0)) flg[g] |= BI_ST_BB_ROOT1;
                         const double A = (U == 0.0) ? (n + ab) / (1.0 + p_cal) : r2;
                         if (!(0.0 <= A)) flg[g] |= BI_ST_BB_NEG;
                         const double mu = U + (A * w) * p_cal;
