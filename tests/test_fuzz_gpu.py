@@ -171,3 +171,44 @@ def test_large_batches_device_planner_and_scan_kernel(seed):
     print('matrix-core scan kernel used in %d of 6 batches' % scan_runs)
     assert scan_runs >= 1 or _COUNT      # (with the default seeds every case reaches the scan kernel at least once)
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_unbinned_random_configurations_match_oracle(seed):
+    """The extended unbinned likelihood (rows = pdf values at the events, likelihood.py:531-573,678-690) on random
+    models: events where every source's pdf is 0 (the outlier clamp), no events at all, small and large batches."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(9000 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(4):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 3, 5]))
+        n_ev = int(rng.choice([0, 1, 7, 300, 513, 2000]))
+        model, _ = random_case(rng, d, S, max(n_ev, 1), -1)
+        shape = model['ps'].shape[:-2]
+        ps = rng.random(shape + (S, n_ev)) ** 2
+        ps[rng.random(ps.shape) < 0.2] = 0.0
+        if n_ev:
+            ps[..., :, rng.integers(n_ev)] = 0.0                 # an event no source can explain, at every anchor
+        model = dict(anchor_z=model['anchor_z'], ps=ps, mus=model['mus'], n_model=None)
+        outlier = float(rng.choice([1e-12, 1e-7, 0.0]))
+        ctx.begin_model(model['anchor_z'], S, n_ev)
+        n_anchors = int(np.prod(shape, dtype=np.int64))
+        flat_ps, flat_mus = ps.reshape((n_anchors, S, n_ev)), model['mus'].reshape((n_anchors, S))
+        for a in range(len(flat_mus)):
+            ctx.set_anchor(a, flat_ps[a], flat_mus[a])
+        ctx.end_model()
+        ctx.set_unbinned(outlier)
+        for P in (int(rng.integers(1, 30)), int(rng.integers(600, 900))):
+            z, r = random_points(rng, model, P, S)
+            with np.errstate(all='ignore'):
+                want = np.array([orc.loglikelihood_unbinned(model, z[i], r[i], outlier_likelihood=outlier) for i in range(P)])
+            got, st = ctx.eval(z if d else None, r)
+            one, _ = ctx.eval(z[0] if d else None, r[0])
+            for i in range(P):
+                w, g = want[i], got[i]
+                ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
+                assert ok, (seed, rep, d, S, n_ev, outlier, P, i, g, w, st[i])
+            assert (np.isnan(want[0]) and np.isnan(one[0])) or one[0] == want[0] or abs(one[0] - want[0]) <= RTOL * max(1, abs(want[0]))
+    ctx.close()
