@@ -212,3 +212,54 @@ def test_unbinned_random_configurations_match_oracle(seed):
                 assert ok, (seed, rep, d, S, n_ev, outlier, P, i, g, w, st[i])
             assert (np.isnan(want[0]) and np.isnan(one[0])) or one[0] == want[0] or abs(one[0] - want[0]) <= RTOL * max(1, abs(want[0]))
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_gradient_random_configurations_against_finite_differences(seed):
+    """bi_eval_grad on random models, both data forms: d ll / d z and d ll / d rate_scale against central finite
+    differences of the CPU oracle at points strictly inside grid cells (ll has kinks on the anchors)."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(7000 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(4):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 3, 5]))
+        B = int(rng.choice([1, 37, 512, 700]))
+        model, counts = random_case(rng, d, S, B, -1)
+        model['ps'] = np.maximum(model['ps'], 1e-4)              # keep mu away from 0: ll is smooth in the cell
+        model['ps'] /= model['ps'].sum(axis=-1, keepdims=True)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        P = 6
+        z = np.empty((P, d))
+        h = np.empty(d)
+        for ax, g in enumerate(model['anchor_z']):
+            if len(g) == 1:
+                z[:, ax], h[ax] = g[0], 0.0                      # a single-anchor axis has nothing to differentiate
+                continue
+            k = rng.integers(0, len(g) - 1, P)
+            z[:, ax] = g[k] + (g[k + 1] - g[k]) * rng.uniform(0.2, 0.8, P)
+            h[ax] = 1e-5 * np.min(np.diff(g))
+        r = rng.uniform(0.3, 2.0, (P, S))
+        for sparse in (0, 1):
+            ctx.set_param('sparse', sparse)
+            ctx.upload_counts(counts)
+            ll, gz, gs, st = ctx.eval_grad(z if d else None, r)
+            assert not st.any()
+            for i in range(P):
+                f = lambda zz, rr: orc.loglikelihood(model, counts, zz, rr)
+                want = f(z[i], r[i])
+                assert abs(ll[i] - want) <= RTOL * max(1, abs(want))
+                scale = max(1.0, abs(want))
+                for ax in range(d):
+                    if h[ax] == 0.0:
+                        continue
+                    e = np.zeros(d); e[ax] = h[ax]
+                    fd = (f(z[i] + e, r[i]) - f(z[i] - e, r[i])) / (2 * h[ax])
+                    assert abs(gz[i, ax] - fd) <= 1e-4 * max(abs(fd), scale / max(np.ptp(model['anchor_z'][ax]), 1e-9) * 1e-3), \
+                        (seed, rep, d, S, B, sparse, i, ax, gz[i, ax], fd)
+                for s in range(S):
+                    e = np.zeros(S); e[s] = 1e-6 * r[i, s]
+                    fd = (f(z[i], r[i] + e) - f(z[i], r[i] - e)) / (2 * e[s])
+                    assert abs(gs[i, s] - fd) <= 1e-4 * max(abs(fd), 1e-3 * scale), (seed, rep, d, S, B, sparse, i, s, gs[i, s], fd)
+    ctx.close()
