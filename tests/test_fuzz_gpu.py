@@ -263,3 +263,40 @@ def test_gradient_random_configurations_against_finite_differences(seed):
                     fd = (f(z[i], r[i] + e) - f(z[i], r[i] - e)) / (2 * e[s])
                     assert abs(gs[i, s] - fd) <= 1e-4 * max(abs(fd), 1e-3 * scale), (seed, rep, d, S, B, sparse, i, s, gs[i, s], fd)
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_device_histogram_random_spaces_equal_numpy_histogramdd(seed):
+    """bi_upload_events (set_data on the device, likelihood.py:603-609) on random analysis spaces: 1-4 axes, uniform and
+    non-uniform edges, events exactly on edges (interior, first, last), outside, +-inf, nan."""
+    from blueice_amd.device import DeviceContext
+    rng = np.random.default_rng(11000 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(5):
+        k = int(rng.integers(1, 5))
+        edges = []
+        for _ in range(k):
+            n = int(rng.integers(1, 9))
+            e = np.linspace(rng.uniform(-5, 0), rng.uniform(1, 6), n + 1) if rng.random() < 0.5 \
+                else np.cumsum(rng.uniform(0.1, 2.0, n + 1)) - rng.uniform(0, 5)
+            edges.append(e)
+        shape = tuple(len(e) - 1 for e in edges)
+        B = int(np.prod(shape))
+        ctx.upload_model([], np.full((1, B), 1.0 / B), np.array([10.]))
+        ctx.set_analysis_space(edges)
+        N = int(rng.choice([0, 1, 50, 5000]))
+        cols = []
+        for e in edges:
+            x = rng.uniform(e[0] - 1, e[-1] + 1, N)
+            snap = rng.random(N) < 0.3
+            x[snap] = rng.choice(e, snap.sum())                  # exactly on an edge
+            odd = rng.random(N) < 0.02
+            x[odd] = rng.choice([np.inf, -np.inf, np.nan], odd.sum())
+            cols.append(x)
+        ctx.upload_events(*cols)
+        got = ctx.download_counts(0).reshape(shape)
+        sample = np.stack(cols, axis=1) if N else np.zeros((0, k))
+        keep = ~np.isnan(sample).any(axis=1)                     # numpy refuses nan in the range autodetection only; drop them
+        want = np.histogramdd(sample[keep], bins=edges)[0]
+        np.testing.assert_array_equal(got, want, err_msg=str((seed, rep, shape, N)))
+    ctx.close()
