@@ -300,3 +300,41 @@ def test_device_histogram_random_spaces_equal_numpy_histogramdd(seed):
         want = np.histogramdd(sample[keep], bins=edges)[0]
         np.testing.assert_array_equal(got, want, err_msg=str((seed, rep, shape, N)))
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_toy_evaluation_random_configurations_match_oracle(seed):
+    """bi_eval_datasets (one point, T datasets: the toy-MC call shape) on random models, both data forms (dense
+    counts / non-empty-bin lists), dataset sub-ranges, datasets with invalid counts, rejected points."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(13000 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(4):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 4, 7]))
+        B = int(rng.choice([1, 40, 512, 1300]))
+        model, counts0 = random_case(rng, d, S, B, -1)
+        T = int(rng.choice([1, 3, 17, 40]))
+        counts = np.stack([rng.poisson(counts0 * rng.uniform(0.3, 3)).astype(float) for _ in range(T)])
+        if rng.random() < 0.5:
+            counts[rng.integers(T), rng.integers(B)] = rng.choice([np.nan, -1.0, 2.5])
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        z, r = random_points(rng, model, 3, S)
+        if d:
+            z[2, 0] = 77.0                                       # outside the box
+        for sparse in (0, 1):
+            ctx.set_param('sparse', sparse)
+            ctx.upload_counts(counts)
+            for i in range(3):
+                t0 = int(rng.integers(0, T))
+                t1 = int(rng.integers(t0, T + 1))
+                got, st = ctx.eval_datasets(z[i] if d else None, r[i], t0, t1)
+                with np.errstate(all='ignore'):
+                    want = np.array([orc.loglikelihood(model, counts[t], z[i], r[i]) for t in range(t0, t1)])
+                assert got.shape == want.shape
+                for t in range(len(want)):
+                    w, g = want[t], got[t]
+                    ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
+                    assert ok, (seed, rep, d, S, B, T, sparse, i, t0 + t, g, w, st)
+    ctx.close()
