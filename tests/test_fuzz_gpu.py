@@ -338,3 +338,45 @@ def test_toy_evaluation_random_configurations_match_oracle(seed):
                     ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
                     assert ok, (seed, rep, d, S, B, T, sparse, i, t0 + t, g, w, st)
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_full_output_random_configurations_match_oracle(seed):
+    """bi_eval_full / bi_interpolate (full_output=True and the morpher closures, likelihood.py:355-357,424-425) on random
+    models with and without Beeston-Barlow: the interpolated tensors bit for bit, the adjusted (mus, ps) and ll to 1e-10."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(15000 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(4):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([2, 3, 5]))
+        B = int(rng.choice([1, 37, 512, 700]))
+        bb = int(rng.integers(S)) if rng.random() < 0.5 else -1
+        model, counts = random_case(rng, d, S, B, bb)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'], n_model=model['n_model'], bb_source=bb)
+        ctx.upload_counts(counts)
+        z, r = random_points(rng, model, 4, S)
+        r = np.maximum(r, 0.2)                                    # every source on: away from the U == 0 knife edge
+        for i in range(4):
+            zi = z[i] if d else None
+            ps_want = orc.interpolate(model['anchor_z'], model['ps'], z[i])
+            np.testing.assert_array_equal(ctx.interpolate('ps', zi), ps_want.reshape(S, B))
+            mus_want = orc.rates_at(model, z[i], np.ones(S))
+            np.testing.assert_array_equal(ctx.interpolate('mus', zi), mus_want)
+            ll, mus, ps, st = ctx.eval_full(zi, r[i])
+            mus_o, ps_o = mus_want * r[i], ps_want.reshape(S, B)
+            if bb >= 0:
+                nm = orc.interpolate(model['anchor_z'], model['n_model'], z[i]).reshape(S, B)
+                np.testing.assert_array_equal(ctx.interpolate('n_model', zi), nm[bb])
+                try:
+                    mus_o, ps_o = orc.adjust_expectations_bb(mus_o, ps_o, nm, counts, bb)
+                except AssertionError:
+                    assert st & 12
+                    continue
+            want = orc.compute_likelihood(mus_o, ps_o, counts)
+            assert st == 0, (seed, rep, d, S, B, bb, i, st)
+            np.testing.assert_allclose(mus, mus_o, rtol=1e-10)
+            np.testing.assert_allclose(ps, ps_o, rtol=1e-10, atol=1e-300)
+            assert (np.isfinite(want) and abs(ll - want) <= RTOL * max(1, abs(want))) or ll == want
+    ctx.close()
