@@ -380,3 +380,78 @@ def test_full_output_random_configurations_match_oracle(seed):
             np.testing.assert_allclose(ps, ps_o, rtol=1e-10, atol=1e-300)
             assert (np.isfinite(want) and abs(ll - want) <= RTOL * max(1, abs(want))) or ll == want
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(4))
+def test_likelihood_api_random_calls_match_oracle_plus_priors(seed):
+    """The Python half of a call (likelihood.py:328-415: defaults, rate multipliers, live-time scaling, log priors,
+    bounds) on top of the device half: lf(**kw) on a synthetic model with random priors against
+    oracle(tensors) + priors, for scalar calls, eval_points and LogLikelihoodSum."""
+    from scipy import stats
+    from oracle import blueice_oracle as orc
+    from blueice_amd import LogLikelihoodSum
+    from blueice_amd.likelihood import BinnedLogLikelihood
+    from blueice_amd.synthetic import SyntheticModel, TemplateSource
+    rng = np.random.default_rng(17000 + seed)
+    S = int(rng.integers(1, 5))
+    n_anchor = tuple(int(rng.integers(2, 4)) for _ in range(int(rng.integers(1, 4))))
+    bins = tuple(int(rng.integers(2, 9)) for _ in range(int(rng.integers(1, 3))))
+    m = SyntheticModel(S, n_anchor, bins, seed=int(rng.integers(1 << 30)))
+    names = ['shape%d' % i for i in range(m.d)]
+    config = dict(analysis_space=[('x%d' % i, np.arange(b + 1, dtype=float)) for i, b in enumerate(bins)],
+                  default_source_class=TemplateSource, synthetic_model=m, shape_names=names, livetime_days=2.0,
+                  sources=[dict(name='s%d' % s, source_index=s) for s in range(S)],
+                  **{n: float(g[len(g) // 2]) for n, g in zip(names, m.anchor_z)})
+    lf = BinnedLogLikelihood(config)
+    rate_priors, shape_priors = {}, {}
+    for s in range(S):
+        if rng.random() < 0.5:
+            rate_priors[s] = stats.norm(1.0, float(rng.uniform(0.05, 0.5))).logpdf
+        lf.add_rate_parameter('s%d' % s, log_prior=rate_priors.get(s))
+    for i, (n, g) in enumerate(zip(names, m.anchor_z)):
+        if rng.random() < 0.5:
+            shape_priors[i] = stats.norm(float(g[len(g) // 2]), float(rng.uniform(0.3, 2.0))).logpdf
+        lf.add_shape_parameter(n, tuple(float(v) for v in g), log_prior=shape_priors.get(i))
+    lf.prepare()
+    counts = m.counts(dense=True)
+    lf.set_binned_data(counts.reshape(bins))
+    model = m.dense_model()
+    # TemplateSource expectations are per day at livetime 1; the config's livetime_days = 2 doubles them
+    model = dict(model, mus=model['mus'] * 1.0)
+
+    def expected(z, mult, livetime):
+        scale = np.array(mult, dtype=float) * (1.0 if livetime is None else livetime / 2.0)
+        ll = orc.loglikelihood(model, counts, z, scale)
+        prior = sum(p(mult[s]) for s, p in rate_priors.items()) + sum(p(z[i]) for i, p in shape_priors.items())
+        return ll if ll == -np.inf else ll + prior
+
+    base_z = np.array([g[len(g) // 2] for g in m.anchor_z])
+    calls = []
+    for _ in range(12):
+        kw, z, mult = {}, base_z.copy(), np.ones(S)
+        for i, (n, g) in enumerate(zip(names, m.anchor_z)):
+            if rng.random() < 0.6:
+                z[i] = rng.uniform(g[0] - 0.2, g[-1] + 0.2) if rng.random() < 0.9 else rng.choice(g)
+                kw[n] = float(z[i])
+        for s in range(S):
+            if rng.random() < 0.6:
+                mult[s] = rng.choice([0.0, rng.uniform(0.1, 3.0)])
+                kw['s%d_rate_multiplier' % s] = float(mult[s])
+        livetime = float(rng.uniform(0.5, 5.0)) if rng.random() < 0.4 else None
+        calls.append((kw, z.copy(), mult.copy(), livetime))
+        want = expected(z, mult, livetime)
+        got = lf(livetime_days=livetime, **kw)
+        assert got == want or abs(got - want) <= RTOL * max(1, abs(want)), (seed, kw, livetime, got, want)
+    # the batched form over the same calls (those without a live-time override), and a weighted sum of two copies
+    plain = [c for c in calls if c[3] is None]
+    if plain:
+        pts = {n: np.array([c[1][i] for c in plain]) for i, n in enumerate(names)}
+        pts.update({'s%d_rate_multiplier' % s: np.array([c[2][s] for c in plain]) for s in range(S)})
+        want = np.array([expected(c[1], c[2], None) for c in plain])
+        got = lf.eval_points(pts)
+        fin = np.isfinite(want)
+        assert np.array_equal(got[~fin], want[~fin])
+        np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+        tot = LogLikelihoodSum([lf, lf], likelihood_weights=[1, 0.5])      # same context twice: the sequential form
+        kw = plain[0][0]
+        assert tot(**kw) == lf(**kw) + 0.5 * lf(**kw)
