@@ -116,6 +116,8 @@ struct bi_ctx {
     bool plan_tables_sparse = false;
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
     int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
+    int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
+    int64_t last_single_cell = -1, last_single_ds = -1;
     int64_t poll_result = 1;                     // single evaluations: poll the pinned result word instead of a stream sync
     int64_t tile_chunks = 8;                     // blocks walk the tiles in this many far-apart regions: block b (XCD b % 8) streams region b % 8
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)

@@ -184,6 +184,7 @@ struct LaunchArgs {
     int n0, n1, n2;         // streams into U (or mu), into P_i, into a
     int n_tiles;
     int chunks;             // > 1: consecutive blocks work in `chunks` far-apart regions of the rows
+    int n_keep;             // NT kernels: the first n_keep stream rows are loaded with the default (cacheable) policy
 };
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
@@ -214,8 +215,20 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
 #pragma unroll
         for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
 
+        int k0 = 0;
+        if constexpr (NT && G == 1) {
+            // rows meant to stay in the Infinity Cache between calls (repeated evaluations in one cell): default policy
+            k0 = a.n_keep;
 #pragma unroll 8
-        for (int k = 0; k < a.n0; ++k) {
+            for (int k = 0; k < k0; ++k) {
+                const double2 v = stream_load<false>(a.ps + rowoff[k] + bin0);
+                const double c = coef[k];
+                acc[0][0] = fma(c, v.x, acc[0][0]);
+                acc[0][1] = fma(c, v.y, acc[0][1]);
+            }
+        }
+#pragma unroll 8
+        for (int k = k0; k < a.n0; ++k) {
             const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {

@@ -108,6 +108,17 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
     const bool nt = !sparse && c->nt_loads != 0;
+    // Repeated evaluations in one grid cell (a minimizer's access pattern): let most of the cell's rows keep the default
+    // cache policy so that they stay in the 256 MiB Infinity Cache between calls (the rest, and every call into a new
+    // cell, stream with the nontemporal hint).  Measured on C2: kernel 50.9 -> 45.1 us with 28 of 32 rows kept.
+    a.n_keep = 0;
+    if (nt && !bb && c->keep_rows != 0) {
+        const bool same_cell = c->last_single_cell == g.cell_anchor && c->last_single_ds == ds;
+        const int64_t fit = (int64_t)(0.85 * 256.0 * 1048576.0 / ((double)row_stride * sizeof(double)));
+        if (same_cell) a.n_keep = (int)std::min<int64_t>(c->keep_rows > 0 ? c->keep_rows : fit, n0);
+    }
+    c->last_single_cell = g.cell_anchor;
+    c->last_single_ds = ds;
     const bool fuse = nbx <= c->fuse_max_blocks;
     const dim3 grid((unsigned)nbx), block(kThreads);
     {

@@ -163,6 +163,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }

@@ -213,6 +213,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   nt_loads          0 never | 1 always | 2 nontemporal template loads when no two items share an anchor (default)
  *   tile_chunks       XCD-aware tile order: contiguous regions per row (8; 1 = plain order)
  *   single_kernel, fuse_max_blocks   one-launch path of single evaluations, in-launch finish up to this many blocks
+ *   keep_rows         single dense evaluations repeated in one cell: stream rows that keep the default cache policy so
+ *                     they stay in the Infinity Cache between calls (-1 = as many as fit, default; 0 = none)
  *   poll_result       single evaluations: poll the pinned result word instead of a stream synchronise (1)
  *   xcd_affine        round block counts to multiples of 8
  *   device_plan_min   batches of at least this many points are planned on the device (512)
