@@ -1,0 +1,396 @@
+"""Communicators for sharded runs: one process per GPU, results gathered once at the end.
+
+The path partitions by evaluation (toy datasets, scan points) and has no data-path collective; the ONE exchange is
+the gather of the per-rank fp64 result vectors.  The reference has no counterpart (its scans
+are Python loops, blueice/inference.py:49-50,424-432; its only parallelism farms template building out to
+processes, blueice/parallel.py:47-103).
+
+Three implementations of one small interface (`rank`, `world`, `all_gather`, `all_reduce`, `broadcast_bytes`,
+`barrier`, `close`):
+
+  SoloCommunicator     a single process.
+  SocketCommunicator   TCP over the loopback interface, star-shaped through rank 0.  Host memory only: the
+                       bootstrap channel (rendezvous, RCCL unique id), the CPU rehearsal of the sharded paths,
+                       and the fall-back gather when RCCL cannot be initialised on a box.
+  RcclCommunicator     RCCL bound directly with ctypes (librccl.so: ncclGetUniqueId / ncclCommInitRank /
+                       ncclAllGather / ncclAllReduce), collectives enqueued on the DeviceContext's own HIP stream
+                       (`bi_stream`) between device buffers -- the results of `bi_run_plan` go from HBM over xGMI
+                       to every rank's HBM with no host hop and no second runtime in the process.
+
+Launch: ranks are plain processes started before any of them touches the GPU -- `python -m blueice_amd.launch
+--nproc N script.py ...`, or any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
+(torch.distributed.run does).  Rendezvous: rank 0 listens on an ephemeral port and publishes it in a small file
+whose name every rank derives from the same environment (BLUEICE_AMD_RDZV, or MASTER_PORT + parent pid).
+"""
+import ctypes as C
+import os
+import socket
+import struct
+import tempfile
+import time
+
+import numpy as np
+
+__all__ = ['SoloCommunicator', 'SocketCommunicator', 'RcclCommunicator', 'connect', 'CommError']
+
+_OPS = ('sum', 'max', 'min', 'bor')
+
+
+class CommError(RuntimeError):
+    pass
+
+
+def _reduce(parts, op):
+    stack = np.stack(parts)
+    if op == 'sum':
+        out = stack[0].copy()
+        for p in stack[1:]:               # fixed rank order: every rank computes the same bits
+            out = out + p
+        return out
+    if op == 'max':
+        return stack.max(axis=0)
+    if op == 'min':
+        return stack.min(axis=0)
+    if op == 'bor':
+        return np.bitwise_or.reduce(stack.astype(np.int64), axis=0).astype(stack.dtype)
+    raise ValueError("op must be one of %s" % (_OPS,))
+
+
+class SoloCommunicator:
+    rank, world = 0, 1
+    kind = 'solo'
+
+    def all_gather(self, local):
+        return np.asarray(local)[None, ...].copy()
+
+    def all_reduce(self, local, op='sum'):
+        return np.array(local, copy=True)
+
+    def broadcast_bytes(self, data=None):
+        return data
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# sockets
+# ---------------------------------------------------------------------------------------------------
+def _send(sock, payload):
+    sock.sendall(struct.pack('<q', len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    chunks, got = [], 0
+    while got < n:
+        b = sock.recv(min(n - got, 1 << 20))
+        if not b:
+            raise CommError("peer closed the connection")
+        chunks.append(b)
+        got += len(b)
+    return b''.join(chunks)
+
+
+def _recv(sock):
+    (n,) = struct.unpack('<q', _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+def rendezvous_path():
+    """The file rank 0 publishes its port in; the same for every rank of one launch."""
+    explicit = os.environ.get('BLUEICE_AMD_RDZV')
+    if explicit:
+        return explicit
+    key = '%s_%s_%s_%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '0'),
+                           os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
+    key = ''.join(ch if ch.isalnum() or ch in '._-' else '_' for ch in key)
+    return os.path.join(tempfile.gettempdir(), 'blueice_amd_rdzv_%d_%s' % (os.getuid(), key))
+
+
+class SocketCommunicator:
+    """Host-side collectives over loopback TCP, star-shaped through rank 0.  Payloads here are a few MB at most
+    (10^6 doubles at configs[3]); the point is correctness and zero dependencies, not bandwidth."""
+
+    kind = 'socket'
+
+    def __init__(self, rank, world, path=None, timeout=180.0, host='127.0.0.1'):
+        self.rank, self.world = int(rank), int(world)
+        self._peers = []          # rank 0: socket of every other rank, by rank
+        self._up = None           # other ranks: socket to rank 0
+        self._path = path or rendezvous_path()
+        deadline = time.monotonic() + timeout
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host, 0))
+            srv.listen(self.world)
+            port = srv.getsockname()[1]
+            tmp = '%s.%d.tmp' % (self._path, os.getpid())
+            with open(tmp, 'w') as f:
+                f.write('%s %d %d\n' % (host, port, os.getpid()))
+            os.replace(tmp, self._path)                        # atomic: readers see all of it or the previous file
+            peers = {}
+            srv.settimeout(1.0)
+            while len(peers) < self.world - 1:
+                if time.monotonic() > deadline:
+                    raise CommError("rendezvous: %d of %d ranks connected within %.0f s" % (len(peers) + 1, self.world, timeout))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                r, w = struct.unpack('<ii', _recv(conn))
+                if w != self.world or not 0 < r < self.world or r in peers:
+                    conn.close()
+                    raise CommError("rendezvous: unexpected peer (rank %d of %d)" % (r, w))
+                peers[r] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+            try:
+                os.unlink(self._path)
+            except OSError:
+                pass
+            for p in self._peers:
+                _send(p, b'go')
+        else:
+            last = None
+            while True:
+                if time.monotonic() > deadline:
+                    raise CommError("rendezvous: rank %d could not reach rank 0 via %s (%s)" % (self.rank, self._path, last))
+                try:
+                    with open(self._path) as f:
+                        h, port, _ = f.read().split()
+                    s = socket.create_connection((h, int(port)), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(timeout)
+                    _send(s, struct.pack('<ii', self.rank, self.world))
+                    if _recv(s) != b'go':
+                        raise CommError("bad handshake")
+                    self._up = s
+                    break
+                except (OSError, ValueError, CommError) as e:     # no file yet, a stale file, or rank 0 not listening yet
+                    last = e
+                    time.sleep(0.05)
+
+    # -- primitives ---------------------------------------------------------------------------
+    def _gather_bytes(self, payload):
+        """rank 0 -> list of every rank's payload (by rank); other ranks -> None."""
+        if self.rank == 0:
+            return [payload] + [_recv(p) for p in self._peers]
+        _send(self._up, payload)
+        return None
+
+    def broadcast_bytes(self, data=None):
+        if self.world == 1:
+            return data
+        if self.rank == 0:
+            for p in self._peers:
+                _send(p, data)
+            return data
+        return _recv(self._up)
+
+    def all_gather(self, local):
+        """Equal-shaped arrays from every rank -> [world, ...] on every rank."""
+        local = np.ascontiguousarray(local)
+        if self.world == 1:
+            return local[None, ...].copy()
+        parts = self._gather_bytes(local.tobytes())
+        blob = self.broadcast_bytes(b''.join(parts) if self.rank == 0 else None)
+        return np.frombuffer(blob, dtype=local.dtype).reshape((self.world,) + local.shape).copy()
+
+    def all_reduce(self, local, op='sum'):
+        local = np.ascontiguousarray(local)
+        if self.world == 1:
+            return local.copy()
+        parts = self._gather_bytes(local.tobytes())
+        if self.rank == 0:
+            out = _reduce([np.frombuffer(p, dtype=local.dtype).reshape(local.shape) for p in parts], op)
+            self.broadcast_bytes(np.ascontiguousarray(out, dtype=local.dtype).tobytes())
+            return out.astype(local.dtype, copy=False)
+        return np.frombuffer(self.broadcast_bytes(), dtype=local.dtype).reshape(local.shape).copy()
+
+    def barrier(self):
+        self.all_reduce(np.zeros(1))
+
+    def close(self):
+        for s in self._peers + ([self._up] if self._up is not None else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._up = [], None
+
+
+# ---------------------------------------------------------------------------------------------------
+# RCCL, bound directly
+# ---------------------------------------------------------------------------------------------------
+class _UniqueId(C.Structure):
+    _fields_ = [('internal', C.c_char * 128)]           # NCCL_UNIQUE_ID_BYTES (rccl.h)
+
+
+_NCCL_INT64, _NCCL_FLOAT64 = 4, 8                        # ncclDataType_t (rccl.h)
+_NCCL_OPS = {'sum': 0, 'max': 2, 'min': 3}               # ncclRedOp_t
+_rccl = None
+
+
+def load_rccl():
+    """librccl.so with prototypes set; CommError if it cannot be loaded."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    last = None
+    for name in (os.environ.get('BLUEICE_AMD_RCCL'), 'librccl.so.1', '/opt/rocm/lib/librccl.so.1', 'librccl.so'):
+        if not name:
+            continue
+        try:
+            lib = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError as e:
+            last = e
+    else:
+        raise CommError("cannot load librccl.so: %s" % last)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    lib.ncclGetErrorString.restype = C.c_char_p
+    lib.ncclGetErrorString.argtypes = [i]
+    for name, args in (('ncclGetVersion', [C.POINTER(i)]), ('ncclGetUniqueId', [C.POINTER(_UniqueId)]),
+                       ('ncclCommInitRank', [C.POINTER(vp), i, _UniqueId, i]), ('ncclCommDestroy', [vp]),
+                       ('ncclAllGather', [vp, vp, sz, i, vp, vp]), ('ncclAllReduce', [vp, vp, sz, i, i, vp, vp])):
+        fn = getattr(lib, name)
+        fn.restype = i
+        fn.argtypes = args
+    _rccl = lib
+    return lib
+
+
+class RcclCommunicator:
+    """Device-side collectives on the context's stream.  `bootstrap` is an already connected host communicator (it
+    carries the unique id, and host-side odds and ends such as the max-over-ranks of a wall time)."""
+
+    kind = 'rccl'
+
+    def __init__(self, ctx, bootstrap):
+        self.ctx, self.boot = ctx, bootstrap
+        self.rank, self.world = bootstrap.rank, bootstrap.world
+        self._lib = load_rccl()
+        self._comm = C.c_void_p()
+        self._send = self._recv = None
+        uid = _UniqueId()
+        if self.rank == 0:
+            self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+        blob = bootstrap.broadcast_bytes(bytes(uid.internal) if self.rank == 0 else None)
+        C.memmove(C.addressof(uid), blob, 128)
+        scratch = ctx.device_alloc(16)                 # also makes the context's GPU the calling thread's current device
+        scratch.free()
+        self._ok(self._lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        v = C.c_int()
+        self._lib.ncclGetVersion(C.byref(v))
+        self.version = v.value
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise CommError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    # -- device form: pointers in, nothing leaves HBM -------------------------------------------
+    def all_gather_device(self, send_ptr, recv_ptr, count, dtype=np.float64):
+        """recv[r * count : (r + 1) * count] = rank r's send[0:count], enqueued on the context stream."""
+        code = _NCCL_FLOAT64 if np.dtype(dtype) == np.float64 else _NCCL_INT64
+        self._ok(self._lib.ncclAllGather(C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), code, self._comm,
+                                         C.c_void_p(self.ctx.stream)), 'ncclAllGather')
+
+    def all_reduce_device(self, send_ptr, recv_ptr, count, op='sum', dtype=np.float64):
+        code = _NCCL_FLOAT64 if np.dtype(dtype) == np.float64 else _NCCL_INT64
+        self._ok(self._lib.ncclAllReduce(C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), code, _NCCL_OPS[op],
+                                         self._comm, C.c_void_p(self.ctx.stream)), 'ncclAllReduce')
+
+    # -- host form (same interface as SocketCommunicator): staged through two device buffers ------
+    def _staging(self, nbytes):
+        if self._send is None or self._send.nbytes < nbytes:
+            for b in (self._send, self._recv):
+                if b is not None:
+                    b.free()
+            self._send = self.ctx.device_alloc(nbytes)
+            self._recv = self.ctx.device_alloc(nbytes * self.world)
+        return self._send, self._recv
+
+    def all_gather(self, local):
+        local = np.ascontiguousarray(local)
+        if local.dtype not in (np.float64, np.int64):
+            raise TypeError("RCCL path carries float64 / int64")
+        send, recv = self._staging(max(local.nbytes, 16))
+        send.from_host(local)
+        self.all_gather_device(send.ptr, recv.ptr, local.size, local.dtype)
+        return recv.to_host(local.dtype, local.size * self.world).reshape((self.world,) + local.shape)
+
+    def all_reduce(self, local, op='sum'):
+        local = np.ascontiguousarray(local)
+        if op == 'bor':                                        # no bitwise reduction in RCCL's fp path: gather, then OR
+            return np.bitwise_or.reduce(self.all_gather(local.astype(np.int64)), axis=0).astype(local.dtype)
+        if local.dtype not in (np.float64, np.int64):
+            raise TypeError("RCCL path carries float64 / int64")
+        send, recv = self._staging(max(local.nbytes, 16))
+        send.from_host(local)
+        self.all_reduce_device(send.ptr, recv.ptr, local.size, op, local.dtype)
+        return recv.to_host(local.dtype, local.size).reshape(local.shape)
+
+    def broadcast_bytes(self, data=None):
+        return self.boot.broadcast_bytes(data)
+
+    def barrier(self):
+        self.ctx.sync()
+        self.all_reduce(np.zeros(1))
+
+    def close(self):
+        for b in (self._send, self._recv):
+            if b is not None:
+                b.free()
+        self._send = self._recv = None
+        if self._comm:
+            self.ctx.sync()
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = C.c_void_p()
+        self.boot.close()
+
+
+def connect(ctx=None, backend='rccl', rank=None, world=None, timeout=180.0):
+    """The communicator of this process, from the launcher's environment (RANK / WORLD_SIZE, default one process).
+
+    backend 'rccl' needs the rank's DeviceContext; if RCCL cannot be loaded or initialised on ANY rank, every rank
+    falls back to the socket communicator together (`.kind == 'socket'`, `.fallback_reason` says why) -- a
+    gather of a few MB must not be what fails a run.  backend 'socket': host-side only (CPU rehearsals)."""
+    rank = int(os.environ.get('RANK', 0)) if rank is None else int(rank)
+    world = int(os.environ.get('WORLD_SIZE', 1)) if world is None else int(world)
+    if world == 1 and backend != 'rccl':
+        return SoloCommunicator()
+    boot = SocketCommunicator(rank, world, timeout=timeout) if world > 1 else SoloCommunicator()
+    if backend == 'socket':
+        return boot
+    if backend != 'rccl':
+        raise ValueError("backend must be 'rccl' or 'socket'")
+    if ctx is None:
+        raise ValueError("the rccl backend needs this rank's DeviceContext")
+    reason = ''
+    try:
+        load_rccl()
+    except CommError as e:
+        reason = str(e)
+    # agree before anybody enters ncclCommInitRank (which blocks until every rank has arrived)
+    if boot.all_reduce(np.array([1.0 if reason else 0.0]), 'max')[0] > 0:
+        boot.fallback_reason = reason or 'librccl.so could not be loaded on another rank'
+        return boot
+    comm = None
+    try:
+        comm = RcclCommunicator(ctx, boot)
+    except CommError as e:
+        reason = str(e)
+    if boot.all_reduce(np.array([1.0 if reason else 0.0]), 'max')[0] > 0:
+        if comm is not None:
+            comm._comm = C.c_void_p()          # a communicator some rank failed to build is not usable: forget it
+        boot.fallback_reason = reason or 'ncclCommInitRank failed on another rank'
+        return boot
+    return comm

@@ -121,6 +121,7 @@ struct bi_ctx {
     int64_t poll_result = 1;                     // single evaluations: poll the pinned result word instead of a stream sync
     int64_t tile_chunks = 8;                     // blocks walk the tiles in this many far-apart regions: block b (XCD b % 8) streams region b % 8
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
+    int64_t toy_offset = 0;                      // bi_generate_toys: toy t of the call is dataset toy_offset + t of the seed's stream
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device

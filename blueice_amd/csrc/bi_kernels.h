@@ -185,6 +185,8 @@ struct LaunchArgs {
     int n_tiles;
     int chunks;             // > 1: consecutive blocks work in `chunks` far-apart regions of the rows
     int n_keep;             // NT kernels: the first n_keep stream rows are loaded with the default (cacheable) policy
+    int nan_S;              // MODE 2 with non-finite pdf values: number of sources (streams are [corner][source]); the
+                            // sum over sources then skips nan terms -- np.nansum, blueice/likelihood.py:686.  0 = off
 };
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
@@ -216,7 +218,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
         for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
 
         int k0 = 0;
-        if constexpr (NT && G == 1) {
+        if constexpr (NT && G == 1 && MODE != 2) {
             // rows meant to stay in the Infinity Cache between calls (repeated evaluations in one cell): default policy
             k0 = a.n_keep;
 #pragma unroll 8
@@ -226,6 +228,32 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                 acc[0][0] = fma(c, v.x, acc[0][0]);
                 acc[0][1] = fma(c, v.y, acc[0][1]);
             }
+        }
+        if constexpr (MODE == 2) if (a.nan_S > 0) {
+            // np.nansum over sources (likelihood.py:686): a source whose morphed density times its rate is nan at an
+            // event contributes nothing there.  Per source the corners are summed first (the morph), then the test.
+            const int S = a.nan_S, nc = a.n0 / S;
+            for (int s = 0; s < S; ++s) {
+                double part[G][2];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { part[g][0] = 0.0; part[g][1] = 0.0; }
+                for (int c = 0; c < nc; ++c) {
+                    const int k = c * S + s;
+                    const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const double cf = coef[k * G + g];
+                        part[g][0] = fma(cf, v.x, part[g][0]);
+                        part[g][1] = fma(cf, v.y, part[g][1]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (part[g][0] == part[g][0]) acc[g][0] += part[g][0];
+                    if (part[g][1] == part[g][1]) acc[g][1] += part[g][1];
+                }
+            }
+            k0 = a.n0;
         }
 #pragma unroll 8
         for (int k = k0; k < a.n0; ++k) {

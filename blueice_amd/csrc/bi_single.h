@@ -26,6 +26,12 @@ int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status)
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!arrived || (seq & 255ull) == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*(const volatile unsigned long long*)(res + 16) != seq) {
+        // the stream drained but no block published a result: the ticket counter was out of step (an earlier launch
+        // was aborted).  Re-arm it and report, rather than hand back the zeroed block as a likelihood of 0.
+        if (c->slot_counter.p) (void)hipMemsetAsync(c->slot_counter.p, 0, 64, c->stream);
+        return fail(c, BI_ERR_HIP, "single-point launch %llu finished without publishing its result", seq);
+    }
     *out = *(double*)res;
     if (status) *status = *(int32_t*)(res + 8);
     return BI_OK;
@@ -107,6 +113,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     a.pflags = (unsigned*)c->slot_pflags.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
+    a.nan_S = (c->unbinned && !c->ps_finite) ? c->S : 0;
     const bool nt = !sparse && c->nt_loads != 0;
     // Repeated evaluations in one grid cell (a minimizer's access pattern): let most of the cell's rows keep the default
     // cache policy so that they stay in the 256 MiB Infinity Cache between calls (the rest, and every call into a new
@@ -266,6 +273,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     a.pflags = (unsigned*)c->slot_pflags.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
+    a.nan_S = (c->unbinned && !c->ps_finite) ? c->S : 0;
     launch_morph_g(c, 1, a, dim3((unsigned)nbx, 1), bb, !sparse && c->nt_loads != 0);
     const int lanes = nbx > 64 ? kThreads : 64;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kThreads), 0, c->stream, (const double*)a.partial,

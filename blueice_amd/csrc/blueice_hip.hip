@@ -167,6 +167,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "toy_offset")) { if (v < 0) return fail(c, BI_ERR_INVALID, "toy_offset >= 0"); c->toy_offset = v; return BI_OK; }
     if (!strcmp(name, "scan_cb")) { c->scan_cb = (v == 2 || v == 4) ? v : 0; return BI_OK; }
     if (!strcmp(name, "nt_loads")) {
         if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
@@ -190,6 +191,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "scan_mfma")) return c->scan_mfma;
     if (!strcmp(name, "n_scan_launches")) return c->n_scan_launches;
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
+    if (!strcmp(name, "toy_offset")) return c->toy_offset;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
     if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
     if (!strcmp(name, "compact_ready")) return c->compact_ready ? 1 : 0;
@@ -471,6 +473,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     a.counts = plan->sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
     a.B = c->B; a.Bp = c->Bp;
     a.outlier = c->outlier;
+    a.nan_S = (c->unbinned && !c->ps_finite) ? c->S : 0;
     a.n0 = bb ? nc * (c->S - 1) : nc * c->S;
     a.n1 = bb ? nc : 0; a.n2 = bb ? nc : 0;
     a.n_tiles = n_tiles_of(c);
@@ -769,33 +772,41 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
 
 // ---- toy-MC form ---------------------------------------------------------------------------
 
-int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
-                     int32_t* status) {
+}  // extern "C"
+
+namespace {
+
+// out_dev != NULL: results stay in HBM at out_dev[0 .. t1 - t0) (the call still returns after the stream has drained:
+// its descriptors travel through the context's pinned staging block, which the next call reuses)
+int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
+                       double* out_dev, int32_t* status) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "bi_eval_datasets is not available with Beeston-Barlow");
     if (c->unbinned) return fail(c, BI_ERR_INVALID, "bi_eval_datasets needs a binned likelihood");
     if (t0 < 0 || t1 > c->T || t0 > t1) return fail(c, BI_ERR_INVALID, "dataset range [%lld,%lld) outside [0,%lld)", (long long)t0, (long long)t1, (long long)c->T);
     if (c->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
-    if (t1 > t0 && !out) return fail(c, BI_ERR_INVALID, "out is NULL");
+    if (t1 > t0 && !out && !out_dev) return fail(c, BI_ERR_INVALID, "out is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t n = t1 - t0;
     if (status) *status = 0;
     const double ninf = -std::numeric_limits<double>::infinity();
-    PointGeom g;
-    if (!point_geometry(c, z, g)) {
-        if (status) *status = BI_ST_OUT_OF_BOUNDS;
-        std::fill(out, out + n, ninf);
+    auto reject = [&](int32_t bit) -> int {          // the reference returns -inf before it looks at any data
+        if (status) *status = bit;
+        if (out_dev) {
+            std::vector<double> fill((size_t)n, ninf);
+            if (n) HIP_TRY(c, hipMemcpy(out_dev, fill.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::fill(out, out + n, ninf);
+        }
         return BI_OK;
-    }
+    };
+    PointGeom g;
+    if (!point_geometry(c, z, g)) return reject(BI_ST_OUT_OF_BOUNDS);
     std::vector<double> r((size_t)c->S);
     interp_mus(c, g, r.data());
     if (rate_scale) for (int s = 0; s < c->S; ++s) r[(size_t)s] *= rate_scale[s];
-    if (!rates_physical(c, r.data())) {
-        if (status) *status = BI_ST_UNPHYSICAL;
-        std::fill(out, out + n, ninf);
-        return BI_OK;
-    }
+    if (!rates_physical(c, r.data())) return reject(BI_ST_UNPHYSICAL);
     const int nc = (int)g.w.size();
     const int NS = nc * c->S;
     std::vector<int64_t> rowoff((size_t)NS);
@@ -816,18 +827,18 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int64_t chunk = csr ? 1048576 : 16384;
     const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
     // descriptors in one packed copy; up to 4 MB of results are written straight into pinned host memory
-    const bool host_out = (size_t)n * sizeof(double) <= ((size_t)4 << 20);
+    const bool host_out = !out_dev && (size_t)n * sizeof(double) <= ((size_t)4 << 20);
     PackedUpload pu;
     if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)}},
                             host_out ? (size_t)n * sizeof(double) : 0, pu)) ||
         (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
         (rc = dev_alloc(c, c->scratch2, (size_t)std::min(n, chunk) * nbx * sizeof(double))) ||
-        (!host_out && (rc = dev_alloc(c, d_out, (size_t)std::max<int64_t>(n, 1) * sizeof(double))))) {
+        (!host_out && !out_dev && (rc = dev_alloc(c, d_out, (size_t)std::max<int64_t>(n, 1) * sizeof(double))))) {
         cleanup();
         return rc;
     }
-    double* res = host_out ? (double*)pu.host_out() : (double*)d_out.p;
+    double* res = out_dev ? out_dev : (host_out ? (double*)pu.host_out() : (double*)d_out.p);
     LaunchArgs a{};
     a.ps = (const double*)c->ps.p;
     a.rowoff = pu.dev<int64_t>(0);
@@ -857,12 +868,27 @@ int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64
                            (const double*)c->lgsum.p, t0 + s0, ni, res + s0);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && n && !host_out) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && n && !host_out && !out_dev) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && n && host_out) memcpy(out, res, (size_t)n * sizeof(double));
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets: %s", hipGetErrorString(e));
     return BI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
+                     int32_t* status) {
+    return eval_datasets_impl(c, z, rate_scale, t0, t1, out, nullptr, status);
+}
+
+int bi_eval_datasets_device(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out_dev,
+                            int32_t* status) {
+    if (t1 > t0 && !out_dev) return fail(c, BI_ERR_INVALID, "out_dev is NULL");
+    return eval_datasets_impl(c, z, rate_scale, t0, t1, nullptr, out_dev, status);
 }
 
 
@@ -926,8 +952,8 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     const int64_t tchunk = 32768;
     for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
         const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_toy_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed, t0,
-                           (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
+        hipLaunchKernelGGL(k_toy_count, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed,
+                           t0 + c->toy_offset, (int32_t*)d_cnt.p + t0 * nchunks, nchunks);
     }
     std::vector<int32_t> h_cnt((size_t)T * nchunks);
     hipError_t e = hipGetLastError();
@@ -949,8 +975,8 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     }
     for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
         const int64_t n = std::min(tchunk, T - t0);
-        hipLaunchKernelGGL(k_toy_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed, t0,
-                           (const int64_t*)d_off.p + t0 * nchunks, nchunks, (int32_t*)c->nz_idx.p, (double*)c->nz_n.p,
+        hipLaunchKernelGGL(k_toy_scatter, dim3((unsigned)nchunks, (unsigned)n), dim3(kThreads), 0, c->stream, mu, p0, B, seed,
+                           t0 + c->toy_offset, (const int64_t*)d_off.p + t0 * nchunks, nchunks, (int32_t*)c->nz_idx.p, (double*)c->nz_n.p,
                            (double*)d_lgp.p + t0 * nchunks);
         hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            (const double*)d_lgp.p + t0 * nchunks, nchunks, (double*)c->lgsum.p + t0, n);
@@ -998,9 +1024,6 @@ int bi_set_unbinned(bi_ctx* c, double outlier_likelihood) {
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "Beeston-Barlow applies to binned likelihoods only");
-    if (!c->ps_finite)
-        return fail(c, BI_ERR_INVALID, "pdf values at the events must be finite (the reference's nansum over sources, "
-                                       "likelihood.py:686, is not reproduced)");
     HIP_TRY(c, hipSetDevice(c->device));
     ++c->epoch;
     c->unbinned = true;
@@ -1111,6 +1134,42 @@ int bi_eval_full(bi_ctx* c, const double* z, const double* rate_scale, int64_t d
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_full: %s", hipGetErrorString(e));
     mus_out[i] = tot * p_cal;  // likelihood.py:658
+    return BI_OK;
+}
+
+// ---- plain device buffers (gather staging for multi-GPU runs) -----------------------------------
+
+int bi_device_alloc(bi_ctx* c, int64_t bytes, void** out) {
+    if (!c || !out || bytes < 0) return BI_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const hipError_t e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) return fail(c, BI_ERR_NOMEM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return BI_OK;
+}
+
+int bi_device_free(bi_ctx* c, void* p) {
+    if (!c) return BI_ERR_INVALID;
+    if (!p) return BI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(p));
+    return BI_OK;
+}
+
+int bi_memcpy_to_host(bi_ctx* c, void* dst, const void* src, int64_t bytes) {
+    if (!c || bytes < 0 || (bytes > 0 && (!dst || !src))) return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BI_OK;
+}
+
+int bi_memcpy_to_device(bi_ctx* c, void* dst, const void* src, int64_t bytes) {
+    if (!c || bytes < 0 || (bytes > 0 && (!dst || !src))) return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BI_OK;
 }
 

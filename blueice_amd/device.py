@@ -11,7 +11,7 @@ from . import _capi
 from ._capi import as_f64, ptr
 from .exceptions import DeviceError, NotPreparedException
 
-__all__ = ['DeviceContext', 'EvalPlan', 'default_device']
+__all__ = ['DeviceContext', 'DeviceBuffer', 'EvalPlan', 'default_device']
 
 
 def default_device():
@@ -244,6 +244,17 @@ class DeviceContext:
         self._check(self._lib.bi_eval_datasets(self._h, ptr(z), ptr(rate_scale), int(t0), t1, ptr(out), ptr(status)))
         return out, int(status[0])
 
+    def eval_datasets_device(self, out_ptr, z, rate_scale=None, t0=0, t1=None):
+        """eval_datasets with the ll vector left in HBM at device address `out_ptr` -> status."""
+        t1 = self.T if t1 is None else int(t1)
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        status = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.bi_eval_datasets_device(self._h, ptr(z), ptr(rate_scale), int(t0), t1, C.c_void_p(out_ptr),
+                                                      ptr(status)))
+        return int(status[0])
+
     def interpolate(self, which, z):
         """which: 'ps' -> [S, B], 'mus' -> [S], 'n_model' -> [B] (the Beeston-Barlow source row)."""
         code = {'ps': 0, 'mus': 1, 'n_model': 2}[which]
@@ -272,6 +283,13 @@ class DeviceContext:
         self._check(self._lib.bi_plan_points(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), C.byref(h)))
         return EvalPlan(self, h, P)
 
+    # -- plain device buffers (gather staging) ------------------------------------------------------
+    def device_alloc(self, nbytes):
+        """-> DeviceBuffer of `nbytes` on this context's GPU (freed with .free() or with the context)."""
+        h = C.c_void_p()
+        self._check(self._lib.bi_device_alloc(self._h, int(nbytes), C.byref(h)))
+        return DeviceBuffer(self, h.value, int(nbytes))
+
     # -- measurement -----------------------------------------------------------------------
     def profile(self, on):
         self._check(self._lib.bi_profile_enable(self._h, 1 if on else 0))
@@ -294,6 +312,37 @@ class DeviceContext:
         ms = C.c_double()
         self._check(self._lib.bi_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+
+class DeviceBuffer:
+    """A plain allocation in HBM: `.ptr` is the device address (an int), e.g. the target of EvalPlan.run or the
+    send / receive buffer of an RCCL collective."""
+
+    def __init__(self, ctx, ptr_value, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr_value, nbytes
+
+    def to_host(self, dtype=np.float64, count=None, offset_bytes=0):
+        n = (self.nbytes - offset_bytes) // np.dtype(dtype).itemsize if count is None else int(count)
+        out = np.empty(n, dtype=dtype)
+        self.ctx._check(self.ctx._lib.bi_memcpy_to_host(self.ctx._h, ptr(out), C.c_void_p(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def from_host(self, a, offset_bytes=0):
+        a = np.ascontiguousarray(a)
+        if a.nbytes + offset_bytes > self.nbytes:
+            raise ValueError("array does not fit the device buffer")
+        self.ctx._check(self.ctx._lib.bi_memcpy_to_device(self.ctx._h, C.c_void_p(self.ptr + offset_bytes), ptr(a), a.nbytes))
+
+    def free(self):
+        if self.ptr and self.ctx._h.value:
+            self.ctx._lib.bi_device_free(self.ctx._h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class EvalPlan:

@@ -87,7 +87,7 @@ def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bound
     use_gradient=True (extension): hand scipy the analytic gradient computed in the same device pass as
     the value instead of letting it difference the objective numerically (n_parameters + 1 calls per step)."""
     minimize_kwargs = minimize_kwargs or {}
-    use_gradient = use_gradient and hasattr(lf, 'value_and_gradient')
+    use_gradient = use_gradient and bool(getattr(lf, 'supports_gradient', False))
     try:
         f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space,
                                                     **(dict(kwargs, with_gradient=True) if use_gradient else kwargs))

@@ -183,18 +183,24 @@ class LogLikelihoodBase:
         return Model(combine_dicts(self.pdf_base_config, settings, deep_copy=True))
 
     # -- host half of one evaluation -------------------------------------------------------
-    def _host_terms(self, livetime_days, kwargs):
+    def _host_terms(self, livetime_days, kwargs, morph=True, mus_of=None):
         """Everything of likelihood.py:328-393 that is scalar bookkeeping.
-        -> (prior_sum, z vector, rate_scale [S]) or (None, None, None) when z is out of bounds."""
+        -> (prior_sum, z vector, rate_scale [S]) or (None, None, None) when z is out of bounds.
+        morph=False is the compute_pdf branch (likelihood.py:331-335): the model is built AT the settings, so there is
+        no anchor-box test and the shape priors are not added (the reference adds them only on the interpolating
+        branch, :341-350); rate priors, live-time and efficiency scaling apply either way.
+        mus_of() -> expected events [S] before rate multipliers; only called for the zero-live-time assertion."""
         multipliers, settings = self._kwargs_to_settings(**kwargs)
         prior = 0
         zs = []
         for name, (_, log_prior, _) in self.shape_parameters.items():
             z = settings[name]
+            zs.append(z)
+            if not morph:
+                continue
             lo, hi = self.get_bounds(name)
             if not lo <= z <= hi:
                 return None, None, None         # cannot extrapolate: -inf (likelihood.py:345-347)
-            zs.append(z)
             if log_prior is not None:
                 prior += log_prior(z)
         scale = np.array(multipliers, dtype=float)
@@ -209,6 +215,9 @@ class LogLikelihoodBase:
             if base == 0:
                 if livetime_days != 0:
                     raise ValueError("Cannot scale from 0 to non-0 livetime")
+                # likelihood.py:380: with no live time every source must expect exactly nothing
+                mus = mus_of() if mus_of is not None else self.ctx.interpolate('mus', np.asarray(zs, dtype=float))
+                assert np.all(np.asarray(mus, dtype=float) * scale == 0), "Got non-0 mus with 0 livetime?!"
             else:
                 scale = scale * (livetime_days / base)
         if True in self.source_apply_efficiency:
@@ -235,6 +244,7 @@ class DeviceLogLikelihood(LogLikelihoodBase):
     evaluation = host bookkeeping + one fused device call."""
 
     model_statistical_uncertainty_handling = None
+    supports_gradient = False          # bestfit_scipy(use_gradient=True) asks; only plain binned likelihoods say yes
 
     def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
         super().__init__(pdf_base_config, likelihood_config, **kwargs)
@@ -332,11 +342,10 @@ class DeviceLogLikelihood(LogLikelihoodBase):
 
     def _call_with_fresh_pdf(self, livetime_days, full_output, kwargs):
         """compute_pdf=True: build the model AT the requested settings instead of morphing
-        (likelihood.py:331-335,611-616) and evaluate it through a scratch d=0 device model."""
-        prior, zs, scale = self._host_terms(livetime_days, kwargs)
-        if prior is None:
-            return -float('inf')
+        (likelihood.py:331-335,611-616) and evaluate it through a scratch d=0 device model.  As in the reference
+        this works outside the anchor box too and leaves the shape priors out."""
         model = self._compute_single_model(**kwargs)
+        prior, zs, scale = self._host_terms(livetime_days, kwargs, morph=False, mus_of=model.expected_events)
         ps, n_mc = self._rows_of(model)
         bb = self._bb_source_index()
         scratch = DeviceContext(self.ctx.device)
@@ -349,9 +358,15 @@ class DeviceLogLikelihood(LogLikelihoodBase):
             if full_output:
                 ll, mus, ps_out, st = scratch.eval_full(None, scale)
                 ll = self._interpret(ll, st, mus)
+                if ll == -float('inf') and st:
+                    return ll
                 return prior + ll, mus, ps_out.reshape(ps.shape)
             ll, st = scratch.eval(None, scale[None, :])
-            return prior + self._interpret(float(ll[0]), int(st[0]), model.expected_events() * scale)
+            ll, st = float(ll[0]), int(st[0])
+            if st:
+                ll0 = self._interpret(ll, st, model.expected_events() * scale)
+                return ll0 if ll0 == -float('inf') else prior + ll0
+            return prior + ll
         finally:
             scratch.close()
 
@@ -385,6 +400,10 @@ class DeviceLogLikelihood(LogLikelihoodBase):
             if base == 0:
                 if livetime_days != 0:
                     raise ValueError("Cannot scale from 0 to non-0 livetime")
+                lo_hi = [self.get_bounds(n) for n in self.shape_parameters]
+                for zi, sc in zip(z, scale):        # likelihood.py:380, per point; points outside the box return -inf first
+                    if all(lo <= v <= hi for v, (lo, hi) in zip(zi, lo_hi)):
+                        assert np.all(self.ctx.interpolate('mus', zi) * sc == 0), "Got non-0 mus with 0 livetime?!"
             else:
                 scale = scale * (livetime_days / base)
         if True in self.source_apply_efficiency:
@@ -513,6 +532,11 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
             return 0.0
         h = 1e-6 * max(1.0, abs(x))
         return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
+
+    @property
+    def supports_gradient(self):
+        """bi_eval_grad exists for plain binned likelihoods (not with Beeston-Barlow: mu then depends on the data)."""
+        return self.model_statistical_uncertainty_handling is None
 
     @_needs_data
     def value_and_gradient(self, livetime_days=None, **kwargs):
@@ -655,9 +679,17 @@ class LogLikelihoodSum:
             total = total + weight * ll.eval_points({k: v for k, v in points.items() if k in names}, livetime_days=lt)
         return total
 
+    @property
+    def supports_gradient(self):
+        """True when every term can return an analytic gradient (binned terms without Beeston-Barlow);
+        `bestfit_scipy(use_gradient=True)` falls back to numerical differences otherwise."""
+        return all(getattr(ll, 'supports_gradient', False) for ll in self.likelihood_list)
+
     def value_and_gradient(self, livetime_days=None, **kwargs):
         """-> (ll, OrderedDict name -> d ll / d parameter): the weighted sum of the terms' values and gradients
         (one device pass per term); lets `bestfit_scipy(use_gradient=True)` work on a sum."""
+        if not self.supports_gradient:
+            raise NotImplementedError("a term of this sum has no analytic gradient (unbinned or Beeston-Barlow)")
         total, grads = 0., OrderedDict()
         for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights)):
             lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days

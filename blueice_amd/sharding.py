@@ -2,8 +2,9 @@
 
 The path partitions by evaluation (toy datasets, scan points): one process per GPU, every rank holds a
 replica of the anchor tensor, no data-path collective; the only exchange is ONE gather of the fp64 result
-vector at the end (`torch.distributed.all_gather` -- RCCL over xGMI with the 'nccl' backend and device
-tensors, gloo with host tensors).  A single sequential fit does not shard (replicas only).
+vector at the end, through a communicator of blueice_amd.comm (RCCL over xGMI bound directly, or loopback
+sockets for CPU rehearsals; anything with the same five methods works -- the tests also plug in
+torch.distributed's gloo).  A single sequential fit does not shard (replicas only).
 
 The reference has no counterpart: its scans are Python loops over `lf(**kw)`
 (blueice/inference.py:49-50,424-432).
@@ -11,7 +12,7 @@ The reference has no counterpart: its scans are Python loops over `lf(**kw)`
 import numpy as np
 
 __all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys',
-           'allreduce_sum', 'bin_sharded_eval']
+           'sharded_scan_device', 'allreduce_sum', 'bin_sharded_eval']
 
 
 def split_range(n, rank, world):
@@ -65,72 +66,110 @@ def deal_points_by_cell(anchor_z, z, world):
     return [np.concatenate(m) if m else np.zeros(0, dtype=np.int64) for m in mine]
 
 
-def gather_vector(local, counts, dist=None, device=None):
-    """all_gather of per-rank fp64 vectors of (known) unequal lengths `counts` -> list of numpy arrays.
-    `dist` = torch.distributed (already initialised) or None for a single process."""
+def _world(comm):
+    return (comm.rank, comm.world) if comm is not None else (0, 1)
+
+
+def gather_vector(local, counts, comm=None):
+    """all_gather of per-rank fp64 vectors of (known) unequal lengths `counts` -> list of numpy arrays."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    rank, world = _world(comm)
+    if world == 1:
         return [local]
-    import torch
-    world = dist.get_world_size()
     n_max = max(int(c) for c in counts)
-    dev = device if device is not None else ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
-    buf = torch.zeros(n_max, dtype=torch.float64, device=dev)
-    buf[:len(local)] = torch.from_numpy(local).to(dev)
-    parts = [torch.empty(n_max, dtype=torch.float64, device=dev) for _ in range(world)]
-    dist.all_gather(parts, buf)                                # the one collective of the path
-    return [p[:int(c)].cpu().numpy() for p, c in zip(parts, counts)]
+    buf = np.zeros(max(n_max, 1))
+    buf[:len(local)] = local
+    parts = comm.all_gather(buf)                                   # the one collective of the path
+    return [np.array(p[:int(c)]) for p, c in zip(parts, counts)]
 
 
-def sharded_eval_points(eval_fn, anchor_z, z, rate_scale, dist=None):
-    """Evaluate P points across the ranks of `dist` and return the full ll [P] on every rank.
+def sharded_eval_points(eval_fn, anchor_z, z, rate_scale, comm=None):
+    """Evaluate P points across the ranks of `comm` and return the full ll [P] on every rank.
     eval_fn(z_local [n, d], rate_local [n, S]) -> ll [n]  (e.g. `lambda z, r: ctx.eval(z, r)[0]`)."""
     z = np.atleast_2d(np.asarray(z, dtype=float))
     rate_scale = np.atleast_2d(np.asarray(rate_scale, dtype=float))
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    rank, world = _world(comm)
     deal = deal_points_by_cell(anchor_z, z, world)
     mine = deal[rank]
     local = np.asarray(eval_fn(z[mine], rate_scale[mine]), dtype=np.float64) if len(mine) else np.zeros(0)
-    parts = gather_vector(local, [len(d) for d in deal], dist)
+    parts = gather_vector(local, [len(d) for d in deal], comm)
     out = np.empty(len(z))
     for idx, vals in zip(deal, parts):
         out[idx] = vals
     return out
 
 
-def sharded_eval_toys(eval_range_fn, T, dist=None):
+def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
+    """The same with nothing but the final vector leaving HBM: this rank's share of the points is planned once,
+    `bi_run_plan` writes into a device buffer, RCCL gathers the buffers of all ranks on the context's stream and the
+    gathered [world, n_max] block crosses PCIe once.  -> (ll [P] on every rank, run) where run() repeats the
+    evaluation + gather on the resident plan (for timing) and returns ll again.
+    `comm` must offer all_gather_device (blueice_amd.comm.RcclCommunicator); other communicators take the host
+    route of sharded_eval_points."""
+    z = np.atleast_2d(np.asarray(z, dtype=float))
+    rate_scale = np.atleast_2d(np.asarray(rate_scale, dtype=float))
+    rank, world = _world(comm)
+    deal = deal_points_by_cell(ctx.anchor_z, z, world)
+    mine = deal[rank]
+    n_max = max(max(len(d) for d in deal), 1)
+    plan = ctx.plan(z[mine], rate_scale[mine], dataset) if len(mine) else None
+    device_path = world > 1 and hasattr(comm, 'all_gather_device')
+    send = ctx.device_alloc(8 * n_max) if device_path else None
+    recv = ctx.device_alloc(8 * n_max * world) if device_path else None
+    if send is not None:
+        send.from_host(np.zeros(n_max))
+
+    def run():
+        if device_path:
+            if plan is not None:
+                plan.run(send.ptr)
+            comm.all_gather_device(send.ptr, recv.ptr, n_max)
+            parts = recv.to_host(np.float64, n_max * world).reshape(world, n_max)
+            parts = [p[:len(d)] for p, d in zip(parts, deal)]
+        else:
+            local = np.zeros(0)
+            if plan is not None:
+                plan.run()
+                local = plan.read()[0]
+            parts = gather_vector(local, [len(d) for d in deal], comm)
+        out = np.empty(len(z))
+        for idx, vals in zip(deal, parts):
+            out[idx] = vals
+        return out
+
+    return run(), run
+
+
+def sharded_eval_toys(eval_range_fn, T, comm=None):
     """Toy-MC form: datasets [0, T) split contiguously over ranks; eval_range_fn(t0, t1) -> ll [t1 - t0]
     for the datasets this rank holds.  Returns ll [T] on every rank."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    rank, world = _world(comm)
     ranges = [split_range(T, r, world) for r in range(world)]
     t0, t1 = ranges[rank]
     local = np.asarray(eval_range_fn(t0, t1), dtype=np.float64) if t1 > t0 else np.zeros(0)
-    return np.concatenate(gather_vector(local, [b - a for a, b in ranges], dist))
+    return np.concatenate(gather_vector(local, [b - a for a, b in ranges], comm))
 
 
-def allreduce_sum(local, dist=None):
+def allreduce_sum(local, comm=None):
     """Element-wise sum of an fp64 vector over the ranks (identity for a single process)."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         return local
-    import torch
-    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-    t = torch.from_numpy(local.copy()).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy()
+    return comm.all_reduce(local, 'sum')
 
 
-def bin_sharded_eval(ctx, z, rate_scale, dist=None):
+def bin_sharded_eval(ctx, z, rate_scale, comm=None):
     """The one configuration with a real exchange step: an anchor tensor too large for
     one GPU is sharded over the BIN axis -- `ctx` holds this rank's slice of the bins of every template row and
     of the data -- every rank evaluates all P points on its slice, and the partial log likelihoods are summed
     with ONE all-reduce of P doubles.  Everything in the likelihood is additive over bins; the only global
     quantity, the Beeston-Barlow normalisation sum_b n_model[bb, b], is all-reduced once per model
-    (`ctx.bb_totals`) before the first evaluation."""
+    (`ctx.bb_totals`) before the first evaluation.  The status bits (Beeston-Barlow assertions, unphysical
+    rates) are OR-ed over the ranks: a flag raised on any bin slice is a flag of the point."""
     if ctx.bb_source >= 0 and not getattr(ctx, '_bb_totals_global', False):
-        ctx.bb_totals(allreduce_sum(ctx.bb_totals(), dist))
+        ctx.bb_totals(allreduce_sum(ctx.bb_totals(), comm))
         ctx._bb_totals_global = True
     ll, status = ctx.eval(z, rate_scale)
-    return allreduce_sum(ll, dist), status
+    if comm is not None and comm.world > 1:
+        status = comm.all_reduce(status.astype(np.int64), 'bor').astype(np.int32)
+    return allreduce_sum(ll, comm), status

@@ -139,12 +139,30 @@ class SyntheticModel:
         return z, r
 
     # -- consumers -------------------------------------------------------------------------
-    def upload(self, ctx):
-        """Stream the model to a DeviceContext one anchor at a time (pdf_morphers.py:62-65 loop)."""
+    def upload(self, ctx, threads=1):
+        """Stream the model to a DeviceContext one anchor at a time (pdf_morphers.py:62-65 loop); with threads > 1
+        the anchor blocks are generated by a small pool a few anchors ahead of the upload (numpy's generators
+        release the interpreter lock), so nothing of tensor size ever exists on the host."""
+        bb = self.bb_source >= 0
+
+        def block(a):
+            return self.anchor_ps(a), self.anchor_mus(a), self.anchor_n_model(a) if bb else None
+
         ctx.begin_model(self.anchor_z, self.S, self.B, bb_source=self.bb_source)
-        for a in range(self.A):
-            ctx.set_anchor(a, self.anchor_ps(a), self.anchor_mus(a),
-                           self.anchor_n_model(a) if self.bb_source >= 0 else None)
+        if threads <= 1 or self.A == 1:
+            for a in range(self.A):
+                ctx.set_anchor(a, *block(a))
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(int(threads)) as pool:
+                pending = [pool.submit(block, a) for a in range(min(int(threads), self.A))]
+                nxt = len(pending)
+                for a in range(self.A):
+                    ps, mus, nm = pending.pop(0).result()
+                    if nxt < self.A:
+                        pending.append(pool.submit(block, nxt))
+                        nxt += 1
+                    ctx.set_anchor(a, ps, mus, nm)
         ctx.end_model()
 
     def cell_model(self, z):

@@ -164,6 +164,10 @@ int bi_eval_grad(bi_ctx* ctx, int64_t P, const double* z, const double* rate_sca
  * Beeston-Barlow (mu then depends on the data).  out [t1 - t0]. */
 int bi_eval_datasets(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
                      double* out, int32_t* status /*[1] or NULL*/);
+/* the same with the results left in HBM (out_dev: t1 - t0 doubles of device memory, e.g. the send buffer of the
+ * gather that ends a toy-MC run sharded over GPUs); returns when the kernels have finished */
+int bi_eval_datasets_device(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
+                            double* out_dev, int32_t* status /*[1] or NULL*/);
 
 /* ---- compatibility mode: materialise what the morpher closures return ---------------------
  * `ps_interpolator(zs)` / `mus_interpolator(zs)` / `n_model_events_interpolator(zs)`
@@ -190,6 +194,15 @@ int64_t bi_plan_launches(const bi_plan* plan); /* morph+reduce launches per bi_r
 void bi_plan_destroy(bi_ctx* ctx, bi_plan* plan);
 int bi_sync(bi_ctx* ctx);
 void* bi_stream(bi_ctx* ctx); /* the hipStream_t the context launches on */
+
+/* Plain device buffers on the context's GPU, for callers that keep results in HBM between bi_run_plan and a
+ * collective (the per-rank result vectors that RCCL gathers over xGMI at the end of a sharded scan: SURVEY.md
+ * section 8e; the reference has no counterpart, its scans are Python loops, blueice/inference.py:424-432).
+ * The copies run on the context stream and return when the data has arrived. */
+int bi_device_alloc(bi_ctx* ctx, int64_t bytes, void** out);
+int bi_device_free(bi_ctx* ctx, void* p);
+int bi_memcpy_to_host(bi_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+int bi_memcpy_to_device(bi_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 
 /* self-test of the device logarithm used in the per-bin terms: out[i] = log(x[i]) as the kernels compute it */
 int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
@@ -221,6 +234,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   scan_mfma, scan_min_items, scan_cb, scan_waves_per_cu   the matrix-core scan kernel: on/off, items per cell from
  *                     which it is used (4; x2 for dense data), strip width (0 = by the data), launch width
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
+ *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
+ *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
  * read-only: tile_bins, padded_bins, n_scan_launches, csr_ready, compact_ready, ps_nonneg, nnz_total */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
 int64_t bi_get_param(bi_ctx* ctx, const char* name);

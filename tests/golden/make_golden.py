@@ -29,6 +29,8 @@ Each fixture `<case>.npz` holds
     call_asserts_<j>                present when the reference raised AssertionError on call j
     full_<j>_mus / full_<j>_ps      `full_output=True` results for call j (a few calls)
 fit_c1_like.npz additionally holds bestfit_scipy results (names, values, max logL).
+api_<case>.npz (model_zoo.API_CASES: compute_pdf, priors, zero live time) hold only call_ll [N] and call_error [N]
+(exception class name or '') -- those calls are not functions of the anchor tensors alone.
 """
 import os
 
@@ -158,6 +160,20 @@ def fit_goldens(ns):
     print('fit_c1_like', dict(zip(t['fit_all_names'], t['fit_all_values'])), t['fit_all_ll'])
 
 
+def dump_api(name, lf, calls):
+    """Return values / exception names of calls that are not functions of the anchor tensors alone."""
+    lls, errs = [], []
+    for kw in calls:
+        try:
+            lls.append(float(lf(**kw)))
+            errs.append('')
+        except (AssertionError, ValueError, NotImplementedError) as e:
+            lls.append(np.nan)
+            errs.append(type(e).__name__)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), call_ll=np.array(lls), call_error=np.array(errs))
+    print('%-28s calls=%d  %s' % (name, len(calls), [e or round(v, 6) for v, e in zip(lls, errs)]))
+
+
 if __name__ == '__main__':
     import scipy
     print('reference blueice', blueice.__version__, 'numpy', np.__version__, 'scipy', scipy.__version__)
@@ -165,4 +181,7 @@ if __name__ == '__main__':
     for name, builder in list(model_zoo.CASES.items()) + list(model_zoo.UNBINNED_CASES.items()):
         lf, calls, full = builder(ns)
         dump(name, lf, calls, full)
+    for name, builder in model_zoo.API_CASES.items():
+        lf, calls = builder(ns)
+        dump_api(name, lf, calls)
     fit_goldens(ns)

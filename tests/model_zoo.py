@@ -407,7 +407,92 @@ def unb_no_events(ns):
     return lf, [{}, dict(some_multiplier=1.5, s0_rate_multiplier=2.)], ()
 
 
-UNBINNED_CASES = OrderedDict((f.__name__, f) for f in (unb_ref_value, unb_shape_2src, unb_d0_three_sources, unb_no_events))
+_holey_cache = {}
+
+
+def holey_gaussian_class(ns):
+    """GaussianSource whose pdf is nan beyond `nan_beyond` sigmas (a density estimate that gives up in its tails):
+    extended_loglikelihood drops such terms with np.nansum (blueice/likelihood.py:686)."""
+    key = ns.GaussianSource
+    if key not in _holey_cache:
+        class HoleyGaussianSource(ns.GaussianSource):
+            def pdf(self, *args):
+                p = np.asarray(super().pdf(*args), dtype=float).copy()
+                x = np.asarray(args[0], dtype=float)
+                cut = self.config.get('nan_beyond')
+                if cut is not None:
+                    p[np.abs(x - self.config['mu']) > cut * self.config['sigma']] = np.nan
+                return p
+        _holey_cache[key] = HoleyGaussianSource
+    return _holey_cache[key]
+
+
+def unb_nan_pdf(ns):
+    """Sources whose pdf is nan at some events, for some anchors only: np.nansum semantics of the unbinned
+    likelihood (an event all of whose sources are nan gets the outlier likelihood)."""
+    rng = np.random.default_rng(33)
+    conf = ns.conf_for_test(n_sources=3, events_per_day=12., default_source_class=holey_gaussian_class(ns))
+    conf['sources'] = [dict(name='a', mu=-1., nan_beyond=2.0), dict(name='b', mu=1.5, sigma=0.8, nan_beyond=2.5),
+                       dict(name='c', mu=0., sigma=3., events_per_day=4.)]
+    lf = ns.UnbinnedLogLikelihood(conf)
+    for n in 'abc':
+        lf.add_rate_parameter(n)
+    lf.add_shape_parameter('sigma', (0.7, 1., 1.6))
+    lf.prepare()
+    xs = np.concatenate([rng.normal(-1., 1.2, 25), rng.normal(1.5, 0.9, 15), [-4.4, 5.9, 0.2, 9.5, -9.]])
+    lf.set_data(_events(xs))
+    calls = [{}, dict(sigma=0.7), dict(sigma=1.6), dict(sigma=1.3), dict(sigma=0.85, a_rate_multiplier=2., c_rate_multiplier=0.),
+             dict(sigma=1.0, b_rate_multiplier=0.), dict(sigma=1.45, c_rate_multiplier=0., b_rate_multiplier=1.7)]
+    return lf, calls, (3,)
+
+
+UNBINNED_CASES = OrderedDict((f.__name__, f) for f in (unb_ref_value, unb_shape_2src, unb_d0_three_sources, unb_no_events,
+                                                       unb_nan_pdf))
+
+
+# ---------------------------------------------------------------------------------------------
+# API cases: calls whose result is not a function of the anchor tensors alone (compute_pdf builds a model at the
+# point; priors; raised errors).  Goldens hold the reference's return values / exception names only
+# (tests/golden/api_<name>.npz) and are compared through the drop-in API on the GPU.
+# ---------------------------------------------------------------------------------------------
+def api_compute_pdf(ns):
+    """compute_pdf=True in and OUTSIDE the anchor box, with a shape prior and a rate prior: the reference builds the
+    model at the point, applies no bounds test and adds only the rate priors (blueice/likelihood.py:331-335,366-371)."""
+    from scipy import stats
+    rng = np.random.default_rng(51)
+    space = [['x', np.linspace(-4, 4, 17)], ['y', np.linspace(0, 5, 6)]]
+    lf = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.), stretch=(0., 1.)), 3000, 250)
+    lf.rate_parameters['s1'] = stats.norm(1, 0.3).logpdf
+    lf.shape_parameters['shift'] = (lf.shape_parameters['shift'][0], stats.norm(0, 0.5).logpdf, None)
+    calls = [dict(shift=0.4, stretch=0.3), dict(compute_pdf=True, shift=0.4, stretch=0.3),
+             dict(compute_pdf=True, shift=1., stretch=1.), dict(shift=1., stretch=1.),
+             dict(compute_pdf=True, shift=1.4, stretch=0.5),                      # outside the box: finite
+             dict(shift=1.4, stretch=0.5),                                        # ... -inf when interpolating
+             dict(compute_pdf=True, shift=-1.7, stretch=1.3, s1_rate_multiplier=0.8, s0_rate_multiplier=1.2),
+             dict(compute_pdf=True, shift=0.2, stretch=0.9, s1_rate_multiplier=-0.5),   # unphysical
+             dict(compute_pdf=True)]
+    return lf, calls
+
+
+def api_livetime_zero(ns):
+    """Base live time 0 (blueice/likelihood.py:374-380): scaling 0 -> 0 is allowed (all rates are 0), 0 -> non-0
+    raises ValueError."""
+    rng = np.random.default_rng(52)
+    space = [['x', np.linspace(-3, 3, 7)]]
+    lf = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 1500, 0, livetime=0.)
+    calls = [dict(livetime_days=0.), dict(livetime_days=0., shift=0.3, s0_rate_multiplier=2.), dict(shift=0.5),
+             dict(livetime_days=2.), dict(livetime_days=0., shift=1.5)]
+    return lf, calls
+
+
+def api_livetime_zero_with_data(ns):
+    rng = np.random.default_rng(53)
+    space = [['x', np.linspace(-3, 3, 7)]]
+    lf = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 1500, 40, livetime=0.)
+    return lf, [dict(livetime_days=0.), dict(shift=-0.2), dict(livetime_days=1e-3)]
+
+
+API_CASES = OrderedDict((f.__name__, f) for f in (api_compute_pdf, api_livetime_zero, api_livetime_zero_with_data))
 
 CASES = OrderedDict((f.__name__, f) for f in (
     ref_single_bin, ref_zero_bin, ref_multi_bin_single_dim, ref_multi_bin, ref_bb_single_bin,

@@ -54,6 +54,47 @@ def test_lf_calls_match_reference(ns, name):
             assert same(b, scalar[j], 1e-12), (name, j, b, scalar[j])
 
 
+@pytest.mark.parametrize('name', list(model_zoo.API_CASES))
+def test_api_cases_match_reference(ns, name):
+    """Calls that are not functions of the anchor tensors alone -- compute_pdf (in and outside the anchor box, with
+    priors), zero live time -- against what the reference returned or raised (tests/golden/api_*.npz)."""
+    lf, calls = model_zoo.API_CASES[name](ns)
+    f = np.load(GOLDEN_DIR + '/%s.npz' % name)
+    assert len(calls) == len(f['call_ll'])
+    errors = {'ValueError': ValueError, 'AssertionError': AssertionError, 'NotImplementedError': NotImplementedError}
+    for j, kw in enumerate(calls):
+        err = str(f['call_error'][j])
+        if err:
+            with pytest.raises(errors[err]):
+                lf(**kw)
+            continue
+        ll = lf(**kw)
+        assert same(ll, f['call_ll'][j], RTOL), (name, j, kw, ll, f['call_ll'][j])
+    if name.startswith('api_livetime_zero'):
+        pts = lf.eval_points(dict(shift=[0.3, -0.5, 1.5]), livetime_days=0.)
+        want = 0.0 if name == 'api_livetime_zero' else -np.inf
+        assert pts[0] == want and pts[1] == want and pts[2] == -np.inf
+        with pytest.raises(ValueError):
+            lf.eval_points(dict(shift=[0.3]), livetime_days=1.)
+
+
+def test_gradient_fit_falls_back_without_gradient_support(ns):
+    """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (Beeston-Barlow terms, a sum
+    containing one) must take the numerical route instead of failing mid-fit."""
+    from blueice_amd import LogLikelihoodSum
+    bb, _, _ = model_zoo.bb_two_shape(ns)
+    plain, _, _ = model_zoo.c1_like(ns)
+    assert plain.supports_gradient and not bb.supports_gradient
+    total = LogLikelihoodSum([plain, bb])
+    assert not total.supports_gradient and LogLikelihoodSum([plain, plain]).supports_gradient
+    with pytest.raises(NotImplementedError):
+        total.value_and_gradient()
+    fixed = dict(strlen_multiplier=2, dummy=0.5)
+    a = total.bestfit_scipy(use_gradient=True, **fixed)
+    b = total.bestfit_scipy(**fixed)
+    assert same(a[1], b[1], 1e-9)
+
+
 def test_reference_binned_tests_verbatim(ns):
     """tests/test_binned_likelihood.py::test_single_bin / test_multi_bin of the reference,
     with the reference's own assertions (closed-form scipy expectations)."""

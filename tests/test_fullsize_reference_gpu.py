@@ -1,0 +1,170 @@
+"""Full-size parity against numbers produced by the REAL reference (tests/golden/fullsize.json, made by
+tests/golden/make_golden_fullsize.py in the development container: blueice's own BinnedLogLikelihood prepared at
+BASELINE.json's sizes through a plug-in Source, blueice/likelihood.py:318-427 + blueice/source.py:266-267), and the
+BASELINE.json configurations at their STATED sizes: 10^4 toys (configs[2]), 10^6 scan points (configs[3]), the
+625-anchor Beeston-Barlow model with 50^4 bins (configs[4]).  Tolerance: |device - reference| <= 1e-10 max(1, |ref|)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(name):
+    with open(os.path.join(HERE, 'golden', 'fullsize.json')) as f:
+        return json.load(f)['cases'][name]
+
+
+def _check_inputs(m, case):
+    """The synthetic tensors regenerated here must be the ones the reference saw (same numpy random streams)."""
+    ck = case['checks']
+    a0 = m.anchor_ps(0)
+    assert [float(v) for v in a0[0, :3]] == ck['ps_anchor0_first'] and float(a0.sum()) == ck['ps_anchor0_sum']
+    assert [float(v) for v in m.anchor_mus(0)] == ck['mus_anchor0']
+    if m.bb_source >= 0:
+        assert float(m.anchor_n_model(0).sum()) == ck['n_model_anchor0_sum']
+
+
+def _compare(ctx, m, case, modes):
+    for dense in (False, True):
+        key = 'dense' if dense else 'sparse'
+        counts = m.counts(dense=dense)
+        assert float(counts.sum()) == case['checks']['counts_%s_sum' % key]
+        assert int(np.count_nonzero(counts)) == case['checks']['counts_%s_nonzero' % key]
+        calls = [c for c in case['calls'] if c['data'] == key]
+        assert len(calls) >= 3
+        z = np.array([c['z'] for c in calls])
+        r = np.array([c['mult'] for c in calls])
+        for sparse in modes:
+            ctx.set_param('sparse', sparse)
+            ctx.upload_counts(counts)
+            batch, bst = ctx.eval(z, r)
+            for j, c in enumerate(calls):
+                assert not c['reference_asserted']
+                one, st = ctx.eval(z[j], r[j])
+                for got in (one[0], batch[j]):
+                    assert abs(got - c['ll']) <= RTOL * max(1.0, abs(c['ll'])), (key, sparse, c['label'], got, c['ll'])
+                assert st[0] == 0 and bst[j] == 0
+
+
+@pytest.fixture(scope='module')
+def c2():
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('C2')
+    ctx = DeviceContext(0)
+    m.upload(ctx, threads=8)
+    yield m, ctx
+    ctx.close()
+
+
+def test_c2_equals_the_reference_at_full_size(c2):
+    """configs[1]: every kernel path (single-point, batched, non-empty-bin form) against the reference's lf(**kw)
+    at an off-grid point, an anchor corner, the top edge, a switched-off source and an interior anchor plane."""
+    m, ctx = c2
+    case = _golden('C2')
+    _check_inputs(m, case)
+    _compare(ctx, m, case, modes=(0, 1))
+    ctx.set_param('sparse', 1)
+
+
+def test_c5_cell_beeston_barlow_equals_the_reference():
+    """One grid cell of configs[4] (2^4 anchors, 6 sources, 50^4 bins, Beeston-Barlow on source 0: all 113 streams of
+    an evaluation) against the reference's adjust_expectations + _compute_likelihood (blueice/likelihood.py:618-675)."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('C5-2anchor', bb_source=0)
+    case = _golden('C5-2anchor')
+    _check_inputs(m, case)
+    ctx = DeviceContext(0)
+    m.upload(ctx, threads=8)
+    _compare(ctx, m, case, modes=(0,))
+    ctx.close()
+
+
+def test_c3_ten_thousand_toys(c2):
+    """configs[2] at its stated size: 10^4 toy datasets drawn on the device and evaluated by one call; 8 of them are
+    fetched back and checked against the oracle, and the per-dataset point form agrees on a sample."""
+    from oracle import blueice_oracle as orc
+    m, ctx = c2
+    T = 10000
+    z, r = m.default_point()
+    ctx.set_param('sparse', 1)
+    ctx.generate_toys(z, r, T, seed=2024)
+    z_eval = np.clip(z + 0.04, -2, 2)
+    ll, st = ctx.eval_datasets(z_eval, r)
+    assert st == 0 and ll.shape == (T,) and np.all(np.isfinite(ll))
+    cell = m.cell_model(z_eval)
+    picks = [0, 1, 17, 2500, 4999, 5000, 7777, T - 1]
+    for t in picks:
+        counts = ctx.download_counts(t)
+        assert 8000 < counts.sum() < 12000 and np.all(counts == np.floor(counts))
+        want = orc.loglikelihood(cell, counts, z_eval, r)
+        assert abs(ll[t] - want) <= RTOL * abs(want), (t, ll[t], want)
+    buf = ctx.device_alloc(8 * T)
+    assert ctx.eval_datasets_device(buf.ptr, z_eval, r) == 0
+    np.testing.assert_array_equal(buf.to_host(), ll)           # results left in HBM for the gather: same numbers
+    buf.free()
+    pts, pst = ctx.eval(np.tile(z_eval, (len(picks), 1)), np.tile(r, (len(picks), 1)), dataset=np.array(picks))
+    np.testing.assert_allclose(pts, ll[picks], rtol=1e-12)
+    assert not pst.any()
+
+
+@pytest.mark.parametrize('sparse', [1, 0])
+def test_c4_million_point_scan(c2, sparse):
+    """configs[3] on one GPU: 10^6 parameter points over the C2 model in one call (device planner; non-empty-bin form,
+    and every bin visited on the matrix-core scan kernel); 8 points checked against the oracle, -inf outside the box."""
+    from oracle import blueice_oracle as orc
+    m, ctx = c2
+    P = 10 ** 6
+    counts = m.counts()
+    ctx.set_param('sparse', sparse)
+    ctx.upload_counts(counts)
+    z, r = m.random_points(P, seed=31)
+    z[123456, 1] = 2.5                        # outside the anchor box
+    r[654321, 2] = -0.5                       # unphysical rate
+    before = ctx.get_param('n_scan_launches')
+    ll, st = ctx.eval(z, r)
+    if not sparse:
+        assert ctx.get_param('n_scan_launches') == before + 1        # the matrix-core kernel took it
+    assert ll[123456] == -np.inf and st[123456] == 1 and ll[654321] == -np.inf and st[654321] == 2
+    ok = np.ones(P, bool)
+    ok[[123456, 654321]] = False
+    assert np.all(np.isfinite(ll[ok])) and not st[ok].any()
+    for i in (0, 1, 99999, 250000, 500000, 750001, 999998, P - 1):
+        want = orc.loglikelihood(m.cell_model(z[i]), counts, z[i], r[i])
+        assert abs(ll[i] - want) <= RTOL * abs(want), (sparse, i, ll[i], want)
+    ctx.set_param('sparse', 1)
+
+
+def test_c5_all_625_anchor_models():
+    """configs[4] at its stated size on ONE GPU: 625 anchor models x 6 sources x 50^4 bins (187.5 GB of templates +
+    31 GB of MC counts resident in HBM), Beeston-Barlow; one evaluation = one 5.65 GB pass, checked against the
+    oracle on the 16 corner models of the point's cell."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('C5', bb_source=0)
+    ctx = DeviceContext(0)
+    if ctx.info()['hbm_bytes'] < 240e9:
+        ctx.close()
+        pytest.skip("needs 219 GB of HBM")
+    m.upload(ctx, threads=14)
+    counts = m.counts(dense=True)
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(counts)
+    z, r = m.random_points(2, seed=2)
+    got, st = ctx.eval(z, r)
+    assert not st.any()
+    want = orc.loglikelihood(m.cell_model(z[0]), counts, z[0], r[0], bb_source=0)
+    assert abs(got[0] - want) <= RTOL * abs(want), (got[0], want)
+    one, _ = ctx.eval(z[1], r[1])
+    assert abs(one[0] - got[1]) <= 1e-13 * abs(one[0])
+    plan = ctx.plan(z[:1], r[:1])
+    assert plan.bytes == 8 * (16 * 6 + 16 + 1) * m.B
+    plan.close()
+    ctx.close()

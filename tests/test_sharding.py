@@ -1,6 +1,8 @@
-"""The N > 1 path on CPU: two gloo ranks shard a scan / a toy-MC batch, evaluate their share (with the
-CPU oracle standing in for the device -- tests may use it as the checker) and gather; the result must
-equal the single-process evaluation, and the dealing must keep cells together and balanced."""
+"""The N > 1 path on CPU: two ranks shard a scan / a toy-MC batch, evaluate their share (with the CPU oracle
+standing in for the device -- tests may use it as the checker) and gather; the result must equal the
+single-process evaluation, and the dealing must keep cells together and balanced.  Run over both transports: the
+package's own loopback-socket communicator (blueice_amd.comm, also the bootstrap channel of the RCCL one) and
+torch.distributed's gloo behind the same interface (tests/comm_adapters.py)."""
 import os
 import socket
 import sys
@@ -54,15 +56,23 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _comm(kind, rank, world, port, rdzv):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      BLUEICE_AMD_RDZV=rdzv)
+    if kind == 'gloo':
+        from comm_adapters import GlooCommunicator
+        return GlooCommunicator(rank, world)
+    from blueice_amd.comm import connect
+    return connect(backend='socket')
+
+
+def _worker(kind, rank, world, port, rdzv, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
     from blueice_amd.sharding import sharded_eval_points, sharded_eval_toys
     from blueice_amd.synthetic import SyntheticModel
     from oracle import blueice_oracle as orc
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    comm = _comm(kind, rank, world, port, rdzv)
     try:
         m = SyntheticModel.named('mini3')
         dense = m.dense_model()
@@ -74,31 +84,40 @@ def _worker(rank, world, port, q):
             calls.append(len(zz))
             return orc.loglikelihood_batch(dense, counts, zz, rr)
 
-        ll = sharded_eval_points(eval_fn, m.anchor_z, z, r, dist)
+        ll = sharded_eval_points(eval_fn, m.anchor_z, z, r, comm)
         toys = np.stack([m.counts(dense=True, dataset=t) for t in range(5)])
         z0, r0 = m.default_point()
         lt = sharded_eval_toys(lambda a, b: orc.loglikelihood_batch(dense, toys, np.tile(z0, (b - a, 1)),
                                                                      np.tile(r0, (b - a, 1)), dataset=np.arange(a, b)),
-                               5, dist)
-        q.put((rank, ll, lt, sum(calls)))
+                               5, comm)
+        mx = comm.all_reduce(np.array([float(rank), -float(rank)]), 'max')
+        bits = comm.all_reduce(np.array([1 << rank, 0], dtype=np.int64), 'bor')
+        q.put((rank, ll, lt, sum(calls), mx, bits, comm.broadcast_bytes(b'id-of-rank-0' if rank == 0 else None)))
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_gloo_ranks_equal_single_process():
-    import torch.multiprocessing as mp
-    from blueice_amd.synthetic import SyntheticModel
-    from oracle import blueice_oracle as orc
+def _run_ranks(target, kind, world, tmp_path):
+    import multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    rdzv = str(tmp_path / ('rdzv_%s' % kind))
+    procs = [ctx.Process(target=target, args=(kind, r, world, port, rdzv, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize('kind', ['socket', 'gloo'])
+def test_two_ranks_equal_single_process(kind, tmp_path):
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    got = _run_ranks(_worker, kind, 2, tmp_path)
     m = SyntheticModel.named('mini3')
     dense, counts = m.dense_model(), m.counts(dense=True)
     z, r = m.random_points(37, seed=2)
@@ -107,20 +126,36 @@ def test_two_gloo_ranks_equal_single_process():
     z0, r0 = m.default_point()
     want_t = orc.loglikelihood_batch(dense, toys, np.tile(z0, (5, 1)), np.tile(r0, (5, 1)), dataset=np.arange(5))
     assert sorted(g[0] for g in got) == [0, 1]
-    for rank, ll, lt, n_eval in got:
+    for rank, ll, lt, n_eval, mx, bits, blob in got:
         np.testing.assert_array_equal(ll, want)            # every rank holds the full gathered vector
         np.testing.assert_array_equal(lt, want_t)
         assert 17 <= n_eval <= 20                          # each rank evaluated about half of the 37 points
+        np.testing.assert_array_equal(mx, [1., 0.])
+        np.testing.assert_array_equal(bits, [3, 0])
+        assert blob == b'id-of-rank-0'
 
 
-def _bins_worker(rank, world, port, q):
+def test_three_socket_ranks(tmp_path):
+    """An odd world size through the package's own communicator (unequal shares, star gather)."""
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    got = _run_ranks(_worker, 'socket', 3, tmp_path)
+    m = SyntheticModel.named('mini3')
+    z, r = m.random_points(37, seed=2)
+    want = orc.loglikelihood_batch(m.dense_model(), m.counts(dense=True), z, r)
+    assert sorted(g[0] for g in got) == [0, 1, 2]
+    for g in got:
+        np.testing.assert_array_equal(g[1], want)
+        assert 11 <= g[3] <= 14
+
+
+def _bins_worker(kind, rank, world, port, rdzv, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from blueice_amd.sharding import bin_sharded_eval, split_range
     from blueice_amd.synthetic import SyntheticModel
     from oracle import blueice_oracle as orc
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    comm = _comm(kind, rank, world, port, rdzv)
     try:
         m = SyntheticModel.named('mini3')
         dense, counts = m.dense_model(), m.counts(dense=True)
@@ -131,31 +166,47 @@ def _bins_worker(rank, world, port, q):
             bb_source = -1
 
             def eval(self, z, r):
-                return orc.loglikelihood_batch(local, counts[lo:hi], z, r), np.zeros(len(z), np.int32)
+                st = np.zeros(len(z), np.int32)
+                st[rank] = 4 << rank          # a flag raised on this rank's slice only
+                return orc.loglikelihood_batch(local, counts[lo:hi], z, r), st
 
         z, r = m.random_points(9, seed=3)
-        ll, _ = bin_sharded_eval(SliceCtx(), z, r, dist)
-        q.put((rank, ll))
+        ll, st = bin_sharded_eval(SliceCtx(), z, r, comm)
+        q.put((rank, ll, st))
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_bin_sharding_allreduce_two_gloo_ranks():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize('kind', ['socket', 'gloo'])
+def test_bin_sharding_allreduce_two_ranks(kind, tmp_path):
     from blueice_amd.synthetic import SyntheticModel
     from oracle import blueice_oracle as orc
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bins_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=900) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _run_ranks(_bins_worker, kind, 2, tmp_path)
     m = SyntheticModel.named('mini3')
     z, r = m.random_points(9, seed=3)
     want = orc.loglikelihood_batch(m.dense_model(), m.counts(dense=True), z, r)
-    for rank, ll in got:
+    for rank, ll, st in got:
         np.testing.assert_allclose(ll, want, rtol=1e-12)
+        np.testing.assert_array_equal(st[:3], [4, 8, 0])       # status bits are OR-ed over the ranks
+
+
+def test_launcher_starts_ranks_and_propagates_failure(tmp_path):
+    """python -m blueice_amd.launch: ranks find each other through the rendezvous file; a failing rank fails the run."""
+    import subprocess
+    script = tmp_path / 'ranks.py'
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from blueice_amd.comm import connect\n"
+        "c = connect(backend='socket')\n"
+        "tot = c.all_reduce(np.array([float(c.rank + 1)]))\n"
+        "assert tot[0] == c.world * (c.world + 1) / 2\n"
+        "assert int(os.environ['LOCAL_RANK']) == c.rank\n"
+        "c.close()\n"
+        "sys.exit(3 if (len(sys.argv) > 1 and c.rank == 1) else 0)\n" % ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ok = subprocess.run([sys.executable, '-m', 'blueice_amd.launch', '--nproc', '3', str(script)], env=env, timeout=300)
+    assert ok.returncode == 0
+    bad = subprocess.run([sys.executable, '-m', 'blueice_amd.launch', '--nproc', '2', str(script), 'fail'], env=env, timeout=300)
+    assert bad.returncode == 3

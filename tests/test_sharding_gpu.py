@@ -1,7 +1,9 @@
-"""Two ranks on the GPU box (both on device 0, gloo for the gather -- the box has one GPU): the sharded
-scan through the real HIP path equals the single-process device result and the oracle."""
+"""Ranks on the GPU box (the box has one GPU, so every rank uses device 0): the sharded scan / toy-MC run through
+the real HIP path equals the single-process device result and the oracle; RCCL bound directly (one-rank
+communicator: the real ncclCommInitRank / ncclAllGather / ncclAllReduce on the context's stream); and two ranks
+asking for RCCL on ONE GPU, which RCCL refuses -- the agreed fall-back to the socket gather must then carry the run."""
 import os
-import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -10,50 +12,55 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+backend, out = sys.argv[2], sys.argv[3]
+from blueice_amd.comm import connect
+from blueice_amd.device import DeviceContext
+from blueice_amd.sharding import sharded_eval_points, sharded_eval_toys, sharded_scan_device, split_range
+from blueice_amd.synthetic import SyntheticModel
+m = SyntheticModel.named('mini3')
+ctx = DeviceContext(0)
+comm = connect(ctx, backend=backend)
+m.upload(ctx)
+ctx.upload_counts(m.counts(dense=True))
+z, r = m.random_points(301, seed=4)
+ll = sharded_eval_points(lambda zz, rr: ctx.eval(zz, rr)[0], m.anchor_z, z, r, comm)
+ll_dev, rerun = sharded_scan_device(ctx, z, r, comm)
+ll_dev2 = rerun()
+# toy-MC: every rank draws ITS range of one ensemble of 9 toys (toy_offset) and evaluates it
+z0, r0 = m.default_point()
+t0, t1 = split_range(9, comm.rank, comm.world)
+ctx.set_param('toy_offset', t0)
+ctx.generate_toys(z0, r0, t1 - t0, seed=77)
+lt = sharded_eval_toys(lambda a, b: ctx.eval_datasets(z0, r0, 0, b - a)[0], 9, comm)
+first = ctx.download_counts(0)
+tot = comm.all_reduce(np.array([float(comm.rank + 1)]))
+bits = comm.all_reduce(np.array([1 << comm.rank], dtype=np.int64), 'bor')
+np.savez(out + '.%d.npz' % comm.rank, ll=ll, ll_dev=ll_dev, ll_dev2=ll_dev2, lt=lt, first=first, tot=tot, bits=bits,
+         kind=comm.kind, reason=getattr(comm, 'fallback_reason', ''), t0=t0)
+comm.close()
+ctx.close()
+"""
 
-def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-    from blueice_amd.device import DeviceContext
-    from blueice_amd.sharding import sharded_eval_points, sharded_eval_toys
-    from blueice_amd.synthetic import SyntheticModel
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        m = SyntheticModel.named('mini3')
-        ctx = DeviceContext(0)
-        m.upload(ctx)
-        ctx.upload_counts(m.counts(dense=True))
-        z, r = m.random_points(301, seed=4)
-        ll = sharded_eval_points(lambda zz, rr: ctx.eval(zz, rr)[0], m.anchor_z, z, r, dist)
-        toys = np.stack([m.counts(dense=True, dataset=t) for t in range(9)])
-        ctx.upload_counts(toys)          # every rank holds all toys here; it evaluates only its range
-        z0, r0 = m.default_point()
-        lt = sharded_eval_toys(lambda a, b: ctx.eval_datasets(z0, r0, a, b)[0], 9, dist)
-        ctx.close()
-        q.put((rank, ll, lt))
-    finally:
-        dist.destroy_process_group()
+
+def _launch(tmp_path, nproc, backend):
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT)
+    out = str(tmp_path / ('res_%s_%d' % (backend, nproc)))
+    res = subprocess.run([sys.executable, '-m', 'blueice_amd.launch', '--nproc', str(nproc), '--devices',
+                          ','.join(['0'] * nproc), str(script), ROOT, backend, out],
+                         env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return [np.load(out + '.%d.npz' % r) for r in range(nproc)]
 
 
-def test_two_ranks_on_gpu_equal_single_process():
-    import torch.multiprocessing as mp
+def _single_process_truth():
     from blueice_amd.device import DeviceContext
     from blueice_amd.synthetic import SyntheticModel
     from oracle import blueice_oracle as orc
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    mpc = mp.get_context('spawn')
-    q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=900) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
     m = SyntheticModel.named('mini3')
     ctx = DeviceContext(0)
     m.upload(ctx)
@@ -61,54 +68,85 @@ def test_two_ranks_on_gpu_equal_single_process():
     ctx.upload_counts(counts)
     z, r = m.random_points(301, seed=4)
     single = ctx.eval(z, r)[0]
-    dense = m.dense_model()
-    want = orc.loglikelihood_batch(dense, counts, z[:12], r[:12])
-    toys = np.stack([m.counts(dense=True, dataset=t) for t in range(9)])
-    ctx.upload_counts(toys)
+    want = orc.loglikelihood_batch(m.dense_model(), counts, z[:12], r[:12])
     z0, r0 = m.default_point()
+    ctx.generate_toys(z0, r0, 9, seed=77)
+    toys = np.stack([ctx.download_counts(t) for t in range(9)])
     single_t = ctx.eval_datasets(z0, r0)[0]
+    want_t = orc.loglikelihood(m.dense_model(), toys[4], z0, r0)
     ctx.close()
-    for rank, ll, lt in got:
-        np.testing.assert_allclose(ll, single, rtol=1e-13)
-        np.testing.assert_allclose(ll[:12], want, rtol=1e-10)
-        np.testing.assert_allclose(lt, single_t, rtol=1e-13)
+    return single, want, toys, single_t, want_t
 
 
-_TORCH_SCRIPT = r"""
+def _check(got, world):
+    single, want, toys, single_t, want_t = _single_process_truth()
+    assert abs(single_t[4] - want_t) <= 1e-10 * abs(want_t)
+    for g in got:
+        for key in ('ll', 'll_dev', 'll_dev2'):
+            np.testing.assert_allclose(g[key], single, rtol=1e-13)
+        np.testing.assert_allclose(g['ll'][:12], want, rtol=1e-10)
+        np.testing.assert_allclose(g['lt'], single_t, rtol=1e-13)         # the ranks' toys ARE the one-process toys
+        np.testing.assert_array_equal(g['first'], toys[int(g['t0'])])
+        assert g['tot'][0] == world * (world + 1) / 2 and g['bits'][0] == (1 << world) - 1
+
+
+def test_two_socket_ranks_on_gpu_equal_single_process(tmp_path):
+    got = _launch(tmp_path, 2, 'socket')
+    assert all(str(g['kind']) == 'socket' for g in got)
+    _check(got, 2)
+
+
+def test_rccl_bound_directly_one_rank(tmp_path):
+    """The real thing with the one GPU the box has: ncclCommInitRank(nranks = 1), the gather between device buffers
+    on the context's stream (`sharded_scan_device` is given a communicator with all_gather_device, but takes its
+    device route only for world > 1, so the collectives are also called explicitly)."""
+    script = tmp_path / 'one.py'
+    script.write_text(r"""
 import sys
 import numpy as np
-import torch
-torch.cuda.set_device(0)                      # bench.py's order: torch initialises the GPU first
-buf = torch.full((300,), float('nan'), dtype=torch.float64, device='cuda:0')
-torch.cuda.synchronize()
 sys.path.insert(0, sys.argv[1])
+from blueice_amd.comm import connect
 from blueice_amd.device import DeviceContext
 from blueice_amd.synthetic import SyntheticModel
 m = SyntheticModel.named('mini3')
 ctx = DeviceContext(0)
+comm = connect(ctx, backend='rccl', rank=0, world=1)
+assert comm.kind == 'rccl', getattr(comm, 'fallback_reason', '')
+print('RCCL version', comm.version)
 m.upload(ctx)
 ctx.upload_counts(m.counts(dense=True))
 z, r = m.random_points(100, seed=8)
 want, _ = ctx.eval(z, r)
 plan = ctx.plan(z, r)
-plan.run(buf.data_ptr() + 8 * 100)            # middle third of the torch tensor
-ctx.sync()
-got = buf.cpu().numpy()
-assert np.all(np.isnan(got[:100])) and np.all(np.isnan(got[200:]))
-np.testing.assert_array_equal(got[100:200], want)
-print('TORCH_TENSOR_OK')
-"""
+send, recv = ctx.device_alloc(8 * 100), ctx.device_alloc(8 * 100)
+recv.from_host(np.full(100, np.nan))
+plan.run(send.ptr)                                   # bi_run_plan writes into the gather's send buffer ...
+comm.all_gather_device(send.ptr, recv.ptr, 100)      # ... and RCCL moves it on the same stream
+np.testing.assert_array_equal(recv.to_host(), want)
+comm.all_reduce_device(send.ptr, recv.ptr, 100, 'sum')
+np.testing.assert_array_equal(recv.to_host(), want)
+np.testing.assert_array_equal(comm.all_gather(np.arange(5.0)), np.arange(5.0)[None])
+np.testing.assert_array_equal(comm.all_reduce(np.array([3, 5], dtype=np.int64), 'max'), [3, 5])
+np.testing.assert_array_equal(comm.all_reduce(np.array([6], dtype=np.int32), 'bor'), [6])
+comm.barrier()
+comm.close()
+ctx.close()
+print('RCCL_ONE_RANK_OK')
+""")
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PYTHONPATH=ROOT))
+    assert res.returncode == 0 and 'RCCL_ONE_RANK_OK' in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
 
 
-def test_results_land_in_a_torch_device_tensor(tmp_path):
-    """bench.py's N > 1 path hands `bi_run_plan` the data pointer of a torch CUDA tensor so that RCCL can
-    gather the results without a host round trip: the library must write straight into foreign device
-    memory.  Run in a fresh process, torch first -- exactly bench.py's order of initialisation."""
-    import subprocess
-    script = tmp_path / 'torch_tensor.py'
-    script.write_text(_TORCH_SCRIPT)
-    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and 'TORCH_TENSOR_OK' in res.stdout, res.stdout + res.stderr
+def test_two_ranks_asking_for_rccl_on_one_gpu(tmp_path):
+    """RCCL refuses two ranks on one device; `connect` must notice on every rank, agree, and hand back the socket
+    communicator -- or, should a future RCCL accept it, the device route must give the same numbers."""
+    got = _launch(tmp_path, 2, 'rccl')
+    kinds = {str(g['kind']) for g in got}
+    assert len(kinds) == 1 and kinds <= {'rccl', 'socket'}
+    if kinds == {'socket'}:
+        assert all(str(g['reason']) for g in got)
+    _check(got, 2)
 
 
 @pytest.mark.parametrize('bb', [-1, 0])
