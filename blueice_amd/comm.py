@@ -231,7 +231,7 @@ class SocketCommunicator:
 # RCCL, bound directly
 # ---------------------------------------------------------------------------------------------------
 class _UniqueId(C.Structure):
-    _fields_ = [('internal', C.c_char * 128)]           # NCCL_UNIQUE_ID_BYTES (rccl.h)
+    _fields_ = [('internal', C.c_ubyte * 128)]          # NCCL_UNIQUE_ID_BYTES (rccl.h); raw bytes, NULs included
 
 
 _NCCL_INT64, _NCCL_FLOAT64 = 4, 8                        # ncclDataType_t (rccl.h)
@@ -283,7 +283,9 @@ class RcclCommunicator:
         uid = _UniqueId()
         if self.rank == 0:
             self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
-        blob = bootstrap.broadcast_bytes(bytes(uid.internal) if self.rank == 0 else None)
+        blob = bootstrap.broadcast_bytes(C.string_at(C.addressof(uid), 128) if self.rank == 0 else None)
+        if len(blob) != 128:
+            raise CommError("unique id of %d bytes received, expected 128" % len(blob))
         C.memmove(C.addressof(uid), blob, 128)
         scratch = ctx.device_alloc(16)                 # also makes the context's GPU the calling thread's current device
         scratch.free()

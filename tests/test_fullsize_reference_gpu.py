@@ -109,9 +109,11 @@ def test_c3_ten_thousand_toys(c2):
     assert ctx.eval_datasets_device(buf.ptr, z_eval, r) == 0
     np.testing.assert_array_equal(buf.to_host(), ll)           # results left in HBM for the gather: same numbers
     buf.free()
-    pts, pst = ctx.eval(np.tile(z_eval, (len(picks), 1)), np.tile(r, (len(picks), 1)), dataset=np.array(picks))
-    np.testing.assert_allclose(pts, ll[picks], rtol=1e-12)
-    assert not pst.any()
+    # (the per-dataset POINT form needs compacted templates: 41 MB per toy, beyond the budget at 10^4 toys -- it is
+    # covered at T = 48 in test_fullsize_gpu.py::test_c3_toy_batch; here the library must say so, not guess)
+    from blueice_amd.exceptions import NotPreparedException
+    with pytest.raises(NotPreparedException):
+        ctx.eval(z_eval, r, dataset=[17])
 
 
 @pytest.mark.parametrize('sparse', [1, 0])
