@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: binned-likelihood evaluations per second on the BASELINE.json model.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C4-dense|C5|C5-2anchor]
 
-Workload (BASELINE.json configs[1], "C2"): 4 sources, 3 shape parameters with 5 anchors each (125
-anchor models), 100x100x100 analysis bins, one dataset; the anchor tensor (4.0 GB fp64) and the counts
-are resident in HBM before the timed region.  One STEP = one batched call evaluating 8 independent
-parameter points: for every point the morph+reduce kernel streams the 2^3 * 4 corner templates of its
-grid cell plus the counts (264 MB per evaluation) and reduces to a scalar -- 2.1 GB
-per step, one kernel launch.  The 8 points of a step lie in grid cells that share no anchor model with
-each other (per axis cells {0,2} or {1,3}), so no template byte is used twice within a step, and a step's
-2.1 GB is far beyond the 256 MiB Infinity Cache: the number is an HBM-streaming number, and the
-algorithmic bytes equal the compulsory traffic.  Successive steps rotate through the 8 parity
-combinations.  (A batch that covers ALL 64 cells runs ~1.4x faster per evaluation because neighbouring
-cells share corner templates in L2 / Infinity Cache -- reported under extras, not as the headline.)
+Default workload (BASELINE.json configs[1], "C2"): 4 sources, 3 shape parameters with 5 anchors each (125 anchor
+models), 100x100x100 analysis bins; the anchor tensor (4.0 GB fp64) and the data are resident in HBM before the
+timed region.  One STEP = one batched call evaluating 8 independent parameter points, each against a dataset of its
+own: for every point the morph+reduce kernel streams the 2^3 * 4 corner templates of its grid cell plus its counts
+row (264 MB per evaluation) and reduces to a scalar -- 2.1 GB per step, ONE kernel launch (the
+last block of every evaluation finishes it inside the launch).  The 8 points of a step lie in grid cells that share
+no anchor model with each other and use 8 different datasets, so no byte is used twice within a step and a step's
+2.1 GB is far beyond the 256 MiB Infinity Cache: algorithmic bytes = compulsory HBM traffic.  Successive steps
+rotate through the 8 parity combinations of cells.
 
-With N > 1 ranks (launched by torch.distributed.run, one process per GPU) every rank holds a replica of
-the tensor and evaluates its own K points (weak scaling, no data-path collective); the per-rank result
-vectors are gathered once at the end with RCCL (all_gather), inside the timed region.
+With N > 1 ranks (one process per GPU; launched by torch.distributed.run or `python -m blueice_amd.launch` -- only the
+RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* environment is read, PyTorch is not imported) every rank holds a replica
+of the tensor and evaluates its own K steps (weak scaling, no data-path collective); the per-rank result vectors stay
+in HBM and are gathered once at the end with RCCL (ncclAllGather, bound directly: blueice_amd.comm), inside the timed
+region.  The configurations that really shard -- 10^6 scan points dealt by grid cell (configs[3]), 10^4 toy datasets
+split by range (configs[2]) -- run as STRONG-scaling legs behind the headline on every N and are reported under
+"legs" (fixed total work, gather inside the timed region, cross-rank consistency asserted on a sample).
 
 The JSON line also carries
-  roofline      morph+reduce kernel: algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s
+  roofline      morph+reduce kernel: algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s, the measured
+                stream ceiling of the same access pattern, PMC traffic from profiles/
   cpu_baseline  the numpy/scipy oracle (the reference's arithmetic) timed on the host, rank 0, N = 1
-  extras        other call shapes of the same path (one point per launch, same-cell repeat, scan batch,
-                toy-MC, synchronous call latency)
+  legs          C4 / C4-dense / C3 (every N) and the Beeston-Barlow kernel on one C5 grid cell (N = 1)
+  extras        other call shapes of the same path (N = 1)
 """
 import argparse
 import json
@@ -38,9 +41,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6     # fp64 matrix = fp64 vector peak (MI355X_MICROARCH.md)
 POOL = 8
+METRIC = 'likelihood evals/sec (and GB/s vs HBM peak), 4-src 5^3-anchor 100^3-bin model'
 
 
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (the only place the oracle is used)
+# ---------------------------------------------------------------------------------------------------------
 def cpu_baseline_all_cores(config, n_procs, budget_s=10.0):
     """N independent host processes (oracle/cpu_worker.py), each evaluating its own point with the oracle
     (BASELINE.md section 4, step 2).  Plain subprocesses: nothing is forked from this GPU-initialised process."""
@@ -67,11 +79,10 @@ def cpu_baseline(model, counts, points, budget_s=20.0):
     from oracle import blueice_oracle as orc
     z, r = points
     cm = model.cell_model(z[0])
-    c = counts
-    orc.loglikelihood(cm, c, z[0], r[0])            # warm
+    orc.loglikelihood(cm, counts, z[0], r[0])            # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        orc.loglikelihood(cm, c, z[0], r[0])
+        orc.loglikelihood(cm, counts, z[0], r[0])
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 200:
@@ -81,118 +92,332 @@ def cpu_baseline(model, counts, points, budget_s=20.0):
                        'numpy %s oracle = the reference arithmetic' % (n, dt, np.__version__))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# communicator plumbing
+# ---------------------------------------------------------------------------------------------------------
+class Ranks:
+    """World of this run + the gather buffers in HBM."""
+
+    def __init__(self, ctx, backend):
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.rank = int(os.environ.get('RANK', 0))
+        self.ctx = ctx
+        self.comm = None
+        self.multi = self.world > 1 or bool(os.environ.get('BLUEICE_BENCH_FORCE_DIST'))
+        if self.multi:
+            from blueice_amd.comm import connect
+            t = time.perf_counter()
+            self.comm = connect(ctx, backend=backend, rank=self.rank, world=self.world)
+            log('rank %d/%d: communicator %s ready in %.1f s %s' % (
+                self.rank, self.world, self.comm.kind, time.perf_counter() - t, getattr(self.comm, 'fallback_reason', '')))
+        self.device_gather = self.comm is not None and hasattr(self.comm, 'all_gather_device')
+        self._send = self._recv = None
+
+    @property
+    def kind(self):
+        if self.comm is None:
+            return 'none (one process)'
+        if self.comm.kind == 'rccl':
+            return 'rccl %s, ncclAllGather on the context stream between device buffers (ctypes binding)' % self.comm.version
+        return '%s (host)%s' % (self.comm.kind, ' -- RCCL unavailable: ' + self.comm.fallback_reason
+                                if getattr(self.comm, 'fallback_reason', '') else '')
+
+    def buffers(self, n):
+        """send [n] and recv [world * n] doubles in HBM."""
+        if self._send is None or self._send.nbytes < 8 * n:
+            for b in (self._send, self._recv):
+                if b is not None:
+                    b.free()
+            self._send = self.ctx.device_alloc(8 * n)
+            self._recv = self.ctx.device_alloc(8 * n * max(self.world, 1))
+        return self._send, self._recv
+
+    def gather(self, n):
+        """All ranks' send[0:n] -> host array [world, n]; the send buffer must have been filled on the context stream."""
+        send, recv = self.buffers(n)
+        if self.device_gather:
+            self.comm.all_gather_device(send.ptr, recv.ptr, n)
+            return recv.to_host(np.float64, n * self.world).reshape(self.world, n)
+        local = send.to_host(np.float64, n)
+        if self.comm is None:
+            return local[None, :]
+        return self.comm.all_gather(local)
+
+    def barrier(self):
+        self.ctx.sync()
+        if self.comm is not None:
+            self.comm.barrier()
+            self.ctx.sync()
+
+    def max_over_ranks(self, x):
+        if self.comm is None:
+            return float(x)
+        return float(self.comm.all_reduce(np.array([float(x)]), 'max')[0])
+
+    def close(self):
+        for b in (self._send, self._recv):
+            if b is not None:
+                b.free()
+        if self.comm is not None:
+            self.comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# strong-scaling legs
+# ---------------------------------------------------------------------------------------------------------
+def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
+    """A profile scan of P parameter points over the resident model (BASELINE.json configs[3]), STRONG scaling: the
+    points are dealt to the ranks by grid cell, every rank plans and evaluates its share (planning is inside the timed
+    step -- it is part of answering a scan), the shares are gathered in HBM and the full vector is assembled on
+    every rank.  Replaces the reference's Python double loop over lf(**kw) (blueice/inference.py:424-432)."""
+    from blueice_amd.sharding import deal_points_by_cell
+    world, rank = ranks.world, ranks.rank
+    work = []
+    for s in range(steps + 1):                                   # step 0 is the warm-up
+        z, r = model.random_points(P, seed=900 + s)
+        deal = deal_points_by_cell(model.anchor_z, z, world)
+        work.append((z, r, deal))
+    n_max = max(max(len(d) for d in w[2]) for w in work)
+    send, _ = ranks.buffers(n_max)
+    send.from_host(np.zeros(n_max))
+
+    def step(w):
+        z, r, deal = w
+        mine = deal[rank]
+        plan = ctx.plan(z[mine], r[mine]) if len(mine) else None
+        if plan is not None:
+            plan.run(send.ptr)
+        parts = ranks.gather(n_max)
+        out = np.empty(len(z))
+        for idx, vals in zip(deal, parts):
+            out[idx] = vals[:len(idx)]
+        if plan is not None:
+            plan.close()
+        return out
+
+    step(work[0])
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for w in work[1:]:
+        out = step(w)
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel): points of this rank and
+    # points another rank evaluated (every rank holds the whole tensor, so any rank can check any point)
+    z, r, deal = work[-1]
+    picks = list(deal[rank][:sample]) + list(deal[(rank + 1) % world][-sample:])
+    worst = 0.0
+    for i in picks:
+        one, _ = ctx.eval(z[i], r[i])
+        worst = max(worst, abs(one[0] - out[i]) / max(1.0, abs(out[i])))
+    assert worst <= 1e-11, '%s: gathered scan differs from single evaluations by %.2e' % (label, worst)
+    assert np.all(np.isfinite(out)), '%s: non-finite values in the gathered scan' % label
+    share = [len(d) for d in work[-1][2]]
+    return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
+                ms_per_step=elapsed / steps * 1e3, points_per_rank_min_max=[min(share), max(share)],
+                sample_max_rel_diff_vs_single_point_kernel=worst, gather=ranks.kind)
+
+
+def toy_leg(ctx, ranks, model, T, steps):
+    """BASELINE.json configs[2]: T toy-MC datasets, one parameter point per call, STRONG scaling: every rank draws its
+    range of the SAME ensemble on the device (toy_offset: the Philox counters are global dataset numbers) and evaluates
+    it; the T/world results stay in HBM and are gathered per call.  Replaces the user's loop over
+    base_model.simulate() -> set_data -> lf() (blueice/model.py:69-91)."""
+    from blueice_amd.sharding import split_range
+    world, rank = ranks.world, ranks.rank
+    spans = [split_range(T, q, world) for q in range(world)]
+    t0_, t1_ = spans[rank]
+    z, r = model.default_point()
+    lo = np.array([g[0] for g in model.anchor_z])
+    hi = np.array([g[-1] for g in model.anchor_z])
+    ctx.set_param('sparse', 1)
+    ctx.set_param('toy_offset', t0_)
+    tg = time.perf_counter()
+    ctx.generate_toys(z, r, t1_ - t0_, seed=4242)
+    gen_s = ranks.max_over_ranks(time.perf_counter() - tg)
+    n_max = max(b - a for a, b in spans)
+    send, _ = ranks.buffers(n_max)
+    send.from_host(np.zeros(n_max))
+
+    def step(k):
+        zk = np.clip(z + 0.01 * (k + 1), lo, hi)
+        st = ctx.eval_datasets_device(send.ptr, zk, r, 0, t1_ - t0_)
+        parts = ranks.gather(n_max)
+        return zk, st, np.concatenate([p[:b - a] for p, (a, b) in zip(parts, spans)])
+
+    step(-1)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        zk, st, out = step(k)
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    assert st == 0 and out.shape == (T,) and np.all(np.isfinite(out))
+    # cross-rank consistency: re-draw single toys of OTHER ranks' ranges here and evaluate them (same counters ->
+    # the same toy -> the same bits)
+    checked = []
+    for t in sorted({spans[(rank + 1) % world][0], spans[(rank + world - 1) % world][1] - 1, T // 2}):
+        ctx.set_param('toy_offset', t)
+        ctx.generate_toys(z, r, 1, seed=4242)
+        one, _ = ctx.eval_datasets(zk, r)
+        assert one[0] == out[t], 'toy %d: %r on this rank, %r gathered' % (t, one[0], out[t])
+        checked.append(t)
+    ctx.set_param('toy_offset', 0)
+    return dict(workload='C3: 10^4 toy datasets (drawn on the device), one parameter point per call, datasets split '
+                         'by range over the ranks', scaling='strong', datasets=T, steps=steps, value=T * steps / elapsed,
+                unit='evals/s', ms_per_step=elapsed / steps * 1e3, generate_s=gen_s, toys_rechecked_bitwise=checked,
+                gather=ranks.kind)
+
+
+def bb_leg(ctx_dev, steps=10):
+    """The Beeston-Barlow kernel (`k_morph_reduce<1,true,true>`) on one grid cell of configs[4]: 2^4 anchors, 6 sources,
+    50^4 bins -- all 113 stream rows of an evaluation, 5.65 GB per pass (blueice/likelihood.py:618-660)."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('C5-2anchor', bb_source=0)
+    ctx = DeviceContext(ctx_dev)
+    try:
+        m.upload(ctx, threads=8)
+        ctx.set_param('sparse', 0)
+        ctx.upload_counts(m.counts(dense=True))
+        z, r = m.random_points(4, seed=2)
+        plans = [ctx.plan(z[i], r[i]) for i in range(4)]
+        for p in plans:
+            p.run()
+        ctx.sync()
+        ctx.profile(True)
+        for i in range(steps):
+            plans[i % 4].run()
+        n, ms = ctx.profile_read()
+        ctx.profile(False)
+        nbytes = plans[0].bytes
+        assert nbytes == 8 * (16 * 6 + 16 + 1) * m.B
+        gbs = nbytes * n / (ms * 1e-3) / 1e9
+        ll, st = plans[0].read()
+        for p in plans:
+            p.close()
+        return dict(workload='C5 grid cell: Beeston-Barlow, 6 sources, 2^4 anchors, 50^4 bins, one evaluation per launch',
+                    kernel='k_morph_reduce<1,true,true> (Beeston-Barlow, nontemporal loads)', bound='hbm',
+                    bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=gbs / HBM_PEAK_GBS, evals_per_s=n / (ms * 1e-3), status_bits=int(st[0]))
+    finally:
+        ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=40)
-    ap.add_argument('--config', default='C2')
+    ap.add_argument('--config', default='C2', help='C2 (headline) | C3 | C4 | C4-dense | C5 | C5-2anchor: the leg that '
+                                                    'becomes the JSON line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo for\n'
-                    'rehearsals on a box with fewer GPUs than ranks)')
+    ap.add_argument('--no-legs', action='store_true')
+    ap.add_argument('--backend', default='rccl', help="gather for N > 1: 'rccl' (direct binding) or 'socket' (host; for "
+                                                      'rehearsals on a box with fewer GPUs than ranks)')
     args = ap.parse_args()
 
-    # stdout must carry exactly one JSON line: native libraries (RCCL's banner, gloo) write to fd 1 too, so fd 1
-    # points at stderr until the line is printed
+    # stdout must carry exactly one JSON line: native libraries (RCCL's banner) write to fd 1 too, so fd 1 points at
+    # stderr until the line is printed
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    dist = None
-    torch = None
     if args.gpus != world:
-        print('bench.py: --gpus %d but WORLD_SIZE=%d; N > 1 must be launched through torch.distributed.run '
-              '(one rank per GPU) -- running with %d rank(s)' % (args.gpus, world, world), file=sys.stderr)
-    n_dev = 1
-    force_dist = bool(os.environ.get('BLUEICE_BENCH_FORCE_DIST'))      # rehearse the N > 1 code path with one rank
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        n_dev = max(torch.cuda.device_count(), 1)
-        if args.backend == 'nccl':
-            torch.cuda.set_device(local_rank % n_dev)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % n_dev))
-        else:
-            dist.init_process_group(args.backend)
-    multi = world > 1 or force_dist
-    use_cuda_tensors = multi and args.backend == 'nccl'
+        log('bench.py: --gpus %d but WORLD_SIZE=%d; N > 1 must be launched with one process per GPU '
+            '(torch.distributed.run or python -m blueice_amd.launch) -- running with %d rank(s)' % (args.gpus, world, world))
 
-    from blueice_amd.device import DeviceContext
+    from blueice_amd.device import DeviceContext, default_device
     from blueice_amd.synthetic import SyntheticModel
 
-    K, W = args.steps, args.warmup
-    model = SyntheticModel.named(args.config)
-    ctx = DeviceContext(local_rank % n_dev if multi else local_rank)
+    ctx = DeviceContext(default_device())
     info = ctx.info()
-    model.upload(ctx)
+    ranks = Ranks(ctx, args.backend)
+
+    def emit(result):
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps(result), flush=True)
+            os.dup2(2, 1)
+
+    K, W = args.steps, args.warmup
+
+    # ---- the other configurations as the JSON line (manual runs) ------------------------------------------
+    if args.config != 'C2':
+        if args.config in ('C3', 'C4', 'C4-dense'):
+            model = SyntheticModel.named('C2')
+            model.upload(ctx, threads=4)
+            steps = max(1, min(K, 5 if args.config != 'C4-dense' else 2))
+            if args.config == 'C3':
+                leg = toy_leg(ctx, ranks, model, 10000, max(1, min(K, 50)))
+            else:
+                ctx.set_param('sparse', 1 if args.config == 'C4' else 0)
+                ctx.upload_counts(model.counts())
+                leg = scan_leg(ctx, ranks, model, 10 ** 6, steps,
+                               'C4: 10^6 scan points over the C2 model, dealt by grid cell (%s)' % (
+                                   'default path: exact non-empty-bin form' if args.config == 'C4' else 'every bin visited'))
+            metric = 'likelihood evals/sec, 4-src 5^3-anchor 100^3-bin model, ' + args.config
+        else:
+            model = SyntheticModel.named(args.config, bb_source=0)
+            t = time.perf_counter()
+            model.upload(ctx, threads=12)
+            log('rank %d: %s resident after %.0f s' % (rank, args.config, time.perf_counter() - t))
+            ctx.set_param('sparse', 0)
+            ctx.upload_counts(model.counts(dense=True))
+            leg = scan_leg(ctx, ranks, model, 256, max(1, min(K, 5)),
+                           '%s: Beeston-Barlow, 6 sources, %s anchors, 50^4 bins; 256 points dealt by grid cell' % (
+                               args.config, 'x'.join(str(n) for n in model.n_anchor)), sample=1)
+            metric = 'Beeston-Barlow likelihood evals/sec, 6-src 50^4-bin model, ' + args.config
+        result = {'metric': metric, 'value': leg['value'], 'unit': 'evals/s', 'n_gpus': world, 'steps': leg['steps'],
+                  'warmup': 1, 'ms_per_step': leg['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
+                  'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                  'config': {'workload': leg['workload'], 'device': info['arch']}, 'leg': leg, 'cpu_baseline': None}
+        emit(result)
+        ranks.close()
+        ctx.close()
+        return
+
+    # ---- headline ----------------------------------------------------------------------------------------
+    model = SyntheticModel.named('C2')
+    model.upload(ctx, threads=4)
     counts = model.counts()
     ctx.set_param('sparse', 0)          # headline = the dense kernel: every evaluation visits every bin
-    ctx.upload_counts(counts)
-
-    # a pool of plans: host-side preparation done, descriptors resident on the device
     sets = [model.disjoint_cell_points(parity=i, seed=1000 * rank + i) for i in range(POOL)]
-    plans = [ctx.plan(zz, rr) for zz, rr in sets]
-    PPS = plans[0].P                                # points (evaluations) per step
+    PPS = len(sets[0][0])                                # points (evaluations) per step
+    # one dataset per point of a step: no byte of a step is used twice (algorithmic = compulsory traffic)
+    ctx.upload_counts(np.stack([counts] + [model.counts(dataset=i) for i in range(1, PPS)]))
+    plans = [ctx.plan(zz, rr, dataset=np.arange(PPS)) for zz, rr in sets]
     z, r = sets[0]
+    NS = 2 ** model.d * model.S
     bytes_per_launch = plans[0].bytes
-    assert plans[0].launches == 1 and bytes_per_launch == PPS * 8 * (8 * model.S + 1) * model.B
+    assert plans[0].launches == 1 and bytes_per_launch == PPS * 8 * (NS + 1) * model.B
 
-    out_ptr = None
-    if use_cuda_tensors:
-        # results land directly in a torch (RCCL-visible) device tensor: no host round trip before the gather
-        out = torch.empty(K * PPS, dtype=torch.float64, device='cuda')
-        gathered = [torch.empty(K * PPS, dtype=torch.float64, device='cuda') for _ in range(world)]
-        out_ptr = out.data_ptr()
-    elif multi:
-        out = torch.empty(K * PPS, dtype=torch.float64)
-        gathered = [torch.empty(K * PPS, dtype=torch.float64) for _ in range(world)]
-
-    def barrier():
-        ctx.sync()
-        if multi:
-            if use_cuda_tensors:
-                torch.cuda.synchronize()
-            dist.barrier()
-            if use_cuda_tensors:
-                torch.cuda.synchronize()
+    send, _ = ranks.buffers(K * PPS)
+    send.from_host(np.full(K * PPS, np.nan))
 
     def run_steps(n, base=0):
-        if out_ptr is not None:
-            for i in range(n):
-                plans[i % POOL].run(out_ptr + 8 * PPS * ((base + i) % K))
-        else:
-            for i in range(n):
-                plans[i % POOL].run()
+        for i in range(n):
+            plans[i % POOL].run(send.ptr + 8 * PPS * ((base + i) % K))
 
     run_steps(W)
-    if multi:
-        dist.all_gather(gathered, out)         # warm-up of the collective as well (communicator, channels, kernels)
-    barrier()
+    if ranks.multi:
+        ranks.gather(K * PPS)              # warm-up of the collective as well (channels, kernels)
+    ranks.barrier()
     t0 = time.perf_counter()
     run_steps(K)
     ctx.sync()
-    if multi:
-        if not use_cuda_tensors:               # rehearsal backend: last step's results via the host
-            last, _ = plans[(K - 1) % POOL].read()
-            out[-PPS:] = torch.from_numpy(last)
-        dist.all_gather(gathered, out)         # the final gather: the only collective (RCCL over xGMI)
-        if use_cuda_tensors:
-            torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if use_cuda_tensors else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # every rank evaluated different points: the gathered vector must be finite everywhere
-        tail = torch.stack([g[-PPS:] for g in gathered]).cpu().numpy()
-        assert np.all(np.isfinite(tail)), 'gathered results contain non-finite values'
+    gathered = ranks.gather(K * PPS) if ranks.multi else None      # the final gather: the only collective
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    if gathered is not None:
+        # every rank evaluated different points: finite everywhere, and this rank's row is what it computed
+        assert gathered.shape == (world, K * PPS) and np.all(np.isfinite(gathered)), 'gathered results are not finite'
+        np.testing.assert_array_equal(gathered[rank], send.to_host(np.float64, K * PPS))
 
     # kernel time of the same steps, HIP events on the context stream around every launch
     ctx.profile(True)
@@ -204,213 +429,261 @@ def main():
 
     # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from the
     # committed summary of the same command (profiles/), corrected as MI355X_MICROARCH.md prescribes
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-            pm = json.load(f)
-        if args.config == 'C2' and pm.get('algorithmic_bytes_per_launch') == bytes_per_launch:
-            traffic = pm['traffic_bytes_per_launch']
-    except Exception:
-        traffic = None
+    traffic = traffic_src = None
+    for name in ('r02_pmc_traffic.json',):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                pm = json.load(f)
+            if pm.get('algorithmic_bytes_per_launch') == bytes_per_launch:
+                traffic = pm['traffic_bytes_per_launch']
+                traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' % name
+        except Exception:
+            pass
 
-    # the device's read-only streaming ceiling, measured live: a plain sum over the same resident tensor
-    stream_ceiling = copy_ceiling = None
+    # the device's read-only ceilings, measured live on the same resident tensor
+    stream_ceiling = linear_ceiling = copy_ceiling = None
     if rank == 0:
         try:
+            stream_ceiling = max(ctx.stream_bandwidth(items=PPS, rows=NS, nontemporal=True, blocks_per_cu=b, reps=4)
+                                 for b in (8, 16))
+            linear_ceiling = max(ctx.read_bandwidth(nontemporal=True, blocks_per_cu=b, reps=3) for b in (16, 32))
             copy_ceiling = ctx.copy_bandwidth(1 << 31, reps=3)
-            stream_ceiling = max(ctx.read_bandwidth(nontemporal=True, blocks_per_cu=b, reps=3) for b in (16, 32))
         except Exception as e:                       # a measurement aid only: never fail the bench line over it
-            print('bench.py: read-bandwidth probe failed: %s' % e, file=sys.stderr)
+            log('bench.py: bandwidth probe failed: %s' % e)
 
     result = None
     if rank == 0:
         result = {
-            'metric': 'likelihood evals/sec (and GB/s vs HBM peak), 4-src 5^3-anchor 100^3-bin model',
+            'metric': METRIC,
             'value': world * K * PPS / elapsed, 'unit': 'evals/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C2: 4 sources, 3 shape params (5^3 anchors), 100^3 bins, single dataset; '
-                                   'step = one batched call of %d independent dense evaluations in grid cells '
-                                   'that share no anchor (no template re-use), tensor replicated per GPU' % PPS,
+            'config': {'workload': 'C2: 4 sources, 3 shape params (5^3 anchors), 100^3 bins; step = one batched call '
+                                   '(one kernel launch) of %d independent dense evaluations, each against its own '
+                                   'dataset, in grid cells that share no anchor (no byte re-used), tensor '
+                                   'replicated per GPU' % PPS,
                        'sources': model.S, 'anchors': list(model.n_anchor), 'bins': list(model.bins),
-                       'evals_per_step': PPS, 'device': info['arch']},
+                       'evals_per_step': PPS, 'device': info['arch'], 'gather': ranks.kind},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                           'bytes per launch)' if traffic else None,
-                         'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads)', 'bytes_per_launch': bytes_per_launch,
-                         'avg_launch_us': ms / max(launches, 1) * 1e3,
-                         'stream_ceiling': stream_ceiling, 'copy_ceiling': copy_ceiling,
-                         'stream_ceiling_note': 'GB/s of a plain 16-byte-load sum over the resident 4 GB tensor '
-                                                '(nontemporal loads, best of 16 / 32 blocks per CU); copy_ceiling: bytes read + written '
-                                                'per second of a 2 GiB device-to-device hipMemcpy; same process'},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads, in-launch finish)',
+                         'bytes_per_launch': bytes_per_launch, 'avg_launch_us': ms / max(launches, 1) * 1e3,
+                         'step_minus_kernel_us': elapsed / K * 1e6 - ms / max(launches, 1) * 1e3,
+                         'stream_ceiling': stream_ceiling, 'linear_read_ceiling': linear_ceiling,
+                         'copy_ceiling': copy_ceiling,
+                         'ceiling_note': 'stream_ceiling: GB/s of the same launch shape (%d items x %d concurrent rows, '
+                                         '16 B per lane per row, nontemporal) with no arithmetic and no counts; '
+                                         'linear_read_ceiling: one linear 16-byte-load sum over the 4 GB tensor; '
+                                         'copy_ceiling: bytes read + written per second of a 2 GiB device-to-device '
+                                         'hipMemcpy; all in this process' % (PPS, NS)},
         }
 
-    if rank == 0 and world == 1 and not args.no_extras:
-        ex = {}
-        bytes_per_eval = bytes_per_launch // PPS
-        zz, rr = model.stratified_points(seed=3)           # all 64 cells in one call: neighbours share corners
-        p = ctx.plan(zz, rr)
-        p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(20):
-            p.run()
-        ctx.sync()
-        ex['all_64_cells_batch_evals_per_s'] = 20 * len(zz) / (time.perf_counter() - t)
-        p.close()
-        singles = [ctx.plan(z[i], r[i]) for i in range(PPS)]     # one evaluation per launch, rotating cells
-        for p in singles:
-            p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(8):
-            for p in singles:
-                p.run()
-        ctx.sync()
-        ex['one_point_per_launch_evals_per_s'] = 8 * PPS / (time.perf_counter() - t)
-        for p in singles:
-            p.close()
-        p = ctx.plan(z[0], r[0])                           # same cell every call (a fit's access pattern)
-        for _ in range(50):
-            p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(1000):
-            p.run()
-        ctx.sync()
-        dt = (time.perf_counter() - t) / 1000
-        ex['same_cell_evals_per_s'] = 1 / dt
-        ex['same_cell_GBps'] = bytes_per_eval / dt / 1e9
-        p.close()
-        t = time.perf_counter()                            # full synchronous call incl. host planning + D2H
-        for i in range(200):
-            ctx.eval(z[i % PPS], r[i % PPS])
-        ex['sync_call_latency_us'] = (time.perf_counter() - t) / 200 * 1e6
-        zz, rr = model.random_points(16384, seed=7)        # scan batch: cell-grouped, templates reused
-        p = ctx.plan(zz, rr)
-        p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(3):
-            p.run()
-        ctx.sync()
-        ex['scan_batch_16384_evals_per_s'] = 3 * 16384 / (time.perf_counter() - t)
-        p.close()
-        zz, rr = model.random_points(131072, seed=11)      # the same on a scan of 131 072 points (128 items per cell)
-        p = ctx.plan(zz, rr)
-        p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        p.run()
-        ctx.sync()
-        ex['dense_scan_131072_evals_per_s'] = len(zz) / (time.perf_counter() - t)
-        p.close()
-        T = 256                                            # toy-MC: one point, T datasets (fp64 counts)
-        toys = np.stack([model.counts(dataset=i) for i in range(T)])
-        for mode, key in ((0, 'toy_mc_256_dense_counts_evals_per_s_kernels'), (1, 'toy_mc_256_csr_evals_per_s_kernels')):
-            ctx.set_param('sparse', mode)
-            ctx.upload_counts(toys)
-            ctx.eval_datasets(z[0], r[0])
-            ctx.profile(True)
-            ctx.eval_datasets(z[0], r[0])
-            _, tms = ctx.profile_read()
-            ctx.profile(False)
-            ex[key] = T / (tms * 1e-3)
-        # non-empty-bin form (exact: templates >= 0): only the ~1e4 bins with data are visited per evaluation
+    # ---- strong-scaling legs: the configurations that really shard (every N) ---------------------------------
+    legs = {}
+    if not args.no_legs:
         ctx.set_param('sparse', 1)
         ctx.upload_counts(counts)
-        zz, rr = model.random_points(131072, seed=11)
-        t = time.perf_counter()
-        p = ctx.plan(zz, rr)
-        t_plan = time.perf_counter() - t
-        p.run()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(3):
-            p.run()
-        ctx.sync()
-        dt = (time.perf_counter() - t) / 3
-        ex['sparse_scan_131072_evals_per_s_device'] = len(zz) / dt
-        ex['sparse_scan_131072_evals_per_s_incl_planning'] = len(zz) / (dt + t_plan)
-        ex['sparse_nonempty_bins'] = ctx.get_param('nnz_total')
-        p.close()
-        # BASELINE.json configs[2] at full scale: 10^4 toy datasets drawn on the device at one parameter point,
-        # all evaluated by one call at a nearby point (wall time includes the D2H of the 10^4 results)
-        t = time.perf_counter()
-        ctx.generate_toys(z[0], r[0], 10000, seed=1)
-        ex['toy_mc_10000_generate_s'] = time.perf_counter() - t
-        z_near = np.clip(z[0] + 0.03, [g[0] for g in model.anchor_z], [g[-1] for g in model.anchor_z])
-        ctx.eval_datasets(z_near, r[0])
-        t = time.perf_counter()
-        for _ in range(5):
-            ctx.eval_datasets(z_near, r[0])
-        ex['toy_mc_10000_evals_per_s_wall'] = 5 * 10000 / (time.perf_counter() - t)
+        legs['C4'] = scan_leg(ctx, ranks, model, 10 ** 6, 3,
+                              'C4: 10^6 scan points over the C2 model, dealt by grid cell (default path: exact '
+                              'non-empty-bin form, %d bins with data)' % ctx.get_param('nnz_total'))
         ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
-        # the same model end to end through the reference's API: Source plug-ins -> BinnedLogLikelihood.prepare()
-        # -> set data -> inference.bestfit_scipy (first rate + the three shape parameters floating)
-        t = time.perf_counter()
-        lf = model.likelihood(device=ctx.device)
-        ex['api_prepare_s'] = time.perf_counter() - t
-        lf.set_binned_data(counts.reshape(model.bins))
-        fixed = {'s%d_rate_multiplier' % s: 1 for s in range(1, model.S)}
-        lf.bestfit_scipy(**fixed)
-        t = time.perf_counter()
-        best, ll = lf.bestfit_scipy(**fixed)
-        ex['api_bestfit_scipy_s'] = time.perf_counter() - t
-        t = time.perf_counter()
-        lf.bestfit_scipy(use_gradient=True, **fixed)
-        ex['api_bestfit_scipy_with_gradient_s'] = time.perf_counter() - t
-        t = time.perf_counter()
-        for i in range(300):
-            lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
-        ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
-        ex['api_bestfit_max_loglikelihood'] = ll
-        # BASELINE.json configs[3] on one GPU: a profile scan of 10^6 parameter points through lf.eval_points
-        g = np.random.default_rng(5)
-        pts = dict(shape0=g.uniform(-2, 2, 10 ** 6), shape1=g.uniform(-2, 2, 10 ** 6), s0_rate_multiplier=g.uniform(0.8, 1.2, 10 ** 6))
-        lf.eval_points(pts)
-        t = time.perf_counter()
-        lf.eval_points(pts)
-        ex['api_eval_points_1e6_s'] = time.perf_counter() - t
-        del lf
-        result['extras'] = ex
-        # BASELINE.json's north star names two targets; where each one is met
+        before = ctx.get_param('n_scan_launches')
+        legs['C4-dense'] = scan_leg(ctx, ranks, model, 10 ** 6, 1,
+                                    'C4: 10^6 scan points over the C2 model, dealt by grid cell (every bin visited: '
+                                    'fp64 matrix-core scan kernel)')
+        legs['C4-dense']['scan_kernel_launches'] = ctx.get_param('n_scan_launches') - before
+        per_rank_flops = 2.0 * NS * model.B * legs['C4-dense']['points_per_rank_min_max'][1]
+        legs['C4-dense']['roofline_scan'] = {
+            'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS,
+            'achieved': per_rank_flops / (legs['C4-dense']['ms_per_step'] * 1e-3) / 1e12,
+            'note': 'fp64 FMA work of the morph alone (2 * 2^d*S * bins flop per evaluation) of the busiest rank over the '
+                    'whole step (planning + k_scan_mfma + gather); the per-bin logarithms are extra VALU work on the '
+                    'same fp64 units'}
+        legs['C4-dense']['roofline_scan']['frac'] = legs['C4-dense']['roofline_scan']['achieved'] / FP64_PEAK_TFLOPS
+        legs['C3'] = toy_leg(ctx, ranks, model, 10000, 20)
+        ctx.set_param('sparse', 0)
+        ctx.upload_counts(counts)
+    if rank == 0:
+        result['legs'] = legs
+
+    if rank == 0 and world == 1 and not args.no_legs:
+        try:
+            result['legs']['C5-BB'] = bb_leg(ctx.device)
+            result['roofline_bb'] = {k: result['legs']['C5-BB'][k] for k in
+                                     ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'bytes_per_launch', 'avg_launch_us')}
+        except Exception as e:
+            result['legs']['C5-BB'] = {'error': repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        result['extras'] = extras(ctx, model, counts, z, r, PPS, bytes_per_launch // PPS)
+        ex = result['extras']
         result['north_star'] = {
             'hbm_frac_target': 0.70, 'hbm_frac': result['roofline']['frac'],
             'evals_per_s_target': 1e6,
-            'dense_evals_per_s_ceiling_no_reuse': HBM_PEAK_GBS * 1e9 / bytes_per_eval,
-            'evals_per_s_scan_every_bin_visited': ex['dense_scan_131072_evals_per_s'],
-            'evals_per_s_scan_default_path_incl_planning': ex['sparse_scan_131072_evals_per_s_incl_planning'],
+            'dense_evals_per_s_ceiling_no_reuse': HBM_PEAK_GBS * 1e9 / (bytes_per_launch // PPS),
+            'evals_per_s_scan_every_bin_visited': ex.get('dense_scan_131072_evals_per_s'),
+            'evals_per_s_scan_default_path_incl_planning_and_gather': legs.get('C4', {}).get('value'),
+            'evals_per_s_toy_mc_10000': legs.get('C3', {}).get('value'),
             'note': 'an evaluation that shares no template bytes with its neighbours moves %.0f MB, so 8 TB/s caps it at '
-                    '%.1f k/s: `value` is that case, at `roofline.frac` of the peak.  10^6/s needs re-use: a scan '
-                    'of 131072 points reads each cell\'s rows once (matrix-core kernel, every bin visited), and the '
-                    'default path (exact non-empty-bin identity, templates >= 0) visits only the %d bins with data'
-                    % (bytes_per_eval / 1e6, HBM_PEAK_GBS * 1e9 / bytes_per_eval / 1e3, ex['sparse_nonempty_bins']),
+                    '%.1f k/s: `value` is that case, at `roofline.frac` of the peak.  10^6/s needs re-use, and is met '
+                    'where the path re-uses: a 10^6-point scan on the default path (exact non-empty-bin identity, '
+                    'templates >= 0) and 10^4 toys per call -- both measured end to end under `legs`.  With EVERY bin '
+                    'visited a scan is bound by the fp64 units (morph FMAs on the matrix cores + per-bin terms), see '
+                    'legs.C4-dense.roofline_scan' % (bytes_per_launch / PPS / 1e6,
+                                                     HBM_PEAK_GBS * 1e9 / (bytes_per_launch / PPS) / 1e3),
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(model, counts, (z, r))
         result['cpu_baseline']['host_cores_available'] = os.cpu_count()
         try:
-            n_procs = max(1, min(16, os.cpu_count() or 1))          # a 1-GPU box's CPU share
-            result['cpu_baseline']['all_cores'] = cpu_baseline_all_cores(args.config, n_procs)
+            share = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            n_procs = max(1, min(16, share))
+            result['cpu_baseline']['all_cores'] = cpu_baseline_all_cores('C2', n_procs)
+            result['cpu_baseline']['all_cores']['cores_note'] = (
+                'a 1-GPU box of this pool is granted a CPU share of 16 workers (the pool kills runs with larger worker '
+                'pools), although the host reports %d logical cores; rate scales ~linearly with processes' % (os.cpu_count() or 0))
         except Exception as e:                                       # never let the side figure break the line
             result['cpu_baseline']['all_cores'] = {'error': repr(e)}
     elif rank == 0:
         result['cpu_baseline'] = None
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(result), flush=True)
-        os.dup2(2, 1)
+    emit(result)
     for p in plans:
         p.close()
+    ranks.close()
     ctx.close()
-    if multi:
-        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
+    """Other call shapes of the same path, N = 1 (state on entry: sparse = 0, `counts` resident as dataset 0)."""
+    ex = {}
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(counts)
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t) / reps
+
+    zz, rr = model.stratified_points(seed=3)           # all 64 cells in one call: neighbours share corners
+    p = ctx.plan(zz, rr)
+    ex['all_64_cells_batch_evals_per_s'] = len(zz) / timed(p.run, 20)
+    p.close()
+    singles = [ctx.plan(z[i], r[i]) for i in range(PPS)]     # one evaluation per launch, rotating cells
+    ex['one_point_per_launch_evals_per_s'] = PPS / timed(lambda: [q.run() for q in singles], 8)
+    for q in singles:
+        q.close()
+    p = ctx.plan(z[0], r[0])                           # same cell every call (a fit's access pattern)
+    dt = timed(p.run, 1000)
+    ex['same_cell_evals_per_s'] = 1 / dt
+    ex['same_cell_GBps'] = bytes_per_eval / dt / 1e9
+    p.close()
+
+    # the synchronous call `lf(**kw)` makes inside a minimizer: bi_eval(P = 1), rotating cells, and where its time goes
+    for i in range(20):
+        ctx.eval_one(z[i % PPS], r[i % PPS])
+    ctx.set_param('single_timing_reset', 1)
+    t = time.perf_counter()
+    for i in range(400):
+        ctx.eval_one(z[i % PPS], r[i % PPS])
+    wall = (time.perf_counter() - t) / 400 * 1e6
+    n = max(ctx.get_param('single_calls'), 1)
+    split = {k: ctx.get_param('single_ns_' + k) / n / 1e3 for k in ('host', 'launch', 'wait')}
+    ctx.profile(True)
+    for i in range(64):
+        ctx.eval_one(z[i % PPS], r[i % PPS])
+    nl, kms = ctx.profile_read()
+    ctx.profile(False)
+    ex['sync_call_latency_us'] = wall
+    ex['sync_call_split_us'] = {'python_ctypes': wall - sum(split.values()), 'host_geometry': split['host'],
+                                'launch_calls': split['launch'], 'wait_for_result': split['wait'],
+                                'kernel_by_hip_events': kms / max(nl, 1) * 1e3,
+                                'note': 'wait_for_result = launch latency + kernel + in-launch finish + result word reaching the host'}
+    for i in range(20):
+        ctx.eval_one(z[0], r[0] * (1 + 1e-3 * i))
+    t = time.perf_counter()
+    for i in range(400):
+        ctx.eval_one(z[0], r[0] * (1 + 1e-4 * i))
+    ex['sync_call_same_cell_latency_us'] = (time.perf_counter() - t) / 400 * 1e6
+
+    zz, rr = model.random_points(16384, seed=7)        # scan batch: cell-grouped, templates reused
+    p = ctx.plan(zz, rr)
+    ex['scan_batch_16384_evals_per_s'] = 16384 / timed(p.run, 3)
+    p.close()
+    zz, rr = model.random_points(131072, seed=11)      # the same on a scan of 131 072 points (128 items per cell)
+    p = ctx.plan(zz, rr)
+    dt = timed(p.run, 2)
+    ex['dense_scan_131072_evals_per_s'] = len(zz) / dt
+    ex['dense_scan_131072_fp64_fma_TFLOPs'] = 2.0 * 32 * model.B * len(zz) / dt / 1e12
+    p.close()
+    dense_counts = model.counts(dense=True)            # ~10 events per bin: a logarithm in every bin
+    ctx.upload_counts(dense_counts)
+    p = ctx.plan(zz, rr)
+    ex['dense_scan_131072_dense_data_evals_per_s'] = len(zz) / timed(p.run, 1)
+    p.close()
+    T = 256                                            # toy-MC: one point, T datasets (fp64 counts)
+    toys = np.stack([model.counts(dataset=i) for i in range(T)])
+    for mode, key in ((0, 'toy_mc_256_dense_counts_evals_per_s_kernels'), (1, 'toy_mc_256_csr_evals_per_s_kernels')):
+        ctx.set_param('sparse', mode)
+        ctx.upload_counts(toys)
+        ctx.eval_datasets(z[0], r[0])
+        ctx.profile(True)
+        ctx.eval_datasets(z[0], r[0])
+        _, tms = ctx.profile_read()
+        ctx.profile(False)
+        ex[key] = T / (tms * 1e-3)
+    # non-empty-bin form (exact: templates >= 0): only the ~1e4 bins with data are visited per evaluation
+    ctx.set_param('sparse', 1)
+    ctx.upload_counts(counts)
+    t = time.perf_counter()
+    p = ctx.plan(zz, rr)
+    t_plan = time.perf_counter() - t
+    dt = timed(p.run, 3)
+    ex['sparse_scan_131072_evals_per_s_device'] = len(zz) / dt
+    ex['sparse_scan_131072_evals_per_s_incl_planning'] = len(zz) / (dt + t_plan)
+    ex['sparse_nonempty_bins'] = ctx.get_param('nnz_total')
+    p.close()
+    t = time.perf_counter()
+    for i in range(400):
+        ctx.eval_one(z[i % PPS], r[i % PPS])
+    ex['sync_call_latency_sparse_form_us'] = (time.perf_counter() - t) / 400 * 1e6
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(counts)
+    # the same model end to end through the reference's API: Source plug-ins -> BinnedLogLikelihood.prepare()
+    # -> set data -> inference.bestfit_scipy (first rate + the three shape parameters floating)
+    t = time.perf_counter()
+    lf = model.likelihood(device=ctx.device)
+    ex['api_prepare_s'] = time.perf_counter() - t
+    lf.set_binned_data(counts.reshape(model.bins))
+    fixed = {'s%d_rate_multiplier' % s: 1 for s in range(1, model.S)}
+    lf.bestfit_scipy(**fixed)
+    t = time.perf_counter()
+    best, ll = lf.bestfit_scipy(**fixed)
+    ex['api_bestfit_scipy_s'] = time.perf_counter() - t
+    t = time.perf_counter()
+    lf.bestfit_scipy(use_gradient=True, **fixed)
+    ex['api_bestfit_scipy_with_gradient_s'] = time.perf_counter() - t
+    t = time.perf_counter()
+    for i in range(300):
+        lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
+    ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
+    ex['api_bestfit_max_loglikelihood'] = ll
+    lf.ctx.set_param('sparse', 0)                       # the same fit with every bin visited on every call
+    lf.set_binned_data(counts.reshape(model.bins))
+    lf.bestfit_scipy(**fixed)
+    t = time.perf_counter()
+    _, ll_dense = lf.bestfit_scipy(**fixed)
+    ex['api_bestfit_scipy_every_bin_visited_s'] = time.perf_counter() - t
+    ex['api_bestfit_every_bin_visited_max_loglikelihood'] = ll_dense
+    del lf
+    return ex
 
 
 if __name__ == '__main__':

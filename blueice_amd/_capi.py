@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BLUEICE_AMD_LIB') or os.path.join(_HERE, 'lib', 'libblueice_hip.so')   # env: A/B builds
 
 # status bits (include/blueice_hip.h)
-ST_OUT_OF_BOUNDS, ST_UNPHYSICAL, ST_BB_ROOT1, ST_BB_NEG, ST_BAD_DATASET = 1, 2, 4, 8, 16
+ST_OUT_OF_BOUNDS, ST_UNPHYSICAL, ST_BB_ROOT1, ST_BB_NEG, ST_BAD_DATASET, ST_INTERNAL = 1, 2, 4, 8, 16, 32
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM = -1, -2, -3, -4
 
 _p = C.c_void_p
@@ -64,6 +64,7 @@ SIGNATURES = {
     'bi_memcpy_to_device': (C.c_int, [_p, _p, _p, _i64]),
     'bi_selftest_log': (C.c_int, [_p, _i64, _p, _p]),
     'bi_measure_read_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p]),
+    'bi_measure_stream_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     'bi_measure_copy_bandwidth': (C.c_int, [_p, _i64, C.c_int, _p]),
     'bi_profile_enable': (C.c_int, [_p, C.c_int]),
     'bi_profile_read': (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_f64)]),

@@ -99,12 +99,15 @@ struct bi_ctx {
 
     // persistent single-point slot (the lf(**kw) call shape): no allocation, one H2D, one D2H per call
     DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
+    DevBuf mail, mail_flags;    // mailbox slots / status words of in-launch finishing: empty / zero between launches
     void* pack_host = nullptr;  // pinned staging of packed_upload (small-batch descriptors in, results out)
     size_t pack_host_bytes = 0;
     DevBuf pack_dev;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
     unsigned long long slot_seq = 0;  // sequence number of single-point calls (the kernel echoes it when done)
+    int64_t single_ns[3] = {0, 0, 0}; // accumulated wall time of single-point calls: host half, launch calls, wait
+    int64_t single_calls = 0;
     int pending = 0;                  // bi_eval_begin without its bi_eval_end: 1 = launch in flight, 2 = answer parked
     unsigned long long pending_seq = 0;
     double pending_ll = 0.0;
@@ -141,7 +144,9 @@ struct bi_ctx {
     int64_t blocks_per_cu = 8;
     int64_t max_group = kMaxG;
     int64_t xcd_affine = 1;                      // multi-item launches: tile chunks keep their XCD across items
-    int64_t fuse_max_blocks = 64;                // finish inside the launch up to this many blocks
+    int64_t fuse_max_blocks = (int64_t)1 << 20;  // single evaluations: finish inside the launch up to this many blocks
+    int64_t single_blocks_per_cu = 4;            // single evaluations: blocks per CU the launch shape aims for
+    int64_t fuse_finish = 1;                     // batched launches of few items: the last block of an item finishes it (no k_finish launch)
     int64_t single_kernel = 1;                   // bi_eval(P = 1): one fused launch (0: two-kernel fallback)
     int64_t nt_loads = 2;                        // nontemporal template loads: 0 never, 1 always, 2 when no reuse
     int64_t sparse = 1;                          // use the sparse forms when they are exactly equivalent

@@ -115,6 +115,31 @@ __global__ __launch_bounds__(kThreads) void k_read_sum(const double* __restrict_
     if (s == 0.123456789) sink[0] = s;      // keeps the loads alive, practically never stores
 }
 
+// measurement probe with the morph kernel's access pattern and nothing else: blockIdx.y = item, every item streams
+// `rows` template rows of its own (row r of item i starts at element ((first + i * rows + r) % total_rows) * Bp), the
+// tiles of a row are walked in the XCD-aware order of morph_tiles, 16 bytes per lane per row, `rows` loads in flight
+// per lane in batches of 8 -- the ceiling `k_morph_reduce` can be held against (bi_measure_stream_bandwidth)
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_read_rows(const double* __restrict__ ps, int64_t Bp, int64_t total_rows,
+                                                        int64_t first, int rows, int n_tiles, int chunks_in,
+                                                        double* __restrict__ sink) {
+    const int64_t row0 = first + (int64_t)blockIdx.y * rows;
+    const int chunks = (chunks_in > 1 && n_tiles >= 64 * chunks_in) ? chunks_in : 1;
+    const int per_chunk = (n_tiles + chunks - 1) / chunks;
+    double s = 0.0;
+    for (int lt = blockIdx.x; lt < per_chunk * chunks; lt += gridDim.x) {
+        const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
+        if (tile >= n_tiles) continue;
+        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
+#pragma unroll 8
+        for (int r = 0; r < rows; ++r) {
+            const double2 v = stream_load<NT>(ps + ((row0 + r) % total_rows) * Bp + bin0);
+            s += v.x + v.y;
+        }
+    }
+    if (s == 0.123456789) sink[0] = s;      // keeps the loads alive, practically never stores
+}
+
 // Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
 // (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
 //   mu not >= 0 (negative or nan) or n nan -> nan
@@ -168,6 +193,58 @@ __device__ __forceinline__ void bb_roots(double a, double p, double U, double d,
     r2 = (lead + sq) / den;
 }
 
+// ---- in-launch finishing through mailboxes -------------------------------------------------------------------
+// A work item's blocks post their partial sums into 8-byte mailbox slots and EXIT; the item's last block in dispatch
+// order (blockIdx.x == gridDim.x - 1: every sibling was dispatched before it, so they are running or done) collects
+// them, sums them in block order (fixed order => bitwise reproducible) and writes the result -- what the k_finish
+// launch did, without the launch.  A slot is one naturally aligned 8-byte granule written by ONE system-scope
+// (sc0 sc1, write-through) store and read with system-scope loads (MI355X_MICROARCH.md "Valid forms": sc0 sc1
+// stores and loads on both sides need no fence); "empty" is a signalling-NaN bit pattern that no arithmetic result
+// can have (posted NaNs are canonicalised), and the collector puts it back as it takes a value, so the slots are
+// empty again when the launch ends.  Posting costs a block one store and no wait: round 2 first tried arrival
+// tickets (publish, drain, returning atomics) and measured +27 us on a 300 us launch -- every one of 8192 blocks
+// held its CU slot for ~4 us of round trips -- and round 1's release fence per block was worse still.
+// The collector's wait is bounded (kMailTimeoutTicks of the 100 MHz wall clock): if a value never arrives it gives
+// up, reports BI_ST_INTERNAL and the result is nan -- no wave can spin forever.
+constexpr unsigned long long kMailEmpty = 0x7FF4B10E1CE00001ull;
+constexpr long long kMailTimeoutTicks = 20000000;                      // 0.2 s
+
+__device__ __forceinline__ void mail_post(double* slot, double v) {
+    if (v != v) v = __builtin_nan("");                                   // never the "empty" pattern
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// take the value out of a slot (waiting for it), leave the slot empty; *late is set if the wait ran out
+__device__ __forceinline__ double mail_take(double* slot, long long deadline, bool* late) {
+    unsigned long long bits;
+    for (;;) {
+        bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (bits != kMailEmpty) break;
+        if ((long long)wall_clock64() > deadline) { *late = true; return __builtin_nan(""); }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), kMailEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __longlong_as_double(bits);
+}
+
+// Beeston-Barlow status bits travel through one word per result slot: a block that has any ORs them in BEFORE it
+// posts its partial (returning atomic: performed when it returns), the collector swaps the word for 0 after the
+// partials have arrived
+__device__ __forceinline__ void flags_post(unsigned* word, unsigned f) {
+    if (f) {
+        const unsigned old = __hip_atomic_fetch_or(word, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("" ::"v"(old) : "memory");                           // the post below must not be hoisted above the return
+    }
+}
+__device__ __forceinline__ unsigned flags_take(unsigned* word) {
+    return __hip_atomic_exchange(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_mail_init(unsigned long long* slots, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = kMailEmpty;
+}
+
 struct LaunchArgs {
     const double* ps;       // [rows][Bp]
     const double* nm;       // [A][Bp] (BB) or null
@@ -185,6 +262,14 @@ struct LaunchArgs {
     int n_tiles;
     int chunks;             // > 1: consecutive blocks work in `chunks` far-apart regions of the rows
     int n_keep;             // NT kernels: the first n_keep stream rows are loaded with the default (cacheable) policy
+    // in-launch finish (k_morph_reduce): when fin_mail != NULL the item's last block collects the item's partials
+    // from the mailbox slots and writes the results -- no k_finish launch behind the morph launch
+    double* fin_mail;           // [items][nbx][G] mailbox slots, empty on entry and on exit
+    unsigned* fin_flags;        // [items][G] status words (Beeston-Barlow), zero on entry and on exit
+    const int64_t* fin_perm;    // [items][G]  result index of every slot (-1: unused slot)
+    const double* fin_slot_lg;  // [items][G]  constant subtracted from the sum
+    double* fin_out;            // results (device or pinned host memory)
+    int32_t* fin_status;        // or NULL
     int nan_S;              // MODE 2 with non-finite pdf values: number of sources (streams are [corner][source]); the
                             // sum over sources then skips nan terms -- np.nansum, blueice/likelihood.py:686.  0 = off
 };
@@ -405,15 +490,67 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
         if (lane == 0) { s_sum[wave][g] = s; s_flg[wave][g] = f; }
     }
     __syncthreads();
+    const bool fuse = a.fin_mail != nullptr;
+    const int nbx = gridDim.x;
     if (threadIdx.x < G) {
         const int g = threadIdx.x;
         double s = s_sum[0][g];
         unsigned f = s_flg[0][g];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w][g]; f |= s_flg[w][g]; }
-        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * G + g;
-        a.partial[o] = s;
-        a.pflags[o] = f;
+        const int64_t o = ((int64_t)item * nbx + blockIdx.x) * G + g;
+        if (fuse) {
+            if (BB) flags_post(a.fin_flags + (int64_t)item * G + g, f);
+            mail_post(a.fin_mail + o, s);
+        } else {
+            a.partial[o] = s;
+            a.pflags[o] = f;
+        }
+    }
+    if (!fuse || (int)blockIdx.x != nbx - 1) return;
+
+    // ---- the item's last block does what k_finish would do, in k_finish's summation order ----
+    const long long deadline = (long long)wall_clock64() + kMailTimeoutTicks;
+    double* __restrict__ mail = a.fin_mail + (int64_t)item * nbx * G;
+    bool late = false;
+    if (nbx <= 64) {
+        // k_finish's 64-lane form: one wave per slot, lane b takes block b's partial
+        for (int g = wave; g < G; g += kThreads / 64) {
+            double s = lane < nbx ? mail_take(mail + (int64_t)lane * G + g, deadline, &late) : 0.0;
+            s = wave_sum(s);
+            const bool any_late = __ballot(late) != 0ull;
+            const int64_t p = a.fin_perm[(int64_t)item * G + g];
+            if (lane == 0) {
+                const unsigned f = (BB ? flags_take(a.fin_flags + (int64_t)item * G + g) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
+                if (p >= 0) {
+                    a.fin_out[p] = s - a.fin_slot_lg[(int64_t)item * G + g];
+                    if (a.fin_status) a.fin_status[p] |= (int32_t)f;
+                }
+            }
+        }
+        return;
+    }
+    // k_finish's 256-lane form: thread l sums blocks l, l + 256, ..., wave tree, then the four waves in order
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nbx; b += kThreads) s += mail_take(mail + (int64_t)b * G + g, deadline, &late);
+        s = wave_sum(s);
+        const unsigned lt = __ballot(late) != 0ull ? 1u : 0u;
+        __syncthreads();                           // s_sum / s_flg are reused
+        if (lane == 0) { s_sum[wave][0] = s; s_flg[wave][0] = lt; }
+        __syncthreads();
+        const int64_t p = a.fin_perm[(int64_t)item * G + g];
+        if (threadIdx.x == 0) {
+            double t = s_sum[0][0];
+            unsigned any_late = s_flg[0][0];
+#pragma unroll
+            for (int w = 1; w < kThreads / 64; ++w) { t += s_sum[w][0]; any_late |= s_flg[w][0]; }
+            const unsigned f = (BB ? flags_take(a.fin_flags + (int64_t)item * G + g) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
+            if (p >= 0) {
+                a.fin_out[p] = t - a.fin_slot_lg[(int64_t)item * G + g];
+                if (a.fin_status) a.fin_status[p] |= (int32_t)f;
+            }
+        }
     }
 }
 
@@ -421,10 +558,9 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
 // The call shape of `lf(**kwargs)` inside a minimizer.  The point's stream descriptors (row offsets and
 // coefficients, <= kMaxSingleStreams of them) travel in the kernel-argument block, so the scalar loads hit the
 // kernarg segment and no host-to-device copy precedes the launch; and the reduction is finished inside the
-// launch: every block publishes its partial with an agent-scope release, draws a ticket, and the block that
-// draws the last one acquires and sums all partials in block order (fixed order => bitwise reproducible) and
-// writes {ll, status} straight into pinned host memory.  (Release / acquire exactly as the compiler lowers
-// __atomic_thread_fence at agent scope; MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".)
+// launch: every block posts its partial into a mailbox slot and leaves, the last block in dispatch order collects
+// them in block order (fixed order => bitwise reproducible; see mail_post) and writes {ll, status} straight into
+// pinned host memory.
 constexpr int kMaxSingleStreams = 128;
 
 struct SingleDesc {
@@ -432,7 +568,7 @@ struct SingleDesc {
     double coef[kMaxSingleStreams];
     double aux[2];        // Beeston-Barlow: p_cal, N
     double slot_lg;       // constant subtracted from the sum (sum lgamma, empty-bin term, or sum of rates)
-    unsigned* counter;    // zero on entry, re-armed by the finishing block
+    unsigned* flags;      // one status word (Beeston-Barlow bits), zero on entry and on exit
     double* out;          // pinned host
     int32_t* status;      // pinned host
     unsigned long long* done;   // pinned host: receives `seq` after out / status (the host polls it)
@@ -447,7 +583,6 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
 
     __shared__ double s_sum[kThreads / 64];
     __shared__ unsigned s_flg[kThreads / 64];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         const double s = wave_sum(sum[0]);
@@ -460,43 +595,34 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
         unsigned f = s_flg[0];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w]; f |= s_flg[w]; }
-        a.partial[blockIdx.x] = s;
-        a.pflags[blockIdx.x] = f;
-        if constexpr (!FUSE) return;   // many blocks: a second, tiny launch sums the partials (k_finish_single)
-        // publish: drain this wave's stores, agent-scope release, then the ticket
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned ticket = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == gridDim.x - 1) ? 1 : 0;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (FUSE) {          // post into the mailbox and leave: the last block collects (see mail_post)
+            if (BB) flags_post(d.flags, f);
+            mail_post(a.partial + blockIdx.x, s);
+        } else {                       // a second, tiny launch sums the partials (k_finish_single)
+            a.partial[blockIdx.x] = s;
+            a.pflags[blockIdx.x] = f;
         }
     }
     if constexpr (!FUSE) return;
-    __syncthreads();
-    if (!s_last) return;
-    // the last block to arrive: sum the partials of all blocks in block order
+    if (blockIdx.x != gridDim.x - 1) return;
+    // the last block in dispatch order: collect the partials of all blocks in block order
+    const long long deadline = (long long)wall_clock64() + kMailTimeoutTicks;
+    bool late = false;
     double s = 0.0;
-    unsigned f = 0u;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += kThreads) {
-        s += a.partial[b];
-        f |= a.pflags[b];
-    }
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kThreads) s += mail_take(a.partial + b, deadline, &late);
     s = wave_sum(s);
-    f = wave_or(f);
+    const unsigned lt = __ballot(late) != 0ull ? 1u : 0u;
     __syncthreads();   // s_sum / s_flg are reused
-    if (lane == 0) { s_sum[wave] = s; s_flg[wave] = f; }
+    if (lane == 0) { s_sum[wave] = s; s_flg[wave] = lt; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = s_sum[0];
-        unsigned ff = s_flg[0];
+        unsigned any_late = s_flg[0];
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { t += s_sum[w]; ff |= s_flg[w]; }
+        for (int w = 1; w < kThreads / 64; ++w) { t += s_sum[w]; any_late |= s_flg[w]; }
+        const unsigned ff = (BB ? flags_take(d.flags) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
         *d.out = t - d.slot_lg;
         *d.status = (int32_t)ff;
-        *d.counter = 0u;   // re-arm for the next launch on this stream
         __hip_atomic_store(d.done, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -64,6 +64,28 @@ void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, b
     }
 }
 
+// the mailbox of in-launch finishing: allocated and emptied once (every collector leaves its slots empty again)
+constexpr int64_t kMailSlots = (int64_t)1 << 20;       // 8 MB
+constexpr int64_t kMailFlagWords = (int64_t)1 << 16;
+
+int ensure_mail(bi_ctx* c) {
+    if (c->mail.p) return BI_OK;
+    void* p = nullptr;
+    void* f = nullptr;
+    // not from the recycle cache: these must keep their contents between calls
+    if (hipMalloc(&p, (size_t)kMailSlots * sizeof(double)) != hipSuccess) return BI_ERR_NOMEM;
+    if (hipMalloc(&f, (size_t)kMailFlagWords * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return BI_ERR_NOMEM; }
+    hipLaunchKernelGGL(k_mail_init, dim3((unsigned)((kMailSlots + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)p, kMailSlots);
+    if (hipGetLastError() != hipSuccess || hipMemsetAsync(f, 0, (size_t)kMailFlagWords * sizeof(unsigned), c->stream) != hipSuccess) {
+        (void)hipFree(p);
+        (void)hipFree(f);
+        return BI_ERR_HIP;
+    }
+    c->mail.p = p; c->mail.bytes = (size_t)kMailSlots * sizeof(double); c->mail.owner = nullptr;
+    c->mail_flags.p = f; c->mail_flags.bytes = (size_t)kMailFlagWords * sizeof(unsigned); c->mail_flags.owner = nullptr;
+    return BI_OK;
+}
+
 int check_ready(bi_ctx* c, bool need_data) {
     if (!c) return BI_ERR_INVALID;
     if (c->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding on this context: call bi_eval_end first");

@@ -26,20 +26,22 @@ int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status)
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!arrived || (seq & 255ull) == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (*(const volatile unsigned long long*)(res + 16) != seq) {
-        // the stream drained but no block published a result: the ticket counter was out of step (an earlier launch
-        // was aborted).  Re-arm it and report, rather than hand back the zeroed block as a likelihood of 0.
-        if (c->slot_counter.p) (void)hipMemsetAsync(c->slot_counter.p, 0, 64, c->stream);
+    if (*(const volatile unsigned long long*)(res + 16) != seq)
+        // the stream drained but nothing was published: report it, rather than hand back the zeroed block as a likelihood of 0
         return fail(c, BI_ERR_HIP, "single-point launch %llu finished without publishing its result", seq);
-    }
     *out = *(double*)res;
     if (status) *status = *(int32_t*)(res + 8);
     return BI_OK;
 }
 
 // wait = false (bi_eval_begin): return right after the launch; bi_eval_end collects the result with single_wait.
+using bi_clock = std::chrono::steady_clock;
+inline int64_t ns_between(bi_clock::time_point a, bi_clock::time_point b) {
+    return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+}
+
 int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_t ds, bool sparse, double* out, int32_t* status,
-                      bool wait = true) {
+                      bool wait = true, bi_clock::time_point t_entry = bi_clock::now()) {
     const int S = c->S;
     const bool bb = c->bb_source >= 0;
     const int nc = (int)g.w.size();
@@ -48,18 +50,23 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;
     const int tiles = (int)(row_stride / kTile);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
-    const int nbx = (int)std::min<int64_t>(tiles, slots);
+    // launch shape of ONE pass over the rows: every block gets the same number of tiles and all blocks are resident at
+    // once (a second, thin round of blocks is a tail the size of a block's lifetime).  Measured on C2 (1954 tiles):
+    // 2 tiles per block on ~4 blocks per CU takes 48 us from launch to result, 1 tile per block on 7.6 per CU 54 us.
+    const int64_t target = (int64_t)c->prop.multiProcessorCount * c->single_blocks_per_cu;
+    const int64_t tiles_per_block = std::max<int64_t>(1, (tiles + target - 1) / target);
+    int64_t want = (tiles + tiles_per_block - 1) / tiles_per_block;
+    if (want >= 8) want = (want + 7) / 8 * 8;      // a block's tiles then all lie in one of the 8 row regions (block b -> XCD b % 8):
+                                                   // 984 blocks take 48 us where 977 take 59
+    const int nbx = (int)std::min<int64_t>(std::min<int64_t>(want, tiles), slots);
     int rc;
     if (!c->slot_host) {
         HIP_TRY(c, hipHostMalloc(&c->slot_host, 4096, hipHostMallocDefault));
         c->slot_host_bytes = 4096;
     }
-    if (!c->slot_counter.p) {
-        if ((rc = dev_alloc(c, c->slot_counter, 64))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->slot_counter.p, 0, 64, c->stream));
-    }
-    if ((rc = dev_alloc(c, c->slot_partial, (size_t)slots * sizeof(double))) ||
-        (rc = dev_alloc(c, c->slot_pflags, (size_t)slots * sizeof(unsigned))))
+    const bool fuse = nbx <= c->fuse_max_blocks && nbx <= kMailSlots && !ensure_mail(c);
+    if (!fuse && ((rc = dev_alloc(c, c->slot_partial, (size_t)slots * sizeof(double))) ||
+                  (rc = dev_alloc(c, c->slot_pflags, (size_t)slots * sizeof(unsigned)))))
         return rc;
     SingleDesc d;
     const int64_t n_rows = c->A * S;
@@ -100,7 +107,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     *(double*)res = 0.0;
     *(int64_t*)(res + 8) = 0;
     *(unsigned long long*)(res + 16) = 0ull;
-    d.counter = (unsigned*)c->slot_counter.p;
+    d.flags = fuse ? (unsigned*)c->mail_flags.p : nullptr;
     d.out = (double*)res;
     d.status = (int32_t*)(res + 8);
     d.done = (unsigned long long*)(res + 16);
@@ -109,7 +116,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
     a.nm = (const double*)c->nm.p;
     a.counts = (sparse ? (const double*)c->cnt_c.p + c->h_cnt_off[(size_t)ds] : (const double*)c->counts.p + ds * c->Bp);
-    a.partial = (double*)c->slot_partial.p;
+    a.partial = fuse ? (double*)c->mail.p : (double*)c->slot_partial.p;
     a.pflags = (unsigned*)c->slot_pflags.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
@@ -126,8 +133,8 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     }
     c->last_single_cell = g.cell_anchor;
     c->last_single_ds = ds;
-    const bool fuse = nbx <= c->fuse_max_blocks;
     const dim3 grid((unsigned)nbx), block(kThreads);
+    const auto t_launch = bi_clock::now();
     {
         EventScope ev(c);
 #define BI_SINGLE(BBv, MODEv)                                                                                          \
@@ -146,12 +153,18 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
         hipLaunchKernelGGL(k_finish_single, dim3(1), block, 0, c->stream, (const double*)a.partial, (const unsigned*)a.pflags,
                            nbx, d.slot_lg, d.out, d.status, d.done, d.seq);
     HIP_TRY(c, hipGetLastError());
+    const auto t_wait = bi_clock::now();
+    c->single_ns[0] += ns_between(t_entry, t_launch);
+    c->single_ns[1] += ns_between(t_launch, t_wait);
+    ++c->single_calls;
     if (!wait) {
         c->pending = 1;
         c->pending_seq = d.seq;
         return BI_OK;
     }
-    return single_wait(c, d.seq, out, status);
+    rc = single_wait(c, d.seq, out, status);
+    c->single_ns[2] += ns_between(t_wait, bi_clock::now());
+    return rc;
 }
 
 // One point, synchronous: the call shape of `lf(**kwargs)` inside a minimizer (inference.py:111-122 makes
@@ -160,6 +173,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
 // wait = false: launch only (bi_eval_begin).  Answers that need no launch -- and the rare fallback path, which then
 // runs synchronously -- are parked in the context (pending = 2) for bi_eval_end.
 int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds, double* out, int32_t* status, bool wait = true) {
+    const auto t_entry = bi_clock::now();
     double parked_ll = 0.0;
     int32_t parked_st = 0;
     if (!wait) { out = &parked_ll; status = &parked_st; c->pending = 2; }
@@ -193,7 +207,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int nbx = (int)std::min<int64_t>(tiles, slots);
 
-    if (NS <= kMaxSingleStreams && c->single_kernel) return eval_single_fused(c, g, rates, ds, sparse, out, status, wait);
+    if (NS <= kMaxSingleStreams && c->single_kernel) return eval_single_fused(c, g, rates, ds, sparse, out, status, wait, t_entry);
 
     // general fallback (more streams than fit the kernel-argument block):
     // slot layout (8-byte units): rowoff[NS] coef[NS] aux[2] cnt_off tiles perm slot_lg | result {ll, status}

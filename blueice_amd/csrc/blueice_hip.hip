@@ -113,6 +113,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
+    dev_free(c->mail); dev_free(c->mail_flags);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     dev_free(c->pack_dev);
@@ -158,7 +159,10 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     }
     if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
     if (!strcmp(name, "single_kernel")) { c->single_kernel = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "fuse_finish")) { c->fuse_finish = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "single_timing_reset")) { c->single_ns[0] = c->single_ns[1] = c->single_ns[2] = 0; c->single_calls = 0; return BI_OK; }
     if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
+    if (!strcmp(name, "single_blocks_per_cu")) { if (v < 1 || v > 32) return fail(c, BI_ERR_INVALID, "single_blocks_per_cu in [1,32]"); c->single_blocks_per_cu = v; return BI_OK; }
     if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
@@ -185,7 +189,13 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "padded_bins")) return c->Bp;
     if (!strcmp(name, "sparse")) return c->sparse;
     if (!strcmp(name, "single_kernel")) return c->single_kernel;
+    if (!strcmp(name, "fuse_finish")) return c->fuse_finish;
+    if (!strcmp(name, "single_ns_host")) return c->single_ns[0];
+    if (!strcmp(name, "single_ns_launch")) return c->single_ns[1];
+    if (!strcmp(name, "single_ns_wait")) return c->single_ns[2];
+    if (!strcmp(name, "single_calls")) return c->single_calls;
     if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
+    if (!strcmp(name, "single_blocks_per_cu")) return c->single_blocks_per_cu;
     if (!strcmp(name, "xcd_affine")) return c->xcd_affine;
     if (!strcmp(name, "device_plan_min")) return c->device_plan_min;
     if (!strcmp(name, "scan_mfma")) return c->scan_mfma;
@@ -526,7 +536,19 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             b.partial = (double*)k.partial.p + i0 * k.nbx * k.G;
             b.pflags = (unsigned*)k.pflags.p + i0 * k.nbx * k.G;
             const bool nt = !plan->sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && plan->no_reuse));
+            // few items (a fit's or a bench step's batch): the last block of every item finishes it inside the launch
+            const bool fuse = c->fuse_finish && k.n_items * k.nbx * k.G <= kMailSlots && k.n_items * k.G <= kMailFlagWords &&
+                              !ensure_mail(c);
+            if (fuse) {
+                b.fin_mail = (double*)c->mail.p;
+                b.fin_flags = (unsigned*)c->mail_flags.p;
+                b.fin_perm = (const int64_t*)k.perm.p;
+                b.fin_slot_lg = (const double*)k.slot_lg.p;
+                b.fin_out = out;
+                b.fin_status = (int32_t*)plan->status.p;
+            }
             launch_morph_g(c, k.G, b, dim3((unsigned)k.nbx, (unsigned)ni), bb, nt);
+            if (fuse) continue;
             const int64_t n_slots = ni * k.G;
             const int lanes = k.nbx > 64 ? kThreads : 64;
             const int per_block = kThreads / lanes;
@@ -1223,6 +1245,43 @@ int bi_measure_read_bandwidth(bi_ctx* c, int nontemporal, int blocks_per_cu, int
     if (e1) (void)hipEventDestroy(e1);
     dev_free(sink);
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_measure_read_bandwidth: %s", hipGetErrorString(e));
+    *gb_per_s = best;
+    return BI_OK;
+}
+
+int bi_measure_stream_bandwidth(bi_ctx* c, int items, int rows, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || reps < 1 || blocks_per_cu < 1 || items < 1 || rows < 1) return BI_ERR_INVALID;
+    if (!c->model_ready || !c->ps.p) return fail(c, BI_ERR_STATE, "bi_measure_stream_bandwidth: no model resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf sink;
+    int rc = dev_alloc(c, sink, 8);
+    if (rc) return rc;
+    const int64_t total_rows = c->A * c->S;
+    const int n_tiles = n_tiles_of(c);
+    // same launch shape as a batched morph launch: blocks_per_cu resident blocks per CU over all items
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * blocks_per_cu;
+    const int nbx = (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, slots / items));
+    const dim3 grid((unsigned)nbx, (unsigned)items);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; e == hipSuccess && r <= reps; ++r) {      // the first pass is the warm-up; every pass starts elsewhere
+        const int64_t first = ((int64_t)r * items * rows * 7) % total_rows;
+        e = hipEventRecord(e0, c->stream);
+        if (nontemporal) hipLaunchKernelGGL(k_read_rows<true>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->Bp, total_rows, first, rows, n_tiles, (int)c->tile_chunks, (double*)sink.p);
+        else hipLaunchKernelGGL(k_read_rows<false>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->Bp, total_rows, first, rows, n_tiles, (int)c->tile_chunks, (double*)sink.p);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r > 0 && ms > 0.f)
+            best = std::max(best, (double)items * rows * (double)c->Bp * 8.0 / (ms * 1e6));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dev_free(sink);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_measure_stream_bandwidth: %s", hipGetErrorString(e));
     *gb_per_s = best;
     return BI_OK;
 }

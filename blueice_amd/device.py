@@ -31,6 +31,7 @@ class DeviceContext:
             raise DeviceError("bi_create(device=%d) failed: %s" % (
                 device, self._lib.bi_last_error(None).decode()))
         self.device = device
+        self._one_out, self._one_st, self._one_ds = C.c_double(), C.c_int32(), C.c_int64()
         self.d = self.S = self.B = None
         self.T = 0
         self.bb_source = -1
@@ -200,6 +201,23 @@ class DeviceContext:
             dataset = np.ascontiguousarray(np.broadcast_to(np.asarray(dataset, dtype=np.int64), (P,)))
         return P, z, rate_scale, dataset
 
+    def eval_one(self, z, rate_scale=None, dataset=0):
+        """One point, the call `lf(**kw)` makes inside a minimizer: -> (ll, status) as Python scalars, with as
+        little marshalling as ctypes allows (z [d] and rate_scale [S] must be float64 arrays or None)."""
+        if z is not None and (z.dtype != np.float64 or not z.flags.c_contiguous or z.size != self.d):
+            z = as_f64(z).reshape(self.d)
+        if rate_scale is not None and (rate_scale.dtype != np.float64 or not rate_scale.flags.c_contiguous
+                                       or rate_scale.size != self.S):
+            rate_scale = as_f64(rate_scale).reshape(self.S)
+        ds = self._one_ds
+        ds.value = dataset
+        rc = self._lib.bi_eval(self._h, 1, z.ctypes.data if self.d else None,
+                               rate_scale.ctypes.data if rate_scale is not None else None, C.addressof(ds),
+                               C.addressof(self._one_out), C.addressof(self._one_st))
+        if rc:
+            self._check(rc)
+        return self._one_out.value, self._one_st.value
+
     def eval(self, z, rate_scale=None, dataset=None):
         """-> (ll [P], status [P]); z [P, d] (or [d]), rate_scale [P, S] or None, dataset [P] or None."""
         P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)
@@ -299,6 +317,14 @@ class DeviceContext:
         out = C.c_double()
         self._check(self._lib.bi_measure_read_bandwidth(self._h, 1 if nontemporal else 0, int(blocks_per_cu), int(reps),
                                                         C.byref(out)))
+        return out.value
+
+    def stream_bandwidth(self, items=8, rows=32, nontemporal=True, blocks_per_cu=8, reps=5):
+        """GB/s of `items` work items streaming `rows` template rows each with the morph kernel's access pattern and
+        no arithmetic: the ceiling the morph + reduce kernel is held against."""
+        out = C.c_double()
+        self._check(self._lib.bi_measure_stream_bandwidth(self._h, int(items), int(rows), 1 if nontemporal else 0,
+                                                          int(blocks_per_cu), int(reps), C.byref(out)))
         return out.value
 
     def copy_bandwidth(self, nbytes=1 << 31, reps=3):

@@ -23,7 +23,7 @@ from scipy import stats
 
 from . import _capi
 from .device import DeviceContext
-from .exceptions import InvalidParameter, InvalidParameterSpecification, NotPreparedException
+from .exceptions import DeviceError, InvalidParameter, InvalidParameterSpecification, NotPreparedException
 from .histdd import Histdd
 from .model import Model
 from .pdf_morphers import MORPHERS
@@ -289,6 +289,8 @@ class DeviceLogLikelihood(LogLikelihoodBase):
 
     # -- evaluation ------------------------------------------------------------------------
     def _interpret(self, ll, status, mus_hint=None):
+        if status & _capi.ST_INTERNAL:
+            raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
         if status & _capi.ST_UNPHYSICAL:
             if self.config.get('unphysical_behaviour') == 'error':
                 raise ValueError("Unphysical rates: %s" % str(mus_hint))
@@ -314,8 +316,8 @@ class DeviceLogLikelihood(LogLikelihoodBase):
             if ll == -float('inf') and st:
                 return ll
             return prior + ll, mus, ps.reshape((len(mus),) + tuple(self.bin_shape))
-        ll, st = self.ctx.eval(zs if len(zs) else None, scale[None, :])
-        return self._finish_call(prior, zs, scale, float(ll[0]), int(st[0]))
+        ll, st = self.ctx.eval_one(zs, scale)
+        return self._finish_call(prior, zs, scale, ll, st)
 
     def _finish_call(self, prior, zs, scale, ll, st):
         if st:
@@ -425,6 +427,8 @@ class DeviceLogLikelihood(LogLikelihoodBase):
         (or raise, under unphysical_behaviour='error'), exactly as the scalar call."""
         z, scale, prior = self._batch_terms(points, livetime_days)
         ll, st = self.ctx.eval(z if z.shape[1] else None, scale, dataset)
+        if np.any(st & _capi.ST_INTERNAL):
+            raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
         bad = st & _capi.ST_UNPHYSICAL
         if np.any(bad) and self.config.get('unphysical_behaviour') == 'error':
             raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(bad)), len(st)))

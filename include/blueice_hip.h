@@ -42,7 +42,8 @@ enum {
     BI_ST_UNPHYSICAL = 2,    /* rates not in [0, inf) [-inf or ValueError, likelihood.py:397-415] */
     BI_ST_BB_ROOT1 = 4,      /* Beeston-Barlow `assert all(A1 <= 0)` would fail [likelihood.py:649] */
     BI_ST_BB_NEG = 8,        /* Beeston-Barlow `assert all(0 <= A)` would fail [likelihood.py:655] */
-    BI_ST_BAD_DATASET = 16   /* dataset index out of range */
+    BI_ST_BAD_DATASET = 16,  /* dataset index out of range */
+    BI_ST_INTERNAL = 32      /* the in-launch reduction gave up waiting for a partial sum (result nan): a device fault */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -217,6 +218,10 @@ int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
  * own copy over the first `bytes` of the template tensor into a scratch buffer -- the other usual ceiling. */
 int bi_measure_read_bandwidth(bi_ctx* ctx, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s);
 int bi_measure_copy_bandwidth(bi_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
+/* the same read-only ceiling with the morph kernel's own access pattern: `items` work items that each stream `rows`
+ * template rows concurrently (16 bytes per lane per row, XCD-aware tile order, the grid a batched launch would get)
+ * and do nothing with them -- what k_morph_reduce's GB/s is to be held against; best of `reps` passes */
+int bi_measure_stream_bandwidth(bi_ctx* ctx, int items, int rows, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s);
 int bi_profile_enable(bi_ctx* ctx, int on);
 int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
 /* Tunables (bi_set_param; all have measured defaults) and read-only counters (bi_get_param):
@@ -226,6 +231,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   nt_loads          0 never | 1 always | 2 nontemporal template loads when no two items share an anchor (default)
  *   tile_chunks       XCD-aware tile order: contiguous regions per row (8; 1 = plain order)
  *   single_kernel, fuse_max_blocks   one-launch path of single evaluations, in-launch finish up to this many blocks
+ *   single_blocks_per_cu   single evaluations: blocks per CU the launch shape aims for, equal tiles per block (4)
+ *   fuse_finish       batched launches whose partial sums fit the context's mailbox (2^20 slots): the last block of an
+ *                     item collects the item's partials inside the launch, no finish launch follows (1)
  *   keep_rows         single dense evaluations repeated in one cell: stream rows that keep the default cache policy so
  *                     they stay in the Infinity Cache between calls (-1 = as many as fit, default; 0 = none)
  *   poll_result       single evaluations: poll the pinned result word instead of a stream synchronise (1)
@@ -236,7 +244,10 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
  *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
- * read-only: tile_bins, padded_bins, n_scan_launches, csr_ready, compact_ready, ps_nonneg, nnz_total */
+ *   single_timing_reset   (write) zero the single-call wall-time accumulators below
+ * read-only: tile_bins, padded_bins, n_scan_launches, csr_ready, compact_ready, ps_nonneg, nnz_total;
+ *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
+ *                     bi_eval(P = 1): host half (geometry, rates, descriptors), launch calls, wait for the result */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
 int64_t bi_get_param(bi_ctx* ctx, const char* name);
 
