@@ -32,7 +32,12 @@ def build(force=False, verbose=False):
     cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-shared', '-fPIC',
            # no implicit FMA contraction: the compatibility morph and the Beeston-Barlow roots follow the
            # reference's operation order exactly; the hot loop uses explicit fma()
-           '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
+           '-ffp-contract=off',
+           # fp64 MFMA accumulators in VGPRs: the scan kernels compare / use every matrix element with vector
+           # instructions, and with the accumulators in AGPRs each element costs two v_accvgpr_read first (no vector
+           # instruction executes beside an fp64 MFMA on gfx950, so every one of them is MFMA time lost)
+           '-mllvm', '--amdgpu-mfma-vgpr-form',
+           '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

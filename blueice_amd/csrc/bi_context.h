@@ -29,6 +29,7 @@ struct bi_plan {
         int64_t n_items = 0;
         int nbx = 0;
         DevBuf rowoff, coef, aux, item_cnt, item_tiles, perm, slot_lg, partial, pflags;
+        DevBuf rowoff_full;        // split scans: offsets of the FULL rows of every item (validity pass)
     };
     std::vector<Class> classes;
     DevBuf bad_idx;            // points answered on the host side with -inf
@@ -42,6 +43,9 @@ struct bi_plan {
     int64_t n_groups = 0;
     int scan_cb = 4;              // its strip width in 16-bin blocks
     DevBuf grp_first, grp_items;
+    bool valid = false;           // split dense scan: classes hold the non-empty-bin pass, k_scan_valid checks every bin
+    int valid_nslots = 0;         // its waves per group
+    DevBuf bad;                   // [items][16] flags it raises
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
@@ -117,6 +121,7 @@ struct bi_ctx {
     DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz;
     int64_t plan_tables_epoch = -1;
     bool plan_tables_sparse = false;
+    int64_t n_valid_launches = 0;                // how often the validity pass of a split scan ran
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
     int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
     int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
@@ -126,6 +131,8 @@ struct bi_ctx {
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
     int64_t toy_offset = 0;                      // bi_generate_toys: toy t of the call is dataset toy_offset + t of the seed's stream
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
+    int64_t scan_split = 1;                      // dense scans over mostly empty data: non-empty-bin pass + matrix-core validity pass
+    int64_t sparse_at_upload = 1;                // value of `sparse` when the resident data were uploaded
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
@@ -287,10 +294,10 @@ inline int packed_upload(bi_ctx* c, const std::vector<std::pair<const void*, siz
 void free_plan_buffers(bi_plan* p) {
     for (auto& k : p->classes) {
         dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
-        dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags);
+        dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags); dev_free(k.rowoff_full);
     }
     dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
-    dev_free(p->slab);
+    dev_free(p->slab); dev_free(p->bad);
 }
 
 }  // namespace

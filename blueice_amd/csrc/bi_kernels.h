@@ -1409,4 +1409,112 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
     }
 }
 
+// ---- the validity pass of a dense scan over sparse data -----------------------------------------------------
+// "Every bin visited" with mostly empty data splits into two passes (plan->valid, bi_planning_device.h):
+//   (A) the bins WITH data, on the compacted rows: n log mu - mu for those bins, and the linear remainder
+//       -sum_{empty b} mu_b = -sum_k coef_k * (row total over the empty bins) from tables -- the non-empty-bin form;
+//   (B) this kernel, over ALL bins: mu[point][bin] on the fp64 matrix cores exactly as in k_scan_mfma, and the one
+//       thing an empty bin can still do to the result -- scipy's poisson.logpmf is nan where mu is negative or nan
+//       (blueice/likelihood.py:674), whatever n is.  So the epilogue is one compare per matrix element, no logarithm,
+//       no running sums, no cross-lane reduction; a point with any such bin is flagged and set to nan afterwards.
+// With non-negative templates and rates (B) can never fire (that is why (A) alone is the default path); it is what makes
+// the split exact for templates or rates of either sign.  Per 16-point item and 64-bin strip: 32 MFMAs (2048 cycles of
+// the SIMD's fp64 pipe) + 16 v_cmp -- against ~240 vector instructions in k_scan_mfma, which matter because on this
+// chip NO vector instruction executes beside an fp64 MFMA (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_scan_pmc.json).
+struct ValidArgs {
+    const double* ps;
+    const int64_t* rowoff;      // [items][NS] element offsets of the FULL rows (rows of a group = rows of its first item)
+    const double* coef;         // [items][NS][16]
+    const int64_t* grp_first;   // [groups]
+    const int32_t* grp_items;   // [groups]
+    unsigned* bad;              // [items][16], zero on entry: set to 1 where a point has a bin with mu < 0 or nan
+    int NS;
+    int nslots;                 // waves per group = gridDim.x * 4
+    int n_strips;               // strips of 16 CB bins per full row
+};
+
+template <int CB, int KG, bool MASK>
+__global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
+    constexpr int STRIP = CB * 16;
+    const int grp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    const int64_t item0 = a.grp_first[grp];
+    const int n_items = a.grp_items[grp];
+    const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
+    const int kq = lane >> 4, col = lane & 15;
+    const int aoff0 = min(kq, a.NS - 1) * 16 + col;
+
+    for (int strip = slot; strip < a.n_strips; strip += a.nslots) {
+        const int64_t bin0 = (int64_t)strip * STRIP + col;
+        double b[KG][CB];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int64_t row = rowoff[min(kg * 4 + kq, a.NS - 1)];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16];
+        }
+        double av[KG];
+        {
+            const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 4 + kq;
+                av[kg] = coef[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) av[kg] = 0.0;
+            }
+        }
+        for (int it = 0; it < n_items; ++it) {
+            const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
+            double an[KG];
+            bi_double4 acc[CB];
+            unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};      // per r: lanes whose element is not >= 0
+#define BI_VCHAIN(cb)                                                                                              \
+    do {                                                                                                           \
+        acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
+        _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
+            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], b[kg][cb], acc[cb], 0, 0, 0);                   \
+    } while (0)
+#define BI_VCHECK(cb)                                                                                              \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] |= __ballot(!(acc[cb][r] >= 0.0));                      \
+    } while (0)
+            BI_VCHAIN(0);
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 4 + kq;
+                an[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) an[kg] = 0.0;
+            }
+#pragma unroll
+            for (int cb = 1; cb < CB; ++cb) {
+                BI_VCHAIN(cb);
+                BI_VCHECK(cb - 1);
+            }
+            BI_VCHECK(CB - 1);
+#undef BI_VCHAIN
+#undef BI_VCHECK
+            if ((m[0] | m[1] | m[2] | m[3]) != 0ull) {         // rare (never with templates and rates >= 0)
+                // element r of lane (kq, col) belongs to point kq + 4 r; lane 16 kq speaks for its row of 16 bins
+                if (col == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((m[r] >> (16 * kq)) & 0xFFFFull) atomicOr(a.bad + (item0 + it) * 16 + kq + 4 * r, 1u);
+                }
+            }
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg];
+        }
+    }
+}
+
+// out[perm[slot]] = nan where the validity pass flagged the slot
+__global__ __launch_bounds__(kThreads) void k_apply_bad(const unsigned* __restrict__ bad, const int64_t* __restrict__ perm,
+                                                        int64_t n_slots, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_slots || !bad[i]) return;
+    const int64_t p = perm[i];
+    if (p >= 0) out[p] = __builtin_nan("");
+}
+
 }  // namespace

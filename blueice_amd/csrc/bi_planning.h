@@ -50,7 +50,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     const int NS = n0 + n1 + n2;
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
+    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !bb && !any_neg && !c->unbinned;
     const int64_t n_rows = c->A * S;
     if (!sparse && !c->dense_counts)
         return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "

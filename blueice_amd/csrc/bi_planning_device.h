@@ -129,7 +129,8 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
                                                         const double* __restrict__ rates, int64_t* __restrict__ rowoff,
                                                         double* __restrict__ coef, int64_t* __restrict__ cnt_off,
                                                         int32_t* __restrict__ tiles, int64_t* __restrict__ perm,
-                                                        double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum) {
+                                                        double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum,
+                                                        int64_t* __restrict__ rowoff_full /* split scans, else NULL */) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const int64_t p = idx[i];
@@ -152,7 +153,10 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
             const double tz = m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0;
             coef[(item * NS + k + s) * kDevG + g] = cf;
             if (m.sparse) zsum += cf * tz;
-            if (g == 0) rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
+            if (g == 0) {
+                rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
+                if (rowoff_full) rowoff_full[item * NS + k + s] = (a * m.S + s) * m.Bp;
+            }
         }
         k += m.S;
     }
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(kThreads) void k_fill_bad_by_status(const int32_t* 
 }
 
 // model / data tables the planning kernels read, mirrored on the device once per model+data epoch
-int ensure_plan_tables(bi_ctx* c, bool sparse) {
-    if (c->plan_tables_epoch == c->epoch && c->plan_tables_sparse == sparse) return BI_OK;
+int ensure_plan_tables(bi_ctx* c) {
+    if (c->plan_tables_epoch == c->epoch) return BI_OK;
     int rc;
     std::vector<double> grid;
     for (auto& g : c->grid) grid.insert(grid.end(), g.begin(), g.end());
@@ -202,22 +206,21 @@ int ensure_plan_tables(bi_ctx* c, bool sparse) {
     if ((rc = dev_upload(c, c->pt_grid, grid)) || (rc = dev_upload(c, c->pt_mus, c->h_mus)) ||
         (rc = dev_upload(c, c->pt_coff, coff)) || (rc = dev_upload(c, c->pt_allow, c->allow_neg)))
         return rc;
-    if (sparse && ((rc = dev_upload(c, c->pt_c_off, c->h_c_off)) || (rc = dev_upload(c, c->pt_cnt_off, c->h_cnt_off)) ||
-                   (rc = dev_upload(c, c->pt_c_np, c->h_c_np)) || (rc = dev_upload(c, c->pt_Tz, c->h_Tz))))
+    if (c->compact_ready && ((rc = dev_upload(c, c->pt_c_off, c->h_c_off)) || (rc = dev_upload(c, c->pt_cnt_off, c->h_cnt_off)) ||
+                             (rc = dev_upload(c, c->pt_c_np, c->h_c_np)) || (rc = dev_upload(c, c->pt_Tz, c->h_Tz))))
         return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->plan_tables_epoch = c->epoch;
-    c->plan_tables_sparse = sparse;
     return BI_OK;
 }
 
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
                        bi_plan** out) {
-    int rc = ensure_plan_tables(c, sparse);
+    int rc = ensure_plan_tables(c);
     if (rc) return rc;
     const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
     PlanMeta m{};
-    m.d = d; m.S = S; m.de = de; m.nc = nc; m.unbinned = c->unbinned ? 1 : 0; m.sparse = sparse ? 1 : 0;
+    m.d = d; m.S = S; m.de = de; m.nc = nc; m.unbinned = c->unbinned ? 1 : 0; m.sparse = sparse ? 1 : 0;   // (split scans switch m.sparse on below)
     m.T = c->T; m.Bp = c->Bp; m.n_rows = c->A * S;
     int off = 0;
     for (int i = 0; i < d; ++i) { m.n_anchor[i] = c->n_anchor[(size_t)i]; m.grid_off[i] = off; off += c->n_anchor[(size_t)i]; m.astride[i] = c->astride[(size_t)i]; }
@@ -290,6 +293,24 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
         const int64_t n_items = h_scal[1];
+        // groups of items sharing (cell, dataset): their number decides which kernels take the batch
+        hipLaunchKernelGGL(k_plan_group_flags, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
+        tb = d_tmp.bytes;
+        (void)hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (int)n_valid, c->stream);   // d_idx = group id + 1
+        int64_t n_groups = 0;
+        e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+        const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
+        const bool scan_shape = c->scan_mfma && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535;
+        // Every bin visited, mostly empty data, several items per cell: split the scan into the non-empty-bin pass (the
+        // descriptors below then describe the compacted rows, as for a sparse plan) and a validity pass over all bins on
+        // the matrix cores (k_scan_valid).  The two together are exact for templates and rates of either sign.
+        const bool split = !sparse && c->scan_split && scan_shape && c->compact_ready && c->dense_counts &&
+                           n_items >= c->scan_min_items * n_groups;
+        const bool compacted = sparse || split;
+        m.sparse = compacted ? 1 : 0;
+        plan->sparse = compacted;
         plan->classes.emplace_back();
         bi_plan::Class& k = plan->classes.back();
         k.G = kDevG;
@@ -297,7 +318,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         const int n_tiles = n_tiles_of(c);
         const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
         int64_t max_tiles = n_tiles;
-        if (sparse) max_tiles = *std::max_element(c->h_c_np.begin(), c->h_c_np.end()) / kTile;
+        if (compacted) max_tiles = *std::max_element(c->h_c_np.begin(), c->h_c_np.end()) / kTile;
         int64_t nbx = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + n_items - 1) / n_items));
         if (n_items == 1) nbx = std::min<int64_t>(max_tiles, slots);
         if (c->xcd_affine && n_items > 1 && nbx > 4 && nbx < max_tiles) nbx = std::min<int64_t>(max_tiles, (nbx + 7) / 8 * 8);
@@ -306,7 +327,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if ((rc = dev_alloc(c, k.rowoff, ni * NS * 8)) || (rc = dev_alloc(c, k.coef, ni * NS * kDevG * 8)) || (rc = dev_alloc(c, k.aux, ni * kDevG * 16)) ||
             (rc = dev_alloc(c, k.item_cnt, ni * 8)) || (rc = dev_alloc(c, k.item_tiles, ni * 4)) || (rc = dev_alloc(c, k.perm, ni * kDevG * 8)) ||
             (rc = dev_alloc(c, k.slot_lg, ni * kDevG * 8)) || (rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||
-            (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))))
+            (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))) ||
+            (split && (rc = dev_alloc(c, k.rowoff_full, ni * NS * 8))))
             return abort_plan(rc);
         e = hipMemsetAsync(k.coef.p, 0, ni * NS * kDevG * 8, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(k.perm.p, 0xFF, ni * kDevG * 8, c->stream);     // -1: padding slots
@@ -315,49 +337,59 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         hipLaunchKernelGGL(k_plan_fill, dim3(vblk), dim3(kThreads), 0, c->stream, m, n_valid, (const uint64_t*)d_keys2.p,
                            (const int64_t*)d_idx2.p, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, (const double*)d_wts.p,
                            (const double*)d_rates.p, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
-                           (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2));
+                           (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
+                           split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
-        plan->bytes = (int64_t)sizeof(double) * ((int64_t)NS + 1) * (sparse ? h_scal[2] * kTile : n_items * c->B);
+        plan->bytes = (int64_t)sizeof(double) * ((int64_t)NS + 1) * (compacted ? h_scal[2] * kTile : n_items * c->B);
         plan->launches = (n_items + 65534) / 65535;
 
-        // groups of items sharing (cell, dataset), for the matrix-core scan kernel
-        hipLaunchKernelGGL(k_plan_group_flags, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
-        tb = d_tmp.bytes;
-        (void)hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (int)n_valid, c->stream);   // d_idx = group id + 1
-        int64_t n_groups = 0;
-        e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
-        // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
-        // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
-        // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
-        // larger part of the work)
-        const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
-        const bool scan_ok = c->scan_mfma && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535 &&
-                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
-                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
-        if (scan_ok) {
-            if ((rc = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
-                return abort_plan(rc);
+        auto group_tables = [&]() -> int {
+            int rc2;
+            if ((rc2 = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc2 = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
+                return rc2;
             hipLaunchKernelGGL(k_plan_group_first, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, (const int64_t*)d_idx.p,
                                (const int64_t*)d_keys.p, n_valid, (int64_t*)plan->grp_first.p);
             hipLaunchKernelGGL(k_plan_group_items, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                                (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p);
-            // scan_waves_per_cu waves per CU over all groups, evened out so that every wave gets the same number of
-            // strips (a block lasts as long as its busiest wave); every wave owns one partial slot per item
-            const int cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
-            const int64_t strips = max_tiles * (kTile / (16 * cb));
+            return BI_OK;
+        };
+        // scan_waves_per_cu waves per CU over all groups, evened out so that every wave gets the same number of
+        // strips (a block lasts as long as its busiest wave)
+        auto waves_per_group = [&](int64_t strips) -> int64_t {
             int64_t blocks = std::max<int64_t>(1, (c->scan_waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, strips / 4));
             const int64_t per_wave = (strips + 4 * blocks - 1) / (4 * blocks);
             blocks = (strips + 4 * per_wave - 1) / (4 * per_wave);
+            return blocks * 4;
+        };
+        if (split) {
+            if ((rc = group_tables()) || (rc = dev_alloc(c, plan->bad, ni * kDevG * sizeof(unsigned)))) return abort_plan(rc);
+            plan->valid = true;
+            plan->n_groups = n_groups;
+            plan->scan_cb = 4;
+            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64));
+            plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
+            plan->launches += 1;
+            e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+        }
+        // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
+        // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
+        // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
+        // larger part of the work)
+        const bool scan_ok = !split && scan_shape &&
+                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
+                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
+        if (scan_ok) {
+            if ((rc = group_tables())) return abort_plan(rc);
+            const int cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
             plan->use_scan = true;
             plan->scan_cb = cb;
             plan->n_groups = n_groups;
-            k.nbx = (int)(blocks * 4);
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)));       // every wave owns one partial slot per item
             dev_free(k.partial);
             dev_free(k.pflags);
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||

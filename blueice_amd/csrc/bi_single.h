@@ -199,7 +199,7 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     const int n0 = bb ? nc * (S - 1) : nc * S, n1 = bb ? nc : 0, n2 = bb ? nc : 0, NS = n0 + n1 + n2;
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !bb && !any_neg && !c->unbinned;
+    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !bb && !any_neg && !c->unbinned;
     if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t row_stride = sparse ? c->h_c_np[(size_t)ds] : c->Bp;
     const int64_t row_base = sparse ? c->h_c_off[(size_t)ds] : 0;

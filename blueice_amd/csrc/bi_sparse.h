@@ -9,7 +9,7 @@ int build_compact_templates(bi_ctx* c) {
     const int64_t T = c->T, Bp = c->Bp;
     int rc;
     hipError_t e;
-    if (!c->ps_nonneg || c->bb_source >= 0) return BI_OK;
+    if (c->bb_source >= 0 || !c->ps_finite) return BI_OK;   // (templates of either sign: the identity holds, only the validity of empty bins does not follow -- see k_scan_valid)
     const int64_t rows = c->A * c->S;
     c->h_c_np.assign((size_t)T, 0);
     c->h_c_off.assign((size_t)T, 0);
@@ -82,7 +82,11 @@ int build_sparse_forms(bi_ctx* c) {
         for (int k = 0; k < nchunks; ++k) { h_off[(size_t)t * nchunks + k] = run; run += h_cnt[(size_t)t * nchunks + k]; }
     }
     c->h_nz_off[(size_t)T] = run;
-    if (c->sparse == 0 || (c->sparse == 1 && run > T * B / 4)) { cleanup(); return BI_OK; }  // dense data: dense forms
+    c->sparse_at_upload = c->sparse;
+    // dense data (more than a quarter of the bins hold events): dense forms only, unless the caller forces the lists.
+    // Mostly empty data get the lists and the compacted templates whatever `sparse` says: with sparse = 0 they are
+    // used by split scans only (k_scan_valid), every other path then visits every bin
+    if (run > T * B / 4 && c->sparse != 2) { cleanup(); return BI_OK; }
     if ((rc = dev_upload(c, d_off, h_off)) || (rc = dev_alloc(c, c->nz_idx, (size_t)std::max<int64_t>(run, 1) * sizeof(int32_t))) ||
         (rc = dev_alloc(c, c->nz_n, (size_t)std::max<int64_t>(run, 1) * sizeof(double))) || (rc = dev_upload(c, c->nz_off, c->h_nz_off))) {
         cleanup();

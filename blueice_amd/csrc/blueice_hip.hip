@@ -166,6 +166,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
@@ -203,8 +204,12 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "nt_loads")) return c->nt_loads;
     if (!strcmp(name, "toy_offset")) return c->toy_offset;
     if (!strcmp(name, "compact_budget")) return c->compact_budget;
-    if (!strcmp(name, "csr_ready")) return c->csr_ready ? 1 : 0;
-    if (!strcmp(name, "compact_ready")) return c->compact_ready ? 1 : 0;
+    // "ready" = prepared AND in use as an evaluation path (with sparse = 0 at upload they serve split scans only)
+    if (!strcmp(name, "csr_ready")) return (c->csr_ready && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
+    if (!strcmp(name, "compact_ready")) return (c->compact_ready && c->ps_nonneg && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
+    if (!strcmp(name, "split_ready")) return (c->compact_ready && c->dense_counts) ? 1 : 0;
+    if (!strcmp(name, "scan_split")) return c->scan_split;
+    if (!strcmp(name, "n_valid_launches")) return c->n_valid_launches;
     if (!strcmp(name, "ps_nonneg")) return c->ps_nonneg ? 1 : 0;
     if (!strcmp(name, "nnz_total")) return c->csr_ready ? c->h_nz_off.back() : -1;
     return -1;
@@ -558,6 +563,33 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
                                (int32_t*)plan->status.p);
         }
     }
+    if (plan->valid) {
+        // split dense scan: the classes above were the non-empty-bin pass; now every bin of every cell, on the matrix cores
+        bi_plan::Class& k = plan->classes[0];
+        ValidArgs va{};
+        va.ps = (const double*)c->ps.p;
+        va.rowoff = (const int64_t*)k.rowoff_full.p; va.coef = (const double*)k.coef.p;
+        va.grp_first = (const int64_t*)plan->grp_first.p; va.grp_items = (const int32_t*)plan->grp_items.p;
+        va.bad = (unsigned*)plan->bad.p; va.NS = NS; va.nslots = plan->valid_nslots;
+        va.n_strips = n_tiles_of(c) * (kTile / 64);
+        HIP_TRY(c, hipMemsetAsync(plan->bad.p, 0, (size_t)k.n_items * k.G * sizeof(unsigned), c->stream));
+        {
+            EventScope ev(c);
+            ++c->n_valid_launches;
+            const dim3 vgrid((unsigned)(plan->valid_nslots / 4), (unsigned)plan->n_groups);
+            const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
+#define BI_VALID(KG)                                                                                              \
+    do {                                                                                                          \
+        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_valid<4, KG, false>), vgrid, dim3(kThreads), 0, c->stream, va); \
+        else hipLaunchKernelGGL((k_scan_valid<4, KG, true>), vgrid, dim3(kThreads), 0, c->stream, va);              \
+    } while (0)
+            if (kg == 1) BI_VALID(1); else if (kg == 2) BI_VALID(2); else if (kg == 4) BI_VALID(4); else BI_VALID(8);
+#undef BI_VALID
+        }
+        const int64_t n_slots = k.n_items * k.G;
+        hipLaunchKernelGGL(k_apply_bad, dim3((unsigned)((n_slots + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                           (const unsigned*)plan->bad.p, (const int64_t*)k.perm.p, n_slots, out);
+    }
     if (plan->n_bad > 0 && plan->device_planned)
         hipLaunchKernelGGL(k_fill_bad_by_status, dim3((unsigned)((plan->P + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                            (const int32_t*)plan->status.p, plan->P, out);
@@ -658,7 +690,7 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     const int nc = 1 << de, NS = nc * S;
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && !any_neg;
+    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !any_neg;
     if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t n_rows = c->A * S;
     const double ninf = -std::numeric_limits<double>::infinity();

@@ -241,11 +241,13 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   device_plan_min   batches of at least this many points are planned on the device (512)
  *   scan_mfma, scan_min_items, scan_cb, scan_waves_per_cu   the matrix-core scan kernel: on/off, items per cell from
  *                     which it is used (4; x2 for dense data), strip width (0 = by the data), launch width
+ *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
+ *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
  *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
- * read-only: tile_bins, padded_bins, n_scan_launches, csr_ready, compact_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
  *                     bi_eval(P = 1): host half (geometry, rates, descriptors), launch calls, wait for the result */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);

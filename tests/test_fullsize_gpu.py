@@ -204,6 +204,7 @@ def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
     counts = m.counts()
     counts[12345] = 2.5           # non-integer count -> -inf for every point of that dataset
     ctx.set_param('sparse', 0)
+    ctx.set_param('scan_split', 0)       # this test is about k_scan_mfma itself (per-bin terms in every bin), not the split path
     ctx.upload_counts(counts)
     rng = np.random.default_rng(8)
     n1 = 20000
@@ -237,6 +238,7 @@ def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
     bad, _ = ctx.eval(z[:n1], r[:n1])
     assert ctx.get_param('n_scan_launches') == before + 1
     assert np.all(np.isnan(bad))
+    ctx.set_param('scan_split', 1)
     ctx.set_param('sparse', 1)
 
 
@@ -259,6 +261,7 @@ def test_matrix_core_scan_small_stream_counts(S, n_anchor, bins):
     ctx = DeviceContext(0)
     m.upload(ctx)
     ctx.set_param('sparse', 0)
+    ctx.set_param('scan_split', 0)       # k_scan_mfma itself; the split path has its own test (test_fullsize_reference_gpu.py)
     model = m.dense_model()
     z, r = m.random_points(3000, seed=5)
     for dense in (False, True):

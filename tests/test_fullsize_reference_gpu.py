@@ -119,7 +119,7 @@ def test_c3_ten_thousand_toys(c2):
 @pytest.mark.parametrize('sparse', [1, 0])
 def test_c4_million_point_scan(c2, sparse):
     """configs[3] on one GPU: 10^6 parameter points over the C2 model in one call (device planner; non-empty-bin form,
-    and every bin visited on the matrix-core scan kernel); 8 points checked against the oracle, -inf outside the box."""
+    and every bin visited: non-empty-bin pass + validity pass on the matrix cores); 8 points checked against the oracle, -inf outside the box."""
     from oracle import blueice_oracle as orc
     m, ctx = c2
     P = 10 ** 6
@@ -129,10 +129,10 @@ def test_c4_million_point_scan(c2, sparse):
     z, r = m.random_points(P, seed=31)
     z[123456, 1] = 2.5                        # outside the anchor box
     r[654321, 2] = -0.5                       # unphysical rate
-    before = ctx.get_param('n_scan_launches')
+    before = ctx.get_param('n_valid_launches')
     ll, st = ctx.eval(z, r)
     if not sparse:
-        assert ctx.get_param('n_scan_launches') == before + 1        # the matrix-core kernel took it
+        assert ctx.get_param('n_valid_launches') == before + 1       # non-empty-bin pass + matrix-core validity pass of every bin
     assert ll[123456] == -np.inf and st[123456] == 1 and ll[654321] == -np.inf and st[654321] == 2
     ok = np.ones(P, bool)
     ok[[123456, 654321]] = False
@@ -170,3 +170,49 @@ def test_c5_all_625_anchor_models():
     assert plan.bytes == 8 * (16 * 6 + 16 + 1) * m.B
     plan.close()
     ctx.close()
+
+
+def test_split_scan_validity_pass_small_models():
+    """Dense scans over mostly empty data run as non-empty-bin pass + validity pass of every bin on the matrix cores
+    (k_scan_valid).  With templates that go NEGATIVE in some bins (a source allowed to be negative, a template with
+    negative entries) the validity pass must reproduce scipy's rule -- nan as soon as any bin, empty or not, has
+    mu < 0 -- exactly where the oracle says so, and must stay silent elsewhere."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    rng = np.random.default_rng(5)
+    for S, n_anchor, bins in [(4, (3, 3, 2), (30, 20, 12)), (3, (2, 3), (64, 33)), (4, (), (5000,))]:
+        m = SyntheticModel(S, n_anchor, bins, seed=99)
+        dense = m.dense_model()
+        # source 0 gets a template with a negative dip in a handful of bins of ONE anchor model
+        dip = rng.choice(m.B, 7, replace=False)
+        flat = dense['ps'].reshape(-1, S, m.B)
+        flat[0, 0, dip] = -3.0 * flat[0, 0, dip]
+        counts = m.counts(dense=False, scale=0.05 if m.B > 5000 else 0.02)
+        counts[dip[0]] = 0.0
+        ctx = DeviceContext(0)
+        ctx.upload_model(dense['anchor_z'], dense['ps'], dense['mus'])
+        ctx.set_allow_negative([0, 1] + [0] * (S - 2))
+        ctx.set_param('sparse', 0)
+        ctx.upload_counts(counts)
+        assert ctx.get_param('split_ready') == 1 and ctx.get_param('compact_ready') == 0
+        P = 6000
+        z, r = m.random_points(P, seed=3)
+        r[::3, 1] = -rng.uniform(0.0, 0.4, len(r[::3]))          # the source that may be negative, sometimes is
+        before = ctx.get_param('n_valid_launches')
+        got, st = ctx.eval(z, r)
+        assert ctx.get_param('n_valid_launches') == before + 1      # the split path took it
+        ctx.set_param('scan_split', 0)
+        ref_dev, st2 = ctx.eval(z, r)                               # every per-bin term in every bin (k_scan_mfma / k_morph_reduce)
+        ctx.set_param('scan_split', 1)
+        want = orc.loglikelihood_batch(dense, counts, z[::40], r[::40], allow_negative=[False, True] + [False] * (S - 2))
+        np.testing.assert_array_equal(st, st2)
+        n_nan = int(np.isnan(ref_dev).sum())
+        assert 0 < n_nan < P, n_nan                                  # the case is neither trivial nor all-nan
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref_dev))
+        np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref_dev))
+        fin = np.isfinite(ref_dev)
+        np.testing.assert_allclose(got[fin], ref_dev[fin], rtol=1e-11)
+        for a, b in zip(got[::40], want):
+            assert (np.isnan(a) and np.isnan(b)) or a == b or abs(a - b) <= RTOL * max(1.0, abs(b)), (a, b)
+        ctx.close()
