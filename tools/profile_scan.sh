@@ -14,6 +14,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 python3 tools/profile/scan_only.py 3 > "$OUT/plain.txt" 2>&1
 python3 tools/profile/scan_only.py 2 dense >> "$OUT/plain.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 tools/profile/scan_only.py 3 > "$OUT/kt.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktd" -o kt -- python3 tools/profile/scan_only.py 2 dense > "$OUT/ktd.txt" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc1" -o pmc -- python3 tools/profile/scan_only.py 2 > "$OUT/pmc1.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc2" -o pmc -- python3 tools/profile/scan_only.py 2 > "$OUT/pmc2.txt" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD --output-format csv -d "$OUT/pmc3" -o pmc -- python3 tools/profile/scan_only.py 2 > "$OUT/pmc3.txt" 2>&1
