@@ -1,12 +1,12 @@
 // bi_planning_device.h -- the planning of bi_planning.h done on the GPU, for large batches (scans).
 // The host version costs ~0.2 us per point even threaded, which caps the non-empty-bin form near 4 M
-// evaluations/s; here the per-point geometry, the (cell, dataset) sort (hipCUB radix sort), the chopping into
+// evaluations/s; here the per-point geometry, the (cell, dataset) sort (rocPRIM radix sort), the chopping into
 // 16-point work items (two prefix scans) and the descriptor fill all run on the device, and the only host
 // round trip is one 24-byte read of the item count.  Plain binned / unbinned likelihoods only
 // (Beeston-Barlow batches are planned on the host).
 #pragma once
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -262,15 +262,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     // sort (key, point) pairs: keys are cell * T + dataset, rejected points carry the largest key
     size_t tmp_bytes = 0;
     int end_bit = 64;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
-                                       (int64_t*)d_idx2.p, (int)P, 0, end_bit, c->stream);
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                                    (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     size_t scan_bytes = 0, scan_bytes2 = 0;
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, (const int64_t*)d_a.p, (int64_t*)d_b.p, hipcub::Max(), (int)P, c->stream);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes2, (const int64_t*)d_a.p, (int64_t*)d_b.p, (int)P, c->stream);
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, rocprim::maximum<int64_t>(), c->stream);
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes2, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, rocprim::plus<int64_t>(), c->stream);
     if ((rc = dev_alloc(c, d_tmp, std::max({tmp_bytes, scan_bytes, scan_bytes2, (size_t)256})))) return abort_plan(rc);
     size_t tb = d_tmp.bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
-                                           (int64_t*)d_idx2.p, (int)P, 0, end_bit, c->stream);
+    e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                                  (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
     int64_t* scal = (int64_t*)d_scal.p;   // [0] n_valid  [1] n_items  [2] sum of tiles
     HIP_TRY(c, hipMemsetAsync(scal, 0, 64, c->stream));
@@ -285,10 +285,10 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         const unsigned vblk = (unsigned)((n_valid + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const uint64_t*)d_keys2.p, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)hipcub::DeviceScan::InclusiveScan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, hipcub::Max(), (int)n_valid, c->stream);  // d_b = group start
+        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, rocprim::maximum<int64_t>(), c->stream);  // d_b = group start
         hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (int)n_valid, c->stream);               // d_keys = item index + 1
+        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);               // d_keys = item index + 1
         e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
@@ -296,7 +296,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // groups of items sharing (cell, dataset): their number decides which kernels take the batch
         hipLaunchKernelGGL(k_plan_group_flags, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (int)n_valid, c->stream);   // d_idx = group id + 1
+        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);   // d_idx = group id + 1
         int64_t n_groups = 0;
         e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
