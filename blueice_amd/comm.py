@@ -359,6 +359,19 @@ class RcclCommunicator:
         self.boot.close()
 
 
+class _BroadcastOnly:
+    """The bootstrap channel as RcclCommunicator's constructor sees it: rank / world and ONE broadcast."""
+
+    def __init__(self, boot):
+        self.rank, self.world, self._boot = boot.rank, boot.world, boot
+
+    def broadcast_bytes(self, data=None):
+        return self._boot.broadcast_bytes(data)
+
+    def close(self):
+        pass
+
+
 def connect(ctx=None, backend='rccl', rank=None, world=None, timeout=180.0):
     """The communicator of this process, from the launcher's environment (RANK / WORLD_SIZE, default one process).
 
@@ -386,10 +399,28 @@ def connect(ctx=None, backend='rccl', rank=None, world=None, timeout=180.0):
         boot.fallback_reason = reason or 'librccl.so could not be loaded on another rank'
         return boot
     comm = None
-    try:
-        comm = RcclCommunicator(ctx, boot)
-    except CommError as e:
-        reason = str(e)
+    # ncclCommInitRank blocks until every rank has arrived; should it never return on some box (a fabric or driver
+    # problem is not ours to debug inside a benchmark), give up after `timeout` and gather through the sockets
+    import threading
+    box = {}
+
+    def build():
+        try:
+            box['comm'] = RcclCommunicator(ctx, boot_for_init)
+        except BaseException as e:                         # CommError, OSError from ctypes, ...
+            box['error'] = e
+
+    boot_for_init = _BroadcastOnly(boot)                   # the init thread may only use the channel for the unique id
+    th = threading.Thread(target=build, name='rccl-init', daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        reason = 'ncclCommInitRank did not return within %.0f s' % timeout
+    elif 'error' in box:
+        reason = str(box['error'])
+    else:
+        comm = box['comm']
+        comm.boot = boot
     if boot.all_reduce(np.array([1.0 if reason else 0.0]), 'max')[0] > 0:
         if comm is not None:
             comm._comm = C.c_void_p()          # a communicator some rank failed to build is not usable: forget it

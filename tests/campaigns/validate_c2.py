@@ -37,22 +37,25 @@ if __name__ == '__main__':
 
     from blueice_amd.device import DeviceContext
     ctx = DeviceContext(0)
-    m.upload(ctx)
+    m.upload(ctx, threads=8)
     worst = 0.0
     for col, (kind, counts) in enumerate(DATA.items()):
         for sparse in (0, 1):
             ctx.set_param('sparse', sparse)
             ctx.upload_counts(counts)
-            for label, setup in (('vector kernel', dict(scan_mfma=0)), ('matrix-core scan', dict(scan_mfma=1, scan_min_items=1))):
+            for label, setup in (('vector kernel', dict(scan_mfma=0, scan_split=0)),
+                                 ('matrix-core scan, per-bin terms', dict(scan_mfma=1, scan_min_items=1, scan_split=0)),
+                                 ('matrix-core scan, split', dict(scan_mfma=1, scan_min_items=1, scan_split=1))):
                 for k, v in setup.items():
                     ctx.set_param(k, v)
-                before = ctx.get_param('n_scan_launches')
+                before = (ctx.get_param('n_scan_launches'), ctx.get_param('n_valid_launches'))
                 got, st = ctx.eval(z, r)
-                scan = ctx.get_param('n_scan_launches') - before
+                scan = ctx.get_param('n_scan_launches') - before[0]
+                valid = ctx.get_param('n_valid_launches') - before[1]
                 err = np.max(np.abs(got - want[:, col]) / np.abs(want[:, col]))
                 worst = max(worst, err)
-                print('%-6s data, sparse=%d, %-17s (scan launches %d): max rel diff %.2e, status bits %d' % (
-                    kind, sparse, label, scan, err, int(np.bitwise_or.reduce(st))), flush=True)
+                print('%-6s data, sparse=%d, %-32s (k_scan_mfma launches %d, k_scan_valid launches %d): max rel diff %.2e, status bits %d' % (
+                    kind, sparse, label, scan, valid, err, int(np.bitwise_or.reduce(st))), flush=True)
             single = np.array([ctx.eval(z[i], r[i])[0][0] for i in range(0, N, 8)])
             err = np.max(np.abs(single - want[::8, col]) / np.abs(want[::8, col]))
             worst = max(worst, err)
