@@ -446,7 +446,7 @@ def main():
     if rank == 0:
         try:
             stream_ceiling = max(ctx.stream_bandwidth(items=PPS, rows=NS, nontemporal=True, blocks_per_cu=b, reps=4)
-                                 for b in (8, 16))
+                                 for b in (8, 16, 32))
             linear_ceiling = max(ctx.read_bandwidth(nontemporal=True, blocks_per_cu=b, reps=3) for b in (16, 32))
             copy_ceiling = ctx.copy_bandwidth(1 << 31, reps=3)
         except Exception as e:                       # a measurement aid only: never fail the bench line over it
@@ -472,8 +472,8 @@ def main():
                          'step_minus_kernel_us': elapsed / K * 1e6 - ms / max(launches, 1) * 1e3,
                          'stream_ceiling': stream_ceiling, 'linear_read_ceiling': linear_ceiling,
                          'copy_ceiling': copy_ceiling,
-                         'ceiling_note': 'stream_ceiling: GB/s of the same launch shape (%d items x %d concurrent rows, '
-                                         '16 B per lane per row, nontemporal) with no arithmetic and no counts; '
+                         'ceiling_note': 'stream_ceiling: GB/s of the same launch shape (%d items x %d concurrent rows, 16 or '
+                                         '32 B per lane per row, nontemporal, best of three grid sizes) with no arithmetic and no counts; '
                                          'linear_read_ceiling: one linear 16-byte-load sum over the 4 GB tensor; '
                                          'copy_ceiling: bytes read + written per second of a 2 GiB device-to-device '
                                          'hipMemcpy; all in this process' % (PPS, NS)},

@@ -91,6 +91,7 @@ struct bi_ctx {
 
     // model statistics (for the sparse forms)
     std::vector<double> h_rowsum;  // [A*S] sum over bins of every ps row
+    std::vector<double> h_rowmin;  // [A*S] smallest entry of every ps row
     bool ps_nonneg = false;        // every ps entry is finite and >= 0
 
     // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
@@ -131,6 +132,8 @@ struct bi_ctx {
     int64_t scan_min_items = 4;                  // ... at least this many 16-point items per cell on average (x2: dense data)
     int64_t toy_offset = 0;                      // bi_generate_toys: toy t of the call is dataset toy_offset + t of the seed's stream
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
+    int64_t bb_exact = 2;                        // single-point Beeston-Barlow calls: N(z) in numpy's summation order: 0 never, 1 always, 2 when some bin can have U_b == 0
+    int64_t n_bb_exact = 0;                      // how often that pass ran
     int64_t scan_split = 1;                      // dense scans over mostly empty data: non-empty-bin pass + matrix-core validity pass
     int64_t sparse_at_upload = 1;                // value of `sparse` when the resident data were uploaded
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell

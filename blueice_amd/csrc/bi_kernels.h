@@ -119,7 +119,9 @@ __global__ __launch_bounds__(kThreads) void k_read_sum(const double* __restrict_
 // `rows` template rows of its own (row r of item i starts at element ((first + i * rows + r) % total_rows) * Bp), the
 // tiles of a row are walked in the XCD-aware order of morph_tiles, 16 bytes per lane per row, `rows` loads in flight
 // per lane in batches of 8 -- the ceiling `k_morph_reduce` can be held against (bi_measure_stream_bandwidth)
-template <bool NT>
+// PIECES: 16-byte pieces per lane per row (1 = the morph kernel's own 512-bin tiles; 2 = 1024-bin tiles, i.e. twice the
+// contiguous run per row per block -- to see whether a wider tile would raise the ceiling: it does not, by more than 1 %)
+template <bool NT, int PIECES>
 __global__ __launch_bounds__(kThreads) void k_read_rows(const double* __restrict__ ps, int64_t Bp, int64_t total_rows,
                                                         int64_t first, int rows, int n_tiles, int chunks_in,
                                                         double* __restrict__ sink) {
@@ -130,11 +132,14 @@ __global__ __launch_bounds__(kThreads) void k_read_rows(const double* __restrict
     for (int lt = blockIdx.x; lt < per_chunk * chunks; lt += gridDim.x) {
         const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
         if (tile >= n_tiles) continue;
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
+        const int64_t bin0 = (int64_t)tile * kTile * PIECES + threadIdx.x * kBinsPerThread;
 #pragma unroll 8
         for (int r = 0; r < rows; ++r) {
-            const double2 v = stream_load<NT>(ps + ((row0 + r) % total_rows) * Bp + bin0);
-            s += v.x + v.y;
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                const double2 v = stream_load<NT>(ps + ((row0 + r) % total_rows) * Bp + bin0 + q * kTile);
+                s += v.x + v.y;
+            }
         }
     }
     if (s == 0.123456789) sink[0] = s;      // keeps the loads alive, practically never stores
@@ -207,7 +212,7 @@ __device__ __forceinline__ void bb_roots(double a, double p, double U, double d,
 // The collector's wait is bounded (kMailTimeoutTicks of the 100 MHz wall clock): if a value never arrives it gives
 // up, reports BI_ST_INTERNAL and the result is nan -- no wave can spin forever.
 constexpr unsigned long long kMailEmpty = 0x7FF4B10E1CE00001ull;
-constexpr long long kMailTimeoutTicks = 20000000;                      // 0.2 s
+constexpr long long kMailTimeoutTicks = 200000000;                     // 2 s: far beyond any delay a busy, shared GPU causes
 
 __device__ __forceinline__ void mail_post(double* slot, double v) {
     if (v != v) v = __builtin_nan("");                                   // never the "empty" pattern
@@ -414,9 +419,11 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                 const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
+                    // (the reference's own order -- value = value + V * w, blueice/pdf_morphers.py:70 via scipy -- with
+                    // separate multiply and add: P_i and a feed the root formula, whose sign tests see last bits)
                     const double c = coef[(a.n0 + k) * G + g];
-                    pi[g][0] = fma(c, v.x, pi[g][0]);
-                    pi[g][1] = fma(c, v.y, pi[g][1]);
+                    pi[g][0] = __dadd_rn(pi[g][0], __dmul_rn(v.x, c));
+                    pi[g][1] = __dadd_rn(pi[g][1], __dmul_rn(v.y, c));
                 }
             }
 #pragma unroll 8
@@ -425,8 +432,8 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const double c = coef[(a.n0 + a.n1 + k) * G + g];
-                    ai[g][0] = fma(c, v.x, ai[g][0]);
-                    ai[g][1] = fma(c, v.y, ai[g][1]);
+                    ai[g][0] = __dadd_rn(ai[g][0], __dmul_rn(v.x, c));
+                    ai[g][1] = __dadd_rn(ai[g][1], __dmul_rn(v.y, c));
                 }
             }
             const double* __restrict__ aux = aux_base;
@@ -768,6 +775,61 @@ __global__ __launch_bounds__(kThreads) void k_row_total(const double* __restrict
         for (int w = 1; w < kThreads / 64; ++w) t += sh[w];
         out[blockIdx.x] = t;
     }
+}
+
+// The Beeston-Barlow normalisation N(z) = n_model_events[i].sum() (likelihood.py:645) in NUMPY'S summation order, so
+// that single-point calls hand bb_roots the very bits the reference computes (the knife edge at
+// U_b == 0).  np.sum over a contiguous array adds, in order, the pairwise sums of 8192-element chunks (its reduction
+// buffer); a chunk's pairwise sum (numpy loops_utils.h.src, pairwise_sum) splits in halves down to blocks of 128, and a
+// block is summed with 8 strided accumulators r_j = a[j] + a[8 + j] + ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
+// One block per chunk: interpolate a(z) for the chunk in the reference's order (value = value + V*w), reproduce that
+// tree.  The (shorter) last chunk is written out as values and summed on the host by the same rule (pairwise_sum_host).
+constexpr int kSumChunk = 8192;
+
+__global__ __launch_bounds__(kThreads) void k_bb_chunk_sums(const double* __restrict__ nm, const int64_t* __restrict__ rowoff,
+                                                            const double* __restrict__ w, int nc, int64_t B,
+                                                            double* __restrict__ chunk_sum, double* __restrict__ tail) {
+    __shared__ double a[kSumChunk / 2];
+    __shared__ double r[256];
+    __shared__ double leaf[64];
+    const int64_t b0 = (int64_t)blockIdx.x * kSumChunk;
+    const int n = (int)(B - b0 < (int64_t)kSumChunk ? B - b0 : (int64_t)kSumChunk);
+    if (n < kSumChunk) {                              // the last, partial chunk: values out, the host sums them
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+            double v = 0.0;
+            for (int c = 0; c < nc; ++c) v = __dadd_rn(v, __dmul_rn(nm[rowoff[c] + b0 + i], w[c]));
+            tail[i] = v;
+        }
+        return;
+    }
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kSumChunk / 2; i += kThreads) {
+            double v = 0.0;
+            for (int c = 0; c < nc; ++c) v = __dadd_rn(v, __dmul_rn(nm[rowoff[c] + b0 + half * (kSumChunk / 2) + i], w[c]));
+            a[i] = v;
+        }
+        __syncthreads();
+        {   // 32 blocks of 128 x 8 accumulators = 256 (block, j) pairs, one per thread
+            const int blk = threadIdx.x >> 3, j = threadIdx.x & 7;
+            double t = a[blk * 128 + j];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) t = __dadd_rn(t, a[blk * 128 + 8 * i + j]);
+            r[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const double* q = r + threadIdx.x * 8;
+            leaf[half * 32 + threadIdx.x] = __dadd_rn(__dadd_rn(__dadd_rn(q[0], q[1]), __dadd_rn(q[2], q[3])),
+                                                      __dadd_rn(__dadd_rn(q[4], q[5]), __dadd_rn(q[6], q[7])));
+        }
+    }
+    __syncthreads();
+    for (int stride = 1; stride < 64; stride <<= 1) {   // the halving recursion over 64 blocks = adjacent pairs, level by level
+        if (threadIdx.x < 64 && (threadIdx.x % (2 * stride)) == 0) leaf[threadIdx.x] = __dadd_rn(leaf[threadIdx.x], leaf[threadIdx.x + stride]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = leaf[0];
 }
 
 // full_output with Beeston-Barlow (likelihood.py:634-658) on already-morphed templates:

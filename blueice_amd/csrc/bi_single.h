@@ -35,6 +35,75 @@ int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status)
 }
 
 // wait = false (bi_eval_begin): return right after the launch; bi_eval_end collects the result with single_wait.
+// numpy's pairwise_sum (loops_utils.h.src) on a host array: the partial last chunk of k_bb_chunk_sums
+double pairwise_sum_host(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum_host(a, n2) + pairwise_sum_host(a + n2, n - n2);
+}
+
+// Can some bin have U_b == 0 (the other sources expecting exactly nothing) at this point?  Not if some other source has a
+// positive rate and strictly positive templates at every corner that carries weight.
+bool bb_zero_u_possible(const bi_ctx* c, const PointGeom& g, const double* rates) {
+    const int nc = (int)g.w.size();
+    for (int s = 0; s < c->S; ++s) {
+        if (s == c->bb_source || !(rates[s] > 0.0)) continue;
+        bool positive = true;
+        for (int corner = 0; corner < nc && positive; ++corner) {
+            if (!(g.w[(size_t)corner] > 0.0)) continue;                       // a corner without weight adds exactly 0
+            const int64_t a = g.cell_anchor + corner_offset(c, corner);
+            positive = c->h_rowmin[(size_t)(a * c->S + s)] > 0.0;
+        }
+        if (positive) return false;
+    }
+    return true;
+}
+
+// N(z) = sum_b a_b(z) exactly as the reference's `n_model_events[source_i].sum()` computes it (likelihood.py:645):
+// one extra pass over the 2^d corner rows of the Monte-Carlo counts (k_bb_chunk_sums), a few KB back, a short host loop.
+int bb_exact_total(bi_ctx* c, const PointGeom& g, double* N) {
+    const int nc = (int)g.w.size();
+    const int64_t B = c->B, n_full = B / kSumChunk, tail_n = B % kSumChunk;
+    const int64_t n_blocks = n_full + (tail_n ? 1 : 0);
+    if (n_blocks == 0) { *N = 0.0; return BI_OK; }
+    std::vector<int64_t> rowoff((size_t)nc);
+    for (int corner = 0; corner < nc; ++corner) rowoff[(size_t)corner] = (g.cell_anchor + corner_offset(c, corner)) * c->Bp;
+    PackedUpload pu;
+    const size_t out_doubles = (size_t)n_full + (size_t)tail_n;
+    int rc;
+    if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {g.w.data(), g.w.size() * sizeof(double)}},
+                            out_doubles * sizeof(double), pu)))
+        return rc;
+    double* h_out = (double*)pu.host_out();           // pinned: the kernel writes chunk sums and tail values straight to the host
+    hipLaunchKernelGGL(k_bb_chunk_sums, dim3((unsigned)n_blocks), dim3(kThreads), 0, c->stream, (const double*)c->nm.p,
+                       pu.dev<int64_t>(0), pu.dev<double>(1), nc, B, h_out, h_out + n_full);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "Beeston-Barlow total: %s", hipGetErrorString(e));
+    bool have = false;
+    double total = 0.0;
+    for (int64_t k = 0; k < n_full; ++k) { total = have ? total + h_out[k] : h_out[k]; have = true; }
+    if (tail_n) { const double t = pairwise_sum_host(h_out + n_full, tail_n); total = have ? total + t : t; }
+    *N = total;
+    ++c->n_bb_exact;
+    return BI_OK;
+}
+
 using bi_clock = std::chrono::steady_clock;
 inline int64_t ns_between(bi_clock::time_point a, bi_clock::time_point b) {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
@@ -93,6 +162,9 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
             d.coef[n0 + n1 + corner] = g.w[(size_t)corner];
             const double term = c->h_nm_tot[(size_t)a] * g.w[(size_t)corner];
             Ntot = Ntot + term;
+        }
+        if (c->bb_exact == 1 || (c->bb_exact == 2 && bb_zero_u_possible(c, g, rates))) {
+            if ((rc = bb_exact_total(c, g, &Ntot))) return rc;
         }
         d.aux[0] = rates[c->bb_source] / Ntot;
         d.aux[1] = Ntot;
@@ -252,6 +324,9 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
             coef[n0 + n1 + corner] = g.w[(size_t)corner];
             const double term = c->h_nm_tot[(size_t)a] * g.w[(size_t)corner];
             Ntot = Ntot + term;
+        }
+        if (c->bb_exact == 1 || (c->bb_exact == 2 && bb_zero_u_possible(c, g, rates))) {
+            if ((rc = bb_exact_total(c, g, &Ntot))) return rc;
         }
         aux[0] = rates[c->bb_source] / Ntot;
         aux[1] = Ntot;

@@ -167,6 +167,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
@@ -209,6 +210,8 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "compact_ready")) return (c->compact_ready && c->ps_nonneg && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
     if (!strcmp(name, "split_ready")) return (c->compact_ready && c->dense_counts) ? 1 : 0;
     if (!strcmp(name, "scan_split")) return c->scan_split;
+    if (!strcmp(name, "bb_exact")) return c->bb_exact;
+    if (!strcmp(name, "n_bb_exact")) return c->n_bb_exact;
     if (!strcmp(name, "n_valid_launches")) return c->n_valid_launches;
     if (!strcmp(name, "ps_nonneg")) return c->ps_nonneg ? 1 : 0;
     if (!strcmp(name, "nnz_total")) return c->csr_ready ? c->h_nz_off.back() : -1;
@@ -313,10 +316,12 @@ int bi_model_end(bi_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(st.data(), c->scratch.p, st.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->h_rowsum.assign((size_t)rows, 0.0);
+        c->h_rowmin.assign((size_t)rows, 0.0);
         c->ps_nonneg = true;
         c->ps_finite = true;
         for (int64_t r = 0; r < rows; ++r) {
             c->h_rowsum[(size_t)r] = st[(size_t)r * 3];
+            c->h_rowmin[(size_t)r] = st[(size_t)r * 3 + 1];
             if (!(st[(size_t)r * 3 + 1] >= 0.0) || st[(size_t)r * 3 + 2] != 0.0) c->ps_nonneg = false;
             if (st[(size_t)r * 3 + 2] != 0.0) c->ps_finite = false;
         }
@@ -542,8 +547,10 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             b.pflags = (unsigned*)k.pflags.p + i0 * k.nbx * k.G;
             const bool nt = !plan->sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && plan->no_reuse));
             // few items (a fit's or a bench step's batch): the last block of every item finishes it inside the launch
-            const bool fuse = c->fuse_finish && k.n_items * k.nbx * k.G <= kMailSlots && k.n_items * k.G <= kMailFlagWords &&
-                              !ensure_mail(c);
+            // (at most 256 collecting blocks at a time: they wait for their siblings, and must never be able to hold
+            // every slot of the chip while siblings still need one, whatever order the blocks are dispatched in)
+            const bool fuse = c->fuse_finish && k.n_items <= 256 && k.n_items * k.nbx * k.G <= kMailSlots &&
+                              k.n_items * k.G <= kMailFlagWords && !ensure_mail(c);
             if (fuse) {
                 b.fin_mail = (double*)c->mail.p;
                 b.fin_flags = (unsigned*)c->mail_flags.p;
@@ -1157,6 +1164,9 @@ int bi_eval_full(bi_ctx* c, const double* z, const double* rate_scale, int64_t d
         const double term = c->h_nm_tot[(size_t)(g.cell_anchor + corner_offset(c, (int)corner))] * g.w[corner];
         Ntot = Ntot + term;
     }
+    if (c->bb_exact == 1 || (c->bb_exact == 2 && bb_zero_u_possible(c, g, mus_out))) {
+        if ((rc = bb_exact_total(c, g, &Ntot))) return rc;     // as the evaluation above did
+    }
     const double p_cal = mus_out[i] / Ntot;
     std::vector<double> a_row((size_t)B);
     if ((rc = bi_interpolate(c, 2, z, a_row.data()))) return rc;
@@ -1289,26 +1299,32 @@ int bi_measure_stream_bandwidth(bi_ctx* c, int items, int rows, int nontemporal,
     int rc = dev_alloc(c, sink, 8);
     if (rc) return rc;
     const int64_t total_rows = c->A * c->S;
-    const int n_tiles = n_tiles_of(c);
-    // same launch shape as a batched morph launch: blocks_per_cu resident blocks per CU over all items
+    // same launch shape as a batched morph launch: blocks_per_cu resident blocks per CU over all items; both the morph
+    // kernel's own 512-bin tiles and (where the padded row length allows) 1024-bin tiles
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * blocks_per_cu;
-    const int nbx = (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, slots / items));
-    const dim3 grid((unsigned)nbx, (unsigned)items);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     double best = 0.0;
-    for (int r = 0; e == hipSuccess && r <= reps; ++r) {      // the first pass is the warm-up; every pass starts elsewhere
-        const int64_t first = ((int64_t)r * items * rows * 7) % total_rows;
-        e = hipEventRecord(e0, c->stream);
-        if (nontemporal) hipLaunchKernelGGL(k_read_rows<true>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->Bp, total_rows, first, rows, n_tiles, (int)c->tile_chunks, (double*)sink.p);
-        else hipLaunchKernelGGL(k_read_rows<false>, grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->Bp, total_rows, first, rows, n_tiles, (int)c->tile_chunks, (double*)sink.p);
-        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        float ms = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e == hipSuccess && r > 0 && ms > 0.f)
-            best = std::max(best, (double)items * rows * (double)c->Bp * 8.0 / (ms * 1e6));
+    for (int pieces = 1; pieces <= 2; ++pieces) {
+        if (c->Bp % (kTile * pieces)) continue;
+        const int n_tiles = (int)(c->Bp / (kTile * pieces));
+        const int nbx = (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, slots / items));
+        const dim3 grid((unsigned)nbx, (unsigned)items);
+        for (int r = 0; e == hipSuccess && r <= reps; ++r) {      // the first pass is the warm-up; every pass starts elsewhere
+            const int64_t first = ((int64_t)r * items * rows * 7) % total_rows;
+            e = hipEventRecord(e0, c->stream);
+#define BI_ROWS(NTv, Pv) hipLaunchKernelGGL((k_read_rows<NTv, Pv>), grid, dim3(kThreads), 0, c->stream, (const double*)c->ps.p, c->Bp, total_rows, first, rows, n_tiles, (int)c->tile_chunks, (double*)sink.p)
+            if (nontemporal) { if (pieces == 1) BI_ROWS(true, 1); else BI_ROWS(true, 2); }
+            else { if (pieces == 1) BI_ROWS(false, 1); else BI_ROWS(false, 2); }
+#undef BI_ROWS
+            if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && r > 0 && ms > 0.f)
+                best = std::max(best, (double)items * rows * (double)c->Bp * 8.0 / (ms * 1e6));
+        }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -232,8 +232,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   tile_chunks       XCD-aware tile order: contiguous regions per row (8; 1 = plain order)
  *   single_kernel, fuse_max_blocks   one-launch path of single evaluations, in-launch finish up to this many blocks
  *   single_blocks_per_cu   single evaluations: blocks per CU the launch shape aims for, equal tiles per block (4)
- *   fuse_finish       batched launches whose partial sums fit the context's mailbox (2^20 slots): the last block of an
- *                     item collects the item's partials inside the launch, no finish launch follows (1)
+ *   fuse_finish       batched launches of up to 256 work items whose partial sums fit the context's mailbox (2^20 slots):
+ *                     the last block of an item collects the item's partials inside the launch, no finish launch follows (1)
  *   keep_rows         single dense evaluations repeated in one cell: stream rows that keep the default cache policy so
  *                     they stay in the Infinity Cache between calls (-1 = as many as fit, default; 0 = none)
  *   poll_result       single evaluations: poll the pinned result word instead of a stream synchronise (1)
@@ -241,13 +241,16 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   device_plan_min   batches of at least this many points are planned on the device (512)
  *   scan_mfma, scan_min_items, scan_cb, scan_waves_per_cu   the matrix-core scan kernel: on/off, items per cell from
  *                     which it is used (4; x2 for dense data), strip width (0 = by the data), launch width
+ *   bb_exact          single-point Beeston-Barlow evaluations: N(z) = sum_b n_model[i, b] in numpy's own summation order (one more
+ *                     pass over the 2^d rows of MC counts), so that the root formula sees the reference's bits: 0 never, 1
+ *                     always, 2 when some bin can have U_b == 0 at the point (default)
  *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
  *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
  *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
- * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_bb_exact, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
  *                     bi_eval(P = 1): host half (geometry, rates, descriptors), launch calls, wait for the result */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);

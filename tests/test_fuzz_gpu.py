@@ -77,7 +77,9 @@ def test_random_configurations_match_oracle(seed):
             ctx.upload_model(model['anchor_z'], model['ps'], model['mus'], n_model=model['n_model'], bb_source=bb)
             ctx.upload_counts(counts)
             got, st = ctx.eval(z if d else None, r)
-            one = np.array([ctx.eval(z[i] if d else None, r[i])[0][0] for i in range(min(P, 5))])
+            singles = [ctx.eval(z[i] if d else None, r[i]) for i in range(min(P, 5))]
+            one = np.array([a[0] for a, _ in singles])
+            one_st = np.array([b[0] for _, b in singles])
             for i in range(P):
                 if np.isnan(want[i]) and bb >= 0:               # the reference asserts there
                     if not st[i] & 12:
@@ -92,6 +94,10 @@ def test_random_configurations_match_oracle(seed):
             for i in range(len(one)):
                 if np.isfinite(want[i]):
                     assert abs(one[i] - want[i]) <= RTOL * max(1, abs(want[i]))
+                if bb >= 0:
+                    # single-point calls see the reference's own bits (N in numpy's summation order): the assertion
+                    # status must agree EXACTLY, knife edge at U_b == 0 included -- no forgiveness here
+                    assert bool(one_st[i] & 12) == bool(np.isnan(want[i])), (seed, d, S, B, bb, sparse, i, int(one_st[i]), want[i])
             if bb < 0:
                 ll, gz, gs, _ = ctx.eval_grad(z if d else None, r)
                 fin = np.isfinite(want)
