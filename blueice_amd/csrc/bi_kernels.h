@@ -786,13 +786,20 @@ __global__ __launch_bounds__(kThreads) void k_row_total(const double* __restrict
 // tree.  The (shorter) last chunk is written out as values and summed on the host by the same rule (pairwise_sum_host).
 constexpr int kSumChunk = 8192;
 
-__global__ __launch_bounds__(kThreads) void k_bb_chunk_sums(const double* __restrict__ nm, const int64_t* __restrict__ rowoff,
-                                                            const double* __restrict__ w, int nc, int64_t B,
-                                                            double* __restrict__ chunk_sum, double* __restrict__ tail) {
+// blockIdx.x = point (fastest in dispatch order: the points of one cell read a chunk's rows back to back, out of L2),
+// blockIdx.y = chunk.  rowoff / w: [points][nc]; chunk_sum: [points][n_full]; tail: [points][B % 8192].
+__global__ __launch_bounds__(kThreads) void k_bb_chunk_sums(const double* __restrict__ nm, const int64_t* __restrict__ rowoff_all,
+                                                            const double* __restrict__ w_all, int nc, int64_t B,
+                                                            double* __restrict__ chunk_sum_all, double* __restrict__ tail_all) {
     __shared__ double a[kSumChunk / 2];
     __shared__ double r[256];
     __shared__ double leaf[64];
-    const int64_t b0 = (int64_t)blockIdx.x * kSumChunk;
+    const int64_t q = blockIdx.x;
+    const int64_t* __restrict__ rowoff = rowoff_all + q * nc;
+    const double* __restrict__ w = w_all + q * nc;
+    double* __restrict__ chunk_sum = chunk_sum_all + q * (B / kSumChunk);
+    double* __restrict__ tail = tail_all + q * (B % kSumChunk);
+    const int64_t b0 = (int64_t)blockIdx.y * kSumChunk;
     const int n = (int)(B - b0 < (int64_t)kSumChunk ? B - b0 : (int64_t)kSumChunk);
     if (n < kSumChunk) {                              // the last, partial chunk: values out, the host sums them
         for (int i = threadIdx.x; i < n; i += kThreads) {
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(kThreads) void k_bb_chunk_sums(const double* __rest
         if (threadIdx.x < 64 && (threadIdx.x % (2 * stride)) == 0) leaf[threadIdx.x] = __dadd_rn(leaf[threadIdx.x], leaf[threadIdx.x + stride]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = leaf[0];
+    if (threadIdx.x == 0) chunk_sum[blockIdx.y] = leaf[0];
 }
 
 // full_output with Beeston-Barlow (likelihood.py:634-658) on already-morphed templates:

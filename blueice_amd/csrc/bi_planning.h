@@ -136,6 +136,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         hc[ci].perm.assign(n * G, -1);
         hc[ci].slot_lg.resize(n * G);
     }
+    std::vector<double*> aux_of(bb ? (size_t)P : 0, nullptr);      // Beeston-Barlow: where every point's {p_cal, N} went
     parallel_for((int64_t)items.size(), 512, [&](int64_t lo, int64_t hi) {
         for (int64_t it = lo; it < hi; ++it) {
             const PlanItem& I = items[(size_t)it];
@@ -185,6 +186,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
                     }
                     h.aux[((size_t)I.slot * G + g) * 2 + 0] = r[c->bb_source] / Ntot;  // p_calibration, likelihood.py:645
                     h.aux[((size_t)I.slot * G + g) * 2 + 1] = Ntot;
+                    aux_of[(size_t)p] = &h.aux[((size_t)I.slot * G + g) * 2];
                 }
                 double& lg = h.slot_lg[(size_t)I.slot * G + g];
                 if (c->unbinned) {   // ll = -sum_s mu_s + sum_e log(...)   (likelihood.py:690)
@@ -197,6 +199,31 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
             }
         }
     });
+
+    // Beeston-Barlow points at which some bin can have U_b == 0: N(z) in numpy's own summation order instead of the
+    // per-anchor totals, so that the root formula sees the reference's bits there (bb_exact_totals)
+    if (bb && c->bb_exact) {
+        std::vector<int64_t> who, anchors;
+        std::vector<double> ws;
+        for (const Pt& q : pts) {
+            const int64_t p = q.idx;
+            if (!aux_of[(size_t)p]) continue;
+            if (c->bb_exact == 1 || bb_zero_u_possible(c, cell[(size_t)p], &wts[(size_t)p * nc], &rates[(size_t)p * S])) {
+                who.push_back(p);
+                anchors.push_back(cell[(size_t)p]);
+                ws.insert(ws.end(), wts.begin() + (size_t)p * nc, wts.begin() + (size_t)(p + 1) * nc);
+            }
+        }
+        if (!who.empty()) {
+            std::vector<double> Nx(who.size());
+            if ((rc = bb_exact_totals(c, (int64_t)who.size(), anchors.data(), ws.data(), Nx.data()))) return rc;
+            for (size_t i = 0; i < who.size(); ++i) {
+                double* aux = aux_of[(size_t)who[i]];
+                aux[0] = rates[(size_t)who[i] * S + c->bb_source] / Nx[i];
+                aux[1] = Nx[i];
+            }
+        }
+    }
 
     // ---- upload; grid shape: enough blocks to fill the chip, few enough that partial buffers stay small ----
     bi_plan* plan = new bi_plan();

@@ -59,14 +59,14 @@ double pairwise_sum_host(const double* a, int64_t n) {
 
 // Can some bin have U_b == 0 (the other sources expecting exactly nothing) at this point?  Not if some other source has a
 // positive rate and strictly positive templates at every corner that carries weight.
-bool bb_zero_u_possible(const bi_ctx* c, const PointGeom& g, const double* rates) {
-    const int nc = (int)g.w.size();
+bool bb_zero_u_possible(const bi_ctx* c, int64_t cell_anchor, const double* w, const double* rates) {
+    const int nc = 1 << (int)c->eff_axes.size();
     for (int s = 0; s < c->S; ++s) {
         if (s == c->bb_source || !(rates[s] > 0.0)) continue;
         bool positive = true;
         for (int corner = 0; corner < nc && positive; ++corner) {
-            if (!(g.w[(size_t)corner] > 0.0)) continue;                       // a corner without weight adds exactly 0
-            const int64_t a = g.cell_anchor + corner_offset(c, corner);
+            if (!(w[corner] > 0.0)) continue;                                 // a corner without weight adds exactly 0
+            const int64_t a = cell_anchor + corner_offset(c, corner);
             positive = c->h_rowmin[(size_t)(a * c->S + s)] > 0.0;
         }
         if (positive) return false;
@@ -74,34 +74,63 @@ bool bb_zero_u_possible(const bi_ctx* c, const PointGeom& g, const double* rates
     return true;
 }
 
-// N(z) = sum_b a_b(z) exactly as the reference's `n_model_events[source_i].sum()` computes it (likelihood.py:645):
-// one extra pass over the 2^d corner rows of the Monte-Carlo counts (k_bb_chunk_sums), a few KB back, a short host loop.
-int bb_exact_total(bi_ctx* c, const PointGeom& g, double* N) {
-    const int nc = (int)g.w.size();
+bool bb_zero_u_possible(const bi_ctx* c, const PointGeom& g, const double* rates) {
+    return bb_zero_u_possible(c, g.cell_anchor, g.w.data(), rates);
+}
+
+// N(z) = sum_b a_b(z) exactly as the reference's `n_model_events[source_i].sum()` computes it (likelihood.py:645), for
+// n points at once: one extra pass over the 2^d corner rows of the Monte-Carlo counts per point (k_bb_chunk_sums; points of
+// one cell share them out of L2), a few KB per point back, a short host loop.  cell_anchor [n], w [n][nc] -> N [n].
+int bb_exact_totals(bi_ctx* c, int64_t n, const int64_t* cell_anchor, const double* w, double* N) {
+    if (n <= 0) return BI_OK;
+    const int nc = 1 << (int)c->eff_axes.size();
     const int64_t B = c->B, n_full = B / kSumChunk, tail_n = B % kSumChunk;
     const int64_t n_blocks = n_full + (tail_n ? 1 : 0);
-    if (n_blocks == 0) { *N = 0.0; return BI_OK; }
-    std::vector<int64_t> rowoff((size_t)nc);
-    for (int corner = 0; corner < nc; ++corner) rowoff[(size_t)corner] = (g.cell_anchor + corner_offset(c, corner)) * c->Bp;
-    PackedUpload pu;
-    const size_t out_doubles = (size_t)n_full + (size_t)tail_n;
+    if (n_blocks == 0) { std::fill(N, N + n, 0.0); return BI_OK; }
+    if (n_blocks > 65535) return fail(c, BI_ERR_INVALID, "Beeston-Barlow total: %lld bins are more than one launch covers", (long long)B);
+    std::vector<int64_t> rowoff((size_t)n * nc);
+    for (int64_t q = 0; q < n; ++q)
+        for (int corner = 0; corner < nc; ++corner) rowoff[(size_t)(q * nc + corner)] = (cell_anchor[q] + corner_offset(c, corner)) * c->Bp;
+    const size_t per_point = (size_t)(n_full + tail_n);
+    DevBuf d_in, d_out;
     int rc;
-    if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {g.w.data(), g.w.size() * sizeof(double)}},
-                            out_doubles * sizeof(double), pu)))
+    if ((rc = dev_alloc(c, d_in, (size_t)n * nc * 16)) || (rc = dev_alloc(c, d_out, (size_t)n * per_point * sizeof(double)))) {
+        dev_free(d_in); dev_free(d_out);
         return rc;
-    double* h_out = (double*)pu.host_out();           // pinned: the kernel writes chunk sums and tail values straight to the host
-    hipLaunchKernelGGL(k_bb_chunk_sums, dim3((unsigned)n_blocks), dim3(kThreads), 0, c->stream, (const double*)c->nm.p,
-                       pu.dev<int64_t>(0), pu.dev<double>(1), nc, B, h_out, h_out + n_full);
-    hipError_t e = hipGetLastError();
+    }
+    std::vector<double> h_out((size_t)n * per_point);
+    hipError_t e = hipMemcpyAsync(d_in.p, rowoff.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((char*)d_in.p + (size_t)n * nc * 8, w, (size_t)n * nc * 8, hipMemcpyHostToDevice, c->stream);
+    double* sums = (double*)d_out.p;
+    double* tails = sums + (size_t)n * n_full;
+    for (int64_t q0 = 0; e == hipSuccess && q0 < n; q0 += 1 << 20) {          // (gridDim.x is generous; keep launches finite)
+        const int64_t nq = std::min<int64_t>((int64_t)1 << 20, n - q0);
+        hipLaunchKernelGGL(k_bb_chunk_sums, dim3((unsigned)nq, (unsigned)n_blocks), dim3(kThreads), 0, c->stream, (const double*)c->nm.p,
+                           (const int64_t*)d_in.p + q0 * nc, (const double*)((char*)d_in.p + (size_t)n * nc * 8) + q0 * nc, nc, B,
+                           sums + q0 * n_full, tails + q0 * tail_n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_in); dev_free(d_out);
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "Beeston-Barlow total: %s", hipGetErrorString(e));
-    bool have = false;
-    double total = 0.0;
-    for (int64_t k = 0; k < n_full; ++k) { total = have ? total + h_out[k] : h_out[k]; have = true; }
-    if (tail_n) { const double t = pairwise_sum_host(h_out + n_full, tail_n); total = have ? total + t : t; }
-    *N = total;
-    ++c->n_bb_exact;
+    for (int64_t q = 0; q < n; ++q) {
+        const double* cs = h_out.data() + (size_t)q * n_full;
+        bool have = false;
+        double total = 0.0;
+        for (int64_t k = 0; k < n_full; ++k) { total = have ? total + cs[k] : cs[k]; have = true; }
+        if (tail_n) {
+            const double t = pairwise_sum_host(h_out.data() + (size_t)n * n_full + (size_t)q * tail_n, tail_n);
+            total = have ? total + t : t;
+        }
+        N[q] = total;
+    }
+    c->n_bb_exact += n;
     return BI_OK;
+}
+
+int bb_exact_total(bi_ctx* c, const PointGeom& g, double* N) {
+    return bb_exact_totals(c, 1, &g.cell_anchor, g.w.data(), N);
 }
 
 using bi_clock = std::chrono::steady_clock;

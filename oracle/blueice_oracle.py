@@ -146,10 +146,8 @@ def adjust_expectations_bb(mus, pmfs, n_model_events, counts, source_i, forgive_
     Raises AssertionError exactly where the reference asserts (likelihood.py:649,655).
     forgive_zero_u=True is NOT the reference: in bins where the other sources expect exactly nothing (U_b == 0) the
     first root is 0 analytically, and its floating-point value -- x - sqrt(x^2 (1 +- eps)) -- is negative, zero or
-    positive by the last bit of its inputs, so the reference's first assertion fires there on a coin flip.  The device
-    evaluates the same expression in the same order, but its inputs can differ from numpy's in the last bit (N from
-    per-anchor totals, FMA interpolation), so the coin can land differently; tests use this switch to tell that one
-    documented case from a real disagreement."""
+    positive by the last bit of its inputs, so the reference's first assertion fires there on a coin flip.  The switch
+    relaxes exactly that assertion (a diagnostic aid; since round 2 the device reproduces the coin and no test uses it)."""
     mus = np.array(mus, dtype=float, copy=True)
     pmfs = np.array(pmfs, dtype=float, copy=True)
     assert pmfs.shape == n_model_events.shape

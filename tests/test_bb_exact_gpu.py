@@ -41,9 +41,11 @@ def test_single_point_calls_assert_exactly_where_the_reference_does(S, n_anchor,
     ctx.upload_counts(counts)
     d = len(n_anchor)
     n_assert = n_fine = 0
+    zs, rs, sts = [], [], []
     for trial in range(60):
         z = np.array([rng.choice(g) if rng.random() < 0.3 else rng.uniform(g[0], g[-1]) for g in model['anchor_z']])
         r = rng.uniform(0.3, 2.0, S)
+        zs.append(z); rs.append(r)
         before = ctx.get_param('n_bb_exact')
         ll, st = ctx.eval(z if d else None, r)
         assert ctx.get_param('n_bb_exact') == before + 1          # U_b == 0 is possible here: the exact pass ran
@@ -53,11 +55,17 @@ def test_single_point_calls_assert_exactly_where_the_reference_does(S, n_anchor,
         except AssertionError:
             asserted = True
         assert bool(st[0] & 12) == asserted, (trial, z, r, int(st[0]), asserted)
+        sts.append(int(st[0]) & 12)
         if asserted:
             n_assert += 1
         else:
             n_fine += 1
             assert abs(ll[0] - want) <= RTOL * max(1.0, abs(want)), (trial, ll[0], want)
+    # the same 60 points as ONE batched call (several points per cell pass): the same assertion bits
+    for maxg in (16, 2):
+        ctx.set_param('max_group', maxg)
+        _, bst = ctx.eval(np.array(zs) if d else None, np.array(rs))
+        np.testing.assert_array_equal(bst & 12, np.array(sts))
     print('S=%d B=%d: reference asserted at %d of 60 points, fine at %d' % (S, B, n_assert, n_fine))
     _OUTCOMES[(S, B)] = (n_assert, n_fine)
     ctx.close()
