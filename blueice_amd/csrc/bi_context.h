@@ -34,6 +34,8 @@ struct bi_plan {
     std::vector<Class> classes;
     DevBuf bad_idx;            // points answered on the host side with -inf
     int64_t n_bad = 0;
+    DevBuf nan_idx;            // ... and with nan (infinite rates whose expectation is nan somewhere, or meets data)
+    int64_t n_nan = 0;
     DevBuf out, status;        // internal result buffers [P]
     std::vector<int32_t> h_status;
     int64_t epoch = 0;         // ctx->epoch at creation: a plan dies with the model / data it was made for
@@ -299,7 +301,7 @@ void free_plan_buffers(bi_plan* p) {
         dev_free(k.rowoff); dev_free(k.coef); dev_free(k.aux); dev_free(k.item_cnt); dev_free(k.item_tiles);
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags); dev_free(k.rowoff_full);
     }
-    dev_free(p->bad_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
+    dev_free(p->bad_idx); dev_free(p->nan_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
     dev_free(p->slab); dev_free(p->bad);
 }
 

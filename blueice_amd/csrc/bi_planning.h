@@ -58,7 +58,10 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
 
     // large plain batches are planned on the device (bi_planning_device.h) unless groups would be tiny
     // (every device-planned item has 16 slots): expected points per (cell, dataset) group >= 8
-    if (!bb && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
+    bool inf_scale = false;      // infinite rates are answered point by point on the host (inf_rate_value): host planner
+    if (any_neg && rate_scale)
+        for (int64_t i = 0; i < P * S && !inf_scale; ++i) inf_scale = std::isinf(rate_scale[i]);
+    if (!bb && !inf_scale && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
         int64_t cells = 1;
         for (int ax : c->eff_axes) cells *= c->n_anchor[(size_t)ax] - 1;
         const int64_t groups = cells * (dataset ? c->T : 1);
@@ -87,11 +90,20 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     // ---- phase 2: group by (cell, dataset) ----------------------------------------------------------
     struct Pt { int64_t key, idx; };
     std::vector<Pt> pts;
-    std::vector<int64_t> bad;
+    std::vector<int64_t> bad, nanv;      // points answered without a launch: -inf / nan
     pts.reserve((size_t)P);
+    const bool answer_inf = !bb && !c->unbinned && c->ps_finite && c->dense_counts;
     for (int64_t p = 0; p < P; ++p) {
-        if (st[(size_t)p]) bad.push_back(p);
-        else pts.push_back({cell[(size_t)p] * c->T + (dataset ? dataset[p] : 0), p});
+        if (st[(size_t)p]) { bad.push_back(p); continue; }
+        if (answer_inf && any_neg && has_infinite_rate(&rates[(size_t)p * S], S)) {
+            PointGeom g;
+            point_geometry(c, z ? z + p * d : nullptr, g);
+            double v = 0.0;
+            if ((rc = inf_rate_value(c, g, &rates[(size_t)p * S], dataset ? dataset[p] : 0, &v))) return rc;
+            (v != v ? nanv : bad).push_back(p);
+            continue;
+        }
+        pts.push_back({cell[(size_t)p] * c->T + (dataset ? dataset[p] : 0), p});
     }
     std::sort(pts.begin(), pts.end(), [](const Pt& a, const Pt& b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); });
 
@@ -236,7 +248,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     const int n_tiles = n_tiles_of(c);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
     const int64_t total_items = (int64_t)items.size();
-    size_t small_bytes = (size_t)P * 16 + bad.size() * 8;
+    size_t small_bytes = (size_t)P * 16 + bad.size() * 8 + nanv.size() * 8 + 64;
     for (int ci = 0; ci < 5; ++ci) {
         const HostClass& h = hc[ci];
         small_bytes += h.rowoff.size() * 8 + h.coef.size() * 8 + h.aux.size() * 8 + h.cnt_off.size() * 8 + h.tiles.size() * 4 +
@@ -279,10 +291,12 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         plan->launches += (k.n_items + 65534) / 65535;
     }
     plan->n_bad = (int64_t)bad.size();
+    plan->n_nan = (int64_t)nanv.size();
     if (packed) {
         // one copy for every descriptor array; out and status live in the pinned block behind them, where the finish
         // kernel writes them directly (the caller reads them there after its stream sync)
         parts.push_back({bad.data(), bad.size() * sizeof(int64_t)});
+        parts.push_back({nanv.data(), nanv.size() * sizeof(int64_t)});
         const size_t out_bytes = ((size_t)std::max<int64_t>(P, 1) * sizeof(double) + 63) / 64 * 64;
         PackedUpload pu;
         if ((rc = packed_upload(c, parts, out_bytes + (size_t)std::max<int64_t>(P, 1) * sizeof(int32_t), pu, &plan->slab)))
@@ -297,7 +311,8 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
             view(k.rowoff, part++); view(k.coef, part++); view(k.aux, part++); view(k.item_cnt, part++);
             view(k.item_tiles, part++); view(k.perm, part++); view(k.slot_lg, part++);
         }
-        view(plan->bad_idx, part);
+        view(plan->bad_idx, part++);
+        view(plan->nan_idx, part);
         plan->host_results = true;
         plan->out.p = pu.host_out();
         plan->out.bytes = out_bytes;
@@ -309,7 +324,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         *out = plan;
         return BI_OK;
     }
-    if ((rc = dev_upload(c, plan->bad_idx, bad)) || (rc = dev_alloc(c, plan->out, (size_t)std::max<int64_t>(P, 1) * sizeof(double))) ||
+    if ((rc = dev_upload(c, plan->bad_idx, bad)) || (rc = dev_upload(c, plan->nan_idx, nanv)) || (rc = dev_alloc(c, plan->out, (size_t)std::max<int64_t>(P, 1) * sizeof(double))) ||
         (rc = dev_upload(c, plan->status, plan->h_status)))
         return abort_plan(rc);
     hipError_t e = hipStreamSynchronize(c->stream);  // the host staging vectors die with this scope

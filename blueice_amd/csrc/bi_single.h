@@ -133,6 +133,60 @@ int bb_exact_total(bi_ctx* c, const PointGeom& g, double* N) {
     return bb_exact_totals(c, 1, &g.cell_anchor, g.w.data(), N);
 }
 
+// A point with an INFINITE rate (legal only beside a source that may go negative, likelihood.py:403-415).  The kernels fold
+// rates into corner coefficients, (w_c r_s) p_c,b, which turns exact zeros of single corner templates into nan; the
+// reference scales the INTERPOLATED template, r_s (sum_c w_c p_c,b).  So such points are answered here, the reference's
+// way: the rows of the infinite-rate sources are interpolated exactly as scipy does (k_morph_store), and since an
+// infinite expectation leaves only two possible results the rest is a classification per bin -- poisson.logpmf(n | mu):
+// nan where mu is nan or negative, -inf where n is not a count, and for mu = +inf: -inf at n = 0, nan (inf - inf) at n > 0.
+// -> *out = nan or -inf.  Plain binned likelihoods with finite templates only (the caller checks).
+int inf_rate_value(bi_ctx* c, const PointGeom& g, const double* rates, int64_t ds, double* out) {
+    const int nc = (int)g.w.size();
+    std::vector<int> srcs;
+    for (int s = 0; s < c->S; ++s)
+        if (std::isinf(rates[s])) srcs.push_back(s);
+    const int R = (int)srcs.size();
+    const int64_t B = c->B;
+    std::vector<int64_t> rowoff((size_t)R * nc);
+    for (int r = 0; r < R; ++r)
+        for (int corner = 0; corner < nc; ++corner)
+            rowoff[(size_t)r * nc + corner] = ((g.cell_anchor + corner_offset(c, corner)) * c->S + srcs[(size_t)r]) * c->Bp;
+    DevBuf d_row, d_w, d_out;
+    auto cleanup = [&]() { dev_free(d_row); dev_free(d_w); dev_free(d_out); };
+    int rc;
+    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_w, g.w)) ||
+        (rc = dev_alloc(c, d_out, (size_t)R * std::max<int64_t>(B, 1) * sizeof(double)))) { cleanup(); return rc; }
+    std::vector<double> rows((size_t)R * B), n((size_t)B);
+    hipError_t e = hipSuccess;
+    if (B > 0) {
+        hipLaunchKernelGGL(k_morph_store, dim3((unsigned)((B + kThreads - 1) / kThreads), (unsigned)R), dim3(kThreads), 0, c->stream,
+                           (const double*)c->ps.p, (const int64_t*)d_row.p, (const double*)d_w.p, nc, B, (double*)d_out.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(rows.data(), d_out.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(n.data(), (const double*)c->counts.p + ds * c->Bp, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "infinite-rate evaluation: %s", hipGetErrorString(e));
+    bool any_nan = false;
+    for (int64_t b = 0; b < B && !any_nan; ++b) {
+        double mu = 0.0;                                        // the finite sources add finite numbers: they cannot change the class
+        for (int r = 0; r < R; ++r) mu += rows[(size_t)r * B + b] * rates[srcs[(size_t)r]];
+        const double nb = n[(size_t)b];
+        if (!(mu >= 0.0) || nb != nb) any_nan = true;                     // scipy: mu invalid or n nan -> nan
+        else if (nb < 0.0 || nb != std::floor(nb)) continue;              // outside the support: -inf
+        else if (nb > 0.0) any_nan = true;                                // xlogy(n, inf) - inf
+    }
+    *out = any_nan ? std::numeric_limits<double>::quiet_NaN() : (B > 0 ? -std::numeric_limits<double>::infinity() : 0.0);
+    return BI_OK;
+}
+
+inline bool has_infinite_rate(const double* rates, int S) {
+    for (int s = 0; s < S; ++s)
+        if (std::isinf(rates[s])) return true;
+    return false;
+}
+
 using bi_clock = std::chrono::steady_clock;
 inline int64_t ns_between(bi_clock::time_point a, bi_clock::time_point b) {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
@@ -294,6 +348,8 @@ int eval_single(bi_ctx* c, const double* z, const double* rate_scale, int64_t ds
     interp_mus(c, g, rates);
     if (rate_scale) for (int s = 0; s < S; ++s) rates[s] *= rate_scale[s];
     if (!rates_physical(c, rates)) { *out = ninf; if (status) *status = BI_ST_UNPHYSICAL; return BI_OK; }
+    if (has_infinite_rate(rates, S) && c->bb_source < 0 && !c->unbinned && c->ps_finite && c->dense_counts)
+        return inf_rate_value(c, g, rates, ds, out);
 
     const bool bb = c->bb_source >= 0;
     const int nc = (int)g.w.size();

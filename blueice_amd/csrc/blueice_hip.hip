@@ -603,6 +603,9 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     else if (plan->n_bad > 0)
         hipLaunchKernelGGL(k_fill_const, dim3((unsigned)((plan->n_bad + 255) / 256)), dim3(256), 0, c->stream, out,
                            (const int64_t*)plan->bad_idx.p, plan->n_bad, -std::numeric_limits<double>::infinity());
+    if (plan->n_nan > 0)
+        hipLaunchKernelGGL(k_fill_const, dim3((unsigned)((plan->n_nan + 255) / 256)), dim3(256), 0, c->stream, out,
+                           (const int64_t*)plan->nan_idx.p, plan->n_nan, std::numeric_limits<double>::quiet_NaN());
     HIP_TRY(c, hipGetLastError());
     return BI_OK;
 }

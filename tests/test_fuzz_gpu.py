@@ -164,11 +164,8 @@ def test_large_batches_device_planner_and_scan_kernel(seed):
             for i in np.flatnonzero(~bad_ds):
                 w, g = want[i], got[i]
                 ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
-                # an infinite rate (legal only next to sources that may go negative, likelihood.py:403-415): the
-                # reference scales the interpolated templates, inf * p, the device folds the rate into the corner
-                # coefficients, (w inf) * p_corner, which is nan wherever a corner template is exactly 0 -- nan here
-                # against the reference's -inf (empty data) is the documented outcome, DESIGN.md section 2
-                ok = ok or (np.isinf(r[i]).any() and np.isnan(g) and w == -np.inf)
+                # (infinite rates -- legal only next to sources that may go negative, likelihood.py:403-415 -- are
+                # answered the reference's way on the host, inf_rate_value: no escape clause here any more)
                 assert ok, (seed, rep, d, S, B, T, sparse, used_scan, i, g, w, st[i])
         if allow_negative is not None:
             ctx.set_allow_negative(np.zeros(S, dtype=bool))

@@ -167,3 +167,46 @@ def test_device_log_accuracy(ctx):
     assert np.mean(ulp == 0) > 0.85
     assert out[-6] == -np.inf and np.isnan(out[-5]) and out[-4] == np.inf and np.isnan(out[-3])
     assert out[len(x) - 12] == 0.0            # log(1) exactly
+
+
+def test_infinite_rate_follows_the_reference():
+    """A rate of +inf is legal next to a source that may go negative (blueice/likelihood.py:403-415).  The reference
+    scales the INTERPOLATED template, inf * p(z)_b: +inf where p(z)_b > 0 (then -inf without data, nan with), nan where
+    p(z)_b == 0.  Corner templates with exact zeros in DIFFERENT bins must not change that: single calls and batches,
+    empty and non-empty data, on and off anchors."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    rng = np.random.default_rng(3)
+    anchor_z = [np.array([-1., 0., 2.]), np.array([0., 1.])]
+    S, B = 3, 40
+    ps = rng.random((3, 2, S, B)) + 0.01
+    ps[0, 0, 0, 3] = 0.0                        # a zero in one corner template only: the interpolated value stays > 0 off that anchor
+    ps[:, :, 0, 7] = 0.0                        # a zero at every anchor: p(z)_7 == 0 everywhere
+    ps /= ps.sum(axis=-1, keepdims=True)
+    mus = rng.uniform(5, 50, (3, 2, S))
+    model = dict(anchor_z=anchor_z, ps=ps, mus=mus, n_model=None)
+    allow = [False, True, False]
+    z = np.array([[-1., 0.], [-0.5, 0.3], [0., 1.], [1.1, 0.7], [2., 0.], [-1., 0.4]])
+    ctx = DeviceContext(0)
+    ctx.upload_model(anchor_z, ps, mus)
+    ctx.set_allow_negative([1 if a else 0 for a in allow])
+    for src_inf in (0, 2):                      # source 0 has the zeros, source 2 has none
+        r = np.ones((len(z), S))
+        r[:, src_inf] = np.inf
+        r[::2, 1] = -0.3
+        for counts in (np.zeros(B), rng.poisson(2.0, B).astype(float)):
+            want = np.array([orc.loglikelihood(model, counts, z[i], r[i], allow_negative=allow) for i in range(len(z))])
+            for sparse in (0, 1):
+                ctx.set_param('sparse', sparse)
+                ctx.upload_counts(counts)
+                batch, st = ctx.eval(z, r)
+                assert not st.any()
+                for i in range(len(z)):
+                    one, st1 = ctx.eval(z[i], r[i])
+                    for got in (one[0], batch[i]):
+                        assert (np.isnan(got) and np.isnan(want[i])) or got == want[i], (src_inf, counts.sum(), sparse, i, got, want[i])
+            if src_inf == 2 and counts.sum() == 0:
+                assert np.all(want == -np.inf)              # +inf expected everywhere, nothing seen
+            if src_inf == 0:
+                assert np.all(np.isnan(want))               # bin 7: inf * 0
+    ctx.close()
