@@ -86,6 +86,15 @@ int ensure_mail(bi_ctx* c) {
     return BI_OK;
 }
 
+// after a collector gave up (BI_ST_INTERNAL) the mailbox may hold values nobody took: empty it again
+void reset_mail(bi_ctx* c) {
+    if (!c->mail.p) return;
+    (void)hipStreamSynchronize(c->stream);
+    hipLaunchKernelGGL(k_mail_init, dim3((unsigned)((kMailSlots + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)c->mail.p, kMailSlots);
+    (void)hipMemsetAsync(c->mail_flags.p, 0, (size_t)kMailFlagWords * sizeof(unsigned), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+}
+
 int check_ready(bi_ctx* c, bool need_data) {
     if (!c) return BI_ERR_INVALID;
     if (c->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding on this context: call bi_eval_end first");

@@ -31,6 +31,7 @@ int single_wait(bi_ctx* c, unsigned long long seq, double* out, int32_t* status)
         return fail(c, BI_ERR_HIP, "single-point launch %llu finished without publishing its result", seq);
     *out = *(double*)res;
     if (status) *status = *(int32_t*)(res + 8);
+    if (*(int32_t*)(res + 8) & BI_ST_INTERNAL) reset_mail(c);
     return BI_OK;
 }
 

@@ -618,6 +618,9 @@ int bi_plan_read(bi_ctx* c, bi_plan* plan, double* out, int32_t* status) {
     if (status && plan->P)
         HIP_TRY(c, hipMemcpyAsync(status, plan->status.p, (size_t)plan->P * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (status)
+        for (int64_t p = 0; p < plan->P; ++p)
+            if (status[p] & BI_ST_INTERNAL) { reset_mail(c); break; }
     return BI_OK;
 }
 
