@@ -30,9 +30,13 @@ def main(argv=None):
     os.close(fd)
     os.unlink(rdzv)
     procs = []
+    # the ranks import what the launcher can import: its working directory (as `python -m` has it on the path) and the
+    # directory this package lives in come first on their PYTHONPATH
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.pathsep.join([p for p in (os.getcwd(), here, os.environ.get('PYTHONPATH', '')) if p])
     for r in range(a.nproc):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(devices[r]), WORLD_SIZE=str(a.nproc),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(a.port), BLUEICE_AMD_RDZV=rdzv)
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(a.port), BLUEICE_AMD_RDZV=rdzv, PYTHONPATH=path)
         procs.append(subprocess.Popen([sys.executable, a.script] + a.args, env=env))
     code = 0
     try:
