@@ -22,14 +22,17 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
 
 // Natural logarithm for the per-bin terms, table-driven (the scheme of Tang's table-driven log as used by modern
 // libms, laid out for this hardware): x = 2^k z with z in [0.6875, 1.375); the 7 leading mantissa bits pick a
-// subinterval with centre c from a 128-entry {1/c, log c} table held in LDS (bi_log_table.h); then
-//     log x = k ln2 + log c + log1p(r),   r = z / c - 1   (one fma, |r| <= 2^-7)
-// with log1p as its Taylor polynomial through r^8 and the leading terms summed as a hi/lo pair.  ~27 full-rate
-// instructions and one 16-byte LDS read per call, no division and no transcendental-rate instruction; worst
-// error measured 0.74 ulp (tools/micro/log_variants.hip), 1.55x the throughput of the fdlibm-style version with
-// its IEEE division.  The log is what bounds passes with several points per cell.
+// subinterval with centre c from a 128-entry {1/c, log c hi, log c lo} table held in LDS (bi_log_table.h); then
+//     log x = (k ln2_hi + log c_hi) + ( r + (r^2 P(r) + k ln2_lo + log c_lo) ),   r = z / c - 1   (one fma, |r| <= 2^-7)
+// where the first bracket is EXACT in one fma (ln2_hi on a 2^-37 grid, log c_hi on a 2^-43 grid), P is log1p's Taylor
+// polynomial through r^8, and the sum of the first bracket and r is carried with its rounding error.  16 fp64
+// instructions, one conversion and 6 integer ones per call (round 1: 19 + 1 + 6: it also had to recover the rounding of an
+// inexact k ln2 + log c), two LDS reads, no division and no transcendental-rate instruction; worst error 0.70 ulp, 98.6 %
+// of results correctly rounded
+// (tools/gen_log_table.py, tests/test_gpu_golden.py::test_device_log_accuracy).  On a chip where no vector instruction
+// executes beside an fp64 MFMA, the logarithm's instruction count is what bounds scans over dense data.
 // Every kernel that calls bin_log fills the LDS table first: log_table_load(), or the overlapped form in morph_tiles.
-__shared__ double2 s_log_table[128];
+__shared__ double4 s_log_table[128];
 
 __device__ __forceinline__ void log_table_load() {
     if (threadIdx.x < 128) s_log_table[threadIdx.x] = kLogTable[threadIdx.x];
@@ -46,21 +49,23 @@ __device__ __forceinline__ double log_core(double x, int k_adjust) {
     const int t = hi - 0x3FE60000;                  // bits(x) - bits(0.6875), high word
     const int k = (t >> 20) + k_adjust;
     const double z = __longlong_as_double(((unsigned long long)(unsigned)(hi - (t & 0xFFF00000)) << 32) | (ix & 0xFFFFFFFFull));
-    const double2 e = s_log_table[(t >> 13) & 127];
+    const double4 e = s_log_table[(t >> 13) & 127];
     const double kd = (double)k;
     const double r = fma(z, e.x, -1.0);
-    const double w = fma(kd, kLn2Hi, e.y);
-    const double h = w + r;
-    double lo = (w - h) + r;
-    lo += fma(kd, kLn2Hi, -w) + e.y;               // what rounding w lost
-    lo = fma(kd, kLn2Lo, lo);
+    const double w = fma(kd, kLn2Hi, e.y);         // exact
+    const double tail = fma(kd, kLn2Lo, e.z);
     double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
     p = fma(r, p, -1.0 / 6.0);
     p = fma(r, p, 1.0 / 5.0);
     p = fma(r, p, -1.0 / 4.0);
     p = fma(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
-    return fma(r * r, p, lo) + h;
+    const double q = fma(r * r, p, tail);
+    // w + r with its rounding error kept (|w| >= |r| wherever w != 0: k != 0, or a subinterval away from the two that touch
+    // 1): where log c and r nearly cancel -- arguments a little off 1 -- the plain r + q would cost up to an ulp
+    const double h = w + r;
+    const double err = (w - h) + r;
+    return h + (err + q);
 }
 
 // for arguments known to be positive normal numbers
@@ -291,7 +296,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                                             double (&sum)[G], unsigned (&flg)[G]) {
     // the log table travels global -> registers -> LDS; the request goes out first and lands under the first tile's
     // row loads, so a block that lives for only a few tiles does not wait for it separately
-    double2 tab = {0.0, 0.0};
+    double4 tab = {0.0, 0.0, 0.0, 0.0};
     if (threadIdx.x < 128) tab = kLogTable[threadIdx.x];
     bool tab_pending = true;
     // XCD-aware tile order: with 8 chunks block b -- dispatched to XCD b % 8 -- streams the b % 8-th contiguous region of

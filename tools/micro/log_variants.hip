@@ -43,7 +43,7 @@ __device__ __forceinline__ double log_b(double x) {   // rcp + Newton instead of
     const double dk = (double)k;
     return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
-__device__ __forceinline__ double log_c(double x, const double2* __restrict__ tab) {   // table-driven
+__device__ __forceinline__ double log_c(double x, const double4* __restrict__ tab) {   // table-driven (the library's log_core)
     if (!__builtin_amdgcn_class(x, 0x100)) return log(x);      // anything but a positive normal number
     const unsigned long long ix = __double_as_longlong(x);
     const int hi = (int)(ix >> 32);
@@ -51,27 +51,26 @@ __device__ __forceinline__ double log_c(double x, const double2* __restrict__ ta
     const int i = (t >> 13) & 127;
     const int k = t >> 20;
     const double z = __longlong_as_double(((unsigned long long)(unsigned)(hi - (t & 0xFFF00000)) << 32) | (ix & 0xFFFFFFFFull));
-    const double2 e = tab[i];
+    const double4 e = tab[i];
     const double kd = (double)k;
     const double r = fma(z, e.x, -1.0);
-    const double w = fma(kd, kLn2Hi, e.y);
-    const double h = w + r;
-    double lo = (w - h) + r;
-    lo += fma(kd, kLn2Hi, -w) + e.y;      // what rounding w lost
-    lo = fma(kd, kLn2Lo, lo);
-    const double r2 = r * r;
-    double p = fma(r, 1.0 / 8.0 * -1.0, 1.0 / 7.0);
+    const double w = fma(kd, kLn2Hi, e.y);         // exact: both on grids (bi_log_table.h)
+    const double tail = fma(kd, kLn2Lo, e.z);
+    double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
     p = fma(r, p, -1.0 / 6.0);
     p = fma(r, p, 1.0 / 5.0);
     p = fma(r, p, -1.0 / 4.0);
     p = fma(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
-    return fma(r2, p, lo) + h;
+    const double q = fma(r * r, p, tail);
+    const double h = w + r;
+    const double err = (w - h) + r;
+    return h + (err + q);
 }
 
 template <int V>
 __global__ __launch_bounds__(256) void k_speed(double* out, int iters, double x0, double step) {
-    __shared__ double2 tab[128];
+    __shared__ double4 tab[128];
     if (V == 2) { if (threadIdx.x < 128) tab[threadIdx.x] = kLogTable[threadIdx.x]; __syncthreads(); }
     double x = x0 + (blockIdx.x * 256 + threadIdx.x) * step, s = 0.0;
     for (int i = 0; i < iters; ++i) {
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256) void k_speed(double* out, int iters, double x0
 }
 template <int V>
 __global__ __launch_bounds__(256) void k_eval(const double* x, double* out, int n) {
-    __shared__ double2 tab[128];
+    __shared__ double4 tab[128];
     if (V == 2) { if (threadIdx.x < 128) tab[threadIdx.x] = kLogTable[threadIdx.x]; __syncthreads(); }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = V == 0 ? log_a(x[i]) : (V == 1 ? log_b(x[i]) : log_c(x[i], tab));
