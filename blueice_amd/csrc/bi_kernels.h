@@ -1395,13 +1395,14 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
         // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
         int kind[CB];
-        bool special[CB];
+        bool special[CB], alldata[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const double v = cnt[bin0 + cb * 16];
             n[cb] = v;
             kind[cb] = (v != v) ? 3 : ((v < 0.0 || v != floor(v)) ? 2 : (v > 0.0 ? 1 : 0));
             special[cb] = __ballot(kind[cb] != 0) != 0ull;      // wave-uniform: does any bin of this block need more
+            alldata[cb] = __ballot(kind[cb] == 1) == ~0ull;     // ... every bin holds a count > 0: the logarithm alone decides
         }
 
         // A operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
@@ -1429,12 +1430,21 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
         _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
             acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], b[kg][cb], acc[cb], 0, 0, 0);                   \
     } while (0)
+    /* (the linear part, -sum_b mu_b = -sum_k coef_k * rowsum_k, is in the per-point constant: k_plan_fill, linear_outside) */ \
 #define BI_EPILOGUE(cb)                                                                                            \
     do {                                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) { /* point (lane >> 4) + 4 r, bin cb * 16 + col */           \
-            s[r] -= acc[cb][r];                                                                                    \
-            mn[r] = fmin(mn[r], acc[cb][r]);                                                                       \
+        if (alldata[cb]) { /* dense data: n log mu in every bin; mu <= 0 / nan comes out of the checked logarithm */ \
+            bool checked = false;                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
+            if (__ballot(checked) == 0ull) {                                                                       \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb], bin_log_fast(acc[cb][r]), s[r]);   \
+            } else {                                                                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log(acc[cb][r]);                 \
+            }                                                                                                      \
+            break;                                                                                                 \
         }                                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) /* point (lane >> 4) + 4 r, bin cb * 16 + col */             \
+            mn[r] = fmin(mn[r], acc[cb][r]);                                                                       \
         if (special[cb]) {                                                                                         \
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \

@@ -29,6 +29,9 @@ struct PlanMeta {
     const int64_t* cnt_off;    // sparse: [T]
     const int64_t* c_np;       // sparse: [T] padded non-empty bins
     const double* Tz;          // sparse: [T][n_rows]
+    const double* rowsum;      // [n_rows] sum of every template row over all bins
+    int linear_outside;        // the batch goes to k_scan_mfma: sum_b mu_b = sum_k coef_k * rowsum_k joins the per-point constant,
+                               // and the kernel adds only the n log mu terms
 };
 
 constexpr uint64_t kBadKey = ~0ull;
@@ -150,9 +153,9 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
 #pragma unroll 4
         for (int s = 0; s < m.S; ++s) {                     // (unrolled: the Tz loads of a corner go out together)
             const double cf = wc * r[s];
-            const double tz = m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0;
+            const double tz = m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0);
             coef[(item * NS + k + s) * kDevG + g] = cf;
-            if (m.sparse) zsum += cf * tz;
+            if (m.sparse || m.linear_outside) zsum += cf * tz;
             if (g == 0) {
                 rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
                 if (rowoff_full) rowoff_full[item * NS + k + s] = (a * m.S + s) * m.Bp;
@@ -204,7 +207,8 @@ int ensure_plan_tables(bi_ctx* c) {
     std::vector<int64_t> coff((size_t)nc);
     for (int k = 0; k < nc; ++k) coff[(size_t)k] = corner_offset(c, k);
     if ((rc = dev_upload(c, c->pt_grid, grid)) || (rc = dev_upload(c, c->pt_mus, c->h_mus)) ||
-        (rc = dev_upload(c, c->pt_coff, coff)) || (rc = dev_upload(c, c->pt_allow, c->allow_neg)))
+        (rc = dev_upload(c, c->pt_coff, coff)) || (rc = dev_upload(c, c->pt_allow, c->allow_neg)) ||
+        (rc = dev_upload(c, c->pt_rowsum, c->h_rowsum)))
         return rc;
     if (c->compact_ready && ((rc = dev_upload(c, c->pt_c_off, c->h_c_off)) || (rc = dev_upload(c, c->pt_cnt_off, c->h_cnt_off)) ||
                              (rc = dev_upload(c, c->pt_c_np, c->h_c_np)) || (rc = dev_upload(c, c->pt_Tz, c->h_Tz))))
@@ -230,6 +234,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     m.allow_neg = (const int32_t*)c->pt_allow.p; m.lgsum = (const double*)c->lgsum.p;
     m.c_off = (const int64_t*)c->pt_c_off.p; m.cnt_off = (const int64_t*)c->pt_cnt_off.p; m.c_np = (const int64_t*)c->pt_c_np.p;
     m.Tz = (const double*)c->pt_Tz.p;
+    m.rowsum = (const double*)c->pt_rowsum.p;
 
     bi_plan* plan = new bi_plan();
     plan->P = P; plan->sparse = sparse; plan->epoch = c->epoch; plan->device_planned = true; plan->no_reuse = false;
@@ -309,7 +314,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         const bool split = !sparse && c->scan_split && scan_shape && c->compact_ready && c->dense_counts &&
                            n_items >= c->scan_min_items * n_groups;
         const bool compacted = sparse || split;
+        // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
+        // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
+        // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
+        // larger part of the work)
+        const bool scan_ok = !split && scan_shape &&
+                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
+                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
         m.sparse = compacted ? 1 : 0;
+        m.linear_outside = scan_ok ? 1 : 0;
         plan->sparse = compacted;
         plan->classes.emplace_back();
         bi_plan::Class& k = plan->classes.back();
@@ -358,8 +371,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         };
         // scan_waves_per_cu waves per CU over all groups, evened out so that every wave gets the same number of
         // strips (a block lasts as long as its busiest wave)
-        auto waves_per_group = [&](int64_t strips) -> int64_t {
-            int64_t blocks = std::max<int64_t>(1, (c->scan_waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
+        auto waves_per_group = [&](int64_t strips, int64_t waves_per_cu) -> int64_t {
+            int64_t blocks = std::max<int64_t>(1, (waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, strips / 4));
             const int64_t per_wave = (strips + 4 * blocks - 1) / (4 * blocks);
             blocks = (strips + 4 * per_wave - 1) / (4 * per_wave);
@@ -370,26 +383,20 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->valid = true;
             plan->n_groups = n_groups;
             plan->scan_cb = 4;
-            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64));
+            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), c->scan_waves_per_cu);
             plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
             plan->launches += 1;
             e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
         }
-        // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
-        // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
-        // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
-        // larger part of the work)
-        const bool scan_ok = !split && scan_shape &&
-                             n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
-                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
         if (scan_ok) {
             if ((rc = group_tables())) return abort_plan(rc);
             const int cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
             plan->use_scan = true;
             plan->scan_cb = cb;
             plan->n_groups = n_groups;
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)));       // every wave owns one partial slot per item
+            // (dense data: a third more waves -- 505 k instead of 476 k evaluations/s at C2, tools/tune_scan_dense.py)
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), mostly_empty ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4 / 3);       // every wave owns one partial slot per item
             dev_free(k.partial);
             dev_free(k.pflags);
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||

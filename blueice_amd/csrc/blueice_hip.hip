@@ -119,7 +119,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->pack_dev);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
-    dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz);
+    dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum);
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
     c->cache.clear();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
