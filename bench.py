@@ -74,7 +74,7 @@ def cpu_baseline_all_cores(config, n_procs, budget_s=10.0):
                 sample='%d processes x %.0f s of single-thread oracle evaluations, one point each' % (done, budget_s))
 
 
-def cpu_baseline(model, counts, points, budget_s=20.0):
+def cpu_baseline(model, counts, points, budget_s=15.0):
     """Time the oracle (numpy/scipy restatement of the reference path) on this host, one thread."""
     from oracle import blueice_oracle as orc
     z, r = points
@@ -85,7 +85,7 @@ def cpu_baseline(model, counts, points, budget_s=20.0):
         orc.loglikelihood(cm, counts, z[0], r[0])
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 200:
+        if dt > budget_s or n >= 2000:
             break
     return dict(value=n / dt, unit='evals/s', cores=1, kind='port',
                 sample='%d single-thread evaluations of the C2 model at one off-grid point (%.1f s); '
