@@ -136,6 +136,8 @@ struct bi_ctx {
     int64_t scan_cb = 0;                         // scan kernel strip width in 16-bin blocks: 2, 4, or 0 = by the data
     int64_t bb_exact = 2;                        // single-point Beeston-Barlow calls: N(z) in numpy's summation order: 0 never, 1 always, 2 when some bin can have U_b == 0
     int64_t n_bb_exact = 0;                      // how often that pass ran
+    int64_t scan_sparse_max_items = (int64_t)1 << 40;   // compacted rows: items per cell up to which the matrix-core scan kernel is used (round 1: 384;
+                                                 // since the kernel leaves the linear term to the host it wins at every size: 46 vs 40 M evaluations/s at 10^6 points)
     int64_t scan_split = 1;                      // dense scans over mostly empty data: non-empty-bin pass + matrix-core validity pass
     int64_t sparse_at_upload = 1;                // value of `sparse` when the resident data were uploaded
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell

@@ -320,7 +320,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // larger part of the work)
         const bool scan_ok = !split && scan_shape &&
                              n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
-                             !(sparse && n_items > 384 * n_groups);   // compacted rows, very long item lists: k_morph_reduce is 10 % ahead
+                             !(sparse && n_items > c->scan_sparse_max_items * n_groups);   // compacted rows, very long item lists: see scan_sparse_max_items
         m.sparse = compacted ? 1 : 0;
         m.linear_outside = scan_ok ? 1 : 0;
         plan->sparse = compacted;
@@ -391,12 +391,14 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         }
         if (scan_ok) {
             if ((rc = group_tables())) return abort_plan(rc);
-            const int cb = c->scan_cb ? (int)c->scan_cb : (mostly_empty ? 4 : 2);   // dense data: narrower strips, more waves
+            // strips of 32 bins where (nearly) every bin needs its logarithm -- dense data, or the compacted rows of the
+            // non-empty-bin form --, 64 where most blocks of 16 bins hold no data at all
+            const int cb = c->scan_cb ? (int)c->scan_cb : ((mostly_empty && !sparse) ? 4 : 2);
             plan->use_scan = true;
             plan->scan_cb = cb;
             plan->n_groups = n_groups;
             // (dense data: a third more waves -- 505 k instead of 476 k evaluations/s at C2, tools/tune_scan_dense.py)
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), mostly_empty ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4 / 3);       // every wave owns one partial slot per item
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), (mostly_empty || sparse) ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4 / 3);       // every wave owns one partial slot per item
             dev_free(k.partial);
             dev_free(k.pflags);
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||

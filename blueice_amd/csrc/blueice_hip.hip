@@ -167,6 +167,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
     if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
+    if (!strcmp(name, "scan_sparse_max_items")) { c->scan_sparse_max_items = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
@@ -210,6 +211,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "compact_ready")) return (c->compact_ready && c->ps_nonneg && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
     if (!strcmp(name, "split_ready")) return (c->compact_ready && c->dense_counts) ? 1 : 0;
     if (!strcmp(name, "scan_split")) return c->scan_split;
+    if (!strcmp(name, "scan_sparse_max_items")) return c->scan_sparse_max_items;
     if (!strcmp(name, "bb_exact")) return c->bb_exact;
     if (!strcmp(name, "n_bb_exact")) return c->n_bb_exact;
     if (!strcmp(name, "n_valid_launches")) return c->n_valid_launches;
