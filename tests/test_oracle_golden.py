@@ -134,3 +134,49 @@ def test_unbinned_oracle_matches_reference_goldens(name):
     if name == 'unb_ref_value':            # the reference's own closed forms (test_likelihood_value)
         assert c['call_ll'][0] == -1 + stats.norm.logpdf(0)
         assert c['call_ll'][1] == -2 + np.log(2 * stats.norm.pdf(0))
+
+
+def _pairwise(a, lo, n):
+    """numpy's pairwise_sum (loops_utils.h.src) restated: what k_bb_chunk_sums / pairwise_sum_host reproduce."""
+    if n < 8:
+        res = 0.0
+        for i in range(n):
+            res += a[lo + i]
+        return res
+    if n <= 128:
+        r = a[lo:lo + 8].copy()
+        m = n - (n % 8)
+        for row in a[lo + 8:lo + m].reshape(-1, 8):
+            r = r + row
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(m, n):
+            res += a[lo + i]
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return _pairwise(a, lo, n2) + _pairwise(a, lo + n2, n - n2)
+
+
+def test_numpy_sum_order_the_device_reproduces():
+    """The Beeston-Barlow normalisation N = n_model_events[i].sum() (blueice/likelihood.py:645) decides assertion
+    outcomes by its last bit, so the device sums in NUMPY'S order: sequentially over chunks of 8192 elements, each chunk
+    by pairwise_sum.  This pins that order for the numpy in use (if a numpy release changes it, this test says so before
+    tests/test_bb_exact_gpu.py does)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 9, 100, 128, 129, 1000, 8191, 8192, 8193, 20000, 65536, 250000):
+        for shape in ((n,), (2, n)):
+            a = rng.random(shape) * 50 + 1
+            row = a if a.ndim == 1 else a[1]
+            total = None
+            for s in range(0, n, 8192):
+                v = _pairwise(row, s, min(8192, n - s))
+                total = v if total is None else total + v
+            assert np.float64(total) == row.sum(), (n, shape)
+    for shape in ((3, 7, 11, 13), (2, 37, 41, 29)):    # N-d rows, as n_model_events[i] is: summed as one contiguous run
+        x = rng.random(shape) * 30 + 1
+        flat = x[-1].ravel()
+        total = None
+        for s in range(0, flat.size, 8192):
+            v = _pairwise(flat, s, min(8192, flat.size - s))
+            total = v if total is None else total + v
+        assert np.float64(total) == x[-1].sum(), shape
