@@ -1322,12 +1322,12 @@ namespace {
 // ---- the scan kernel: many points per grid cell, fp64 matrix cores ---------------------------------------
 // For a batch whose points pile up in few grid cells (likelihood scans), mu[point][bin] = sum_k coef[point][k] *
 // row[k][bin] is a [points x streams] x [streams x bins] product.  One wave owns a strip of 16 CB bins of the cell's
-// 2^d*S template rows, holds it in registers in v_mfma_f64_16x16x4 B-operand layout (k = lane >> 4,
+// 2^d*S template rows, holds it in registers in v_mfma_f64_16x16x4 operand layout (k = lane >> 4,
 // bin = lane & 15; loaded once, every 128-byte cache line fully used) and loops over ALL 16-point work items of
-// the cell: per item KG coalesced A-operand loads (coef[k][point], point = lane & 15) and, for the CB column blocks
-// of the strip, KG MFMAs each; the Poisson epilogue of a block is issued behind the next block's MFMA chain.  A 16-lane
-// row reduction leaves the 16 per-point sums in 4 lanes, which add them (no-return fp64 atomics) into a partial slot
-// that only this wave ever touches, so the result is deterministic.
+// the cell: per item KG coalesced coefficient loads (coef[k][point], point = lane & 15) and, for the CB 16-bin blocks
+// of the strip, KG MFMAs each, then the Poisson epilogue of the block.  Two cross-row exchanges leave the 16
+// per-point sums in the first 16 lanes, which add them (no-return fp64 atomics) into a partial slot that only this
+// wave ever touches, so the result is deterministic.
 // Bound: 78.6 TFLOP/s fp64 matrix peak / (2 * 2^d*S * B flop per evaluation) = 1.2 M evaluations/s at C2 for the
 // FMA work alone; fp64 MFMA and fp64 VALU share the same units on this chip (measured: tools/micro/
 // mfma_valu_overlap.hip), so the epilogue's logarithms add to that rather than hide under it.
@@ -1348,28 +1348,33 @@ struct ScanArgs {
     int nslots;                 // waves per group = gridDim.x * 4
 };
 
-// sum of a double over the 16 lanes of a DPP row (lanes 16r .. 16r+15): four rotate-and-add steps on the
-// cross-lane data path, no LDS round trip; every lane of the row ends up with the total
-__device__ __forceinline__ double row16_sum(double v) {
-#define BI_ROR_ADD(N)                                                                                              \
+// sum of a double over the 4 DPP rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): one half-row exchange and one half-wave
+// exchange (v_permlane16_swap / v_permlane32_swap, gfx950), every lane ends up with the total
+__device__ __forceinline__ double rows4_sum(double v) {
+#define BI_SWAP_ADD(SWAP)                                                                                          \
     do {                                                                                                           \
         const unsigned long long u = __double_as_longlong(v);                                                      \
-        const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x120 + N, 0xF, 0xF, true);           \
-        const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x120 + N, 0xF, 0xF, true);   \
-        v += __longlong_as_double(((unsigned long long)hi << 32) | lo);                                            \
+        const auto lo = SWAP((unsigned)u, (unsigned)u, false, false);                                              \
+        const auto hi = SWAP((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);                              \
+        v = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) +                                      \
+            __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);                                       \
     } while (0)
-    BI_ROR_ADD(8);
-    BI_ROR_ADD(4);
-    BI_ROR_ADD(2);
-    BI_ROR_ADD(1);
-#undef BI_ROR_ADD
+    BI_SWAP_ADD(__builtin_amdgcn_permlane16_swap);
+    BI_SWAP_ADD(__builtin_amdgcn_permlane32_swap);
+#undef BI_SWAP_ADD
     return v;
 }
 
-// CB: 16-bin column blocks per strip (strip = CB * 16 bins).  KG: groups of 4 streams (4 KG >= NS).  MASK: NS < 4 KG,
-// the A operands of the padding streams must be zeroed.
+// CB: 16-bin blocks per strip (strip = CB * 16 bins).  KG: groups of 4 streams (4 KG >= NS).  MASK: NS < 4 KG,
+// the coefficient operands of the padding streams must be zeroed.
+// Operand roles: the template strip is the MFMA's A operand (row i = bin = lane & 15, k = lane >> 4), the coefficients
+// its B operand (k = lane >> 4, column j = point = lane & 15), so lane (kq, col) receives mu[bin = 4 r + kq][point = col]
+// in accumulator element r: ALL FOUR elements of a lane belong to ONE point.  The per-point sum therefore needs three
+// in-lane additions and two cross-row exchanges per item (rows4_sum: ~10 vector instructions) -- with the operands the
+// other way round (bins along the lanes of a row) it took four 16-lane rotations per accumulator element, ~60
+// instructions per item, a fifth of the kernel's vector work when every bin has data.
 template <int CB, int KG, bool MASK>
-__global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
     constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1381,31 +1386,37 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
     const int n_strips = a.item_tiles[item0] * (kTile / STRIP);
     log_table_load();
     const int kq = lane >> 4, col = lane & 15;
-    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // A operand of K group kg sits at aoff0 + kg * 64 (clamped)
+    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // coefficient of K group kg sits at aoff0 + kg * 64 (clamped)
 
     for (int strip = slot; strip < n_strips; strip += a.nslots) {
-        const int64_t bin0 = (int64_t)strip * STRIP + col;
-        double b[KG][CB], n[CB];
+        const int64_t bin0 = (int64_t)strip * STRIP;
+        double b[KG][CB], n[CB][4];
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int64_t row = rowoff[min(kg * 4 + kq, a.NS - 1)];   // streams beyond NS: a valid row times a zero coefficient
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16];
+            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16 + col];
         }
         // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
-        int kind[CB];
+        // (the four kinds of a lane's bins packed into one register, 2 bits each: registers decide the occupancy here)
+        int kinds[CB];
         bool special[CB], alldata[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const double v = cnt[bin0 + cb * 16];
-            n[cb] = v;
-            kind[cb] = (v != v) ? 3 : ((v < 0.0 || v != floor(v)) ? 2 : (v > 0.0 ? 1 : 0));
-            special[cb] = __ballot(kind[cb] != 0) != 0ull;      // wave-uniform: does any bin of this block need more
-            alldata[cb] = __ballot(kind[cb] == 1) == ~0ull;     // ... every bin holds a count > 0: the logarithm alone decides
+            kinds[cb] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = cnt[bin0 + cb * 16 + 4 * r + kq];
+                n[cb][r] = v;
+                kinds[cb] |= ((v != v) ? 3 : ((v < 0.0 || v != floor(v)) ? 2 : (v > 0.0 ? 1 : 0))) << (2 * r);
+            }
+            special[cb] = __ballot(kinds[cb] != 0) != 0ull;       // wave-uniform: does any bin of this block need more
+            alldata[cb] = __ballot(kinds[cb] == 0x55) == ~0ull;   // ... every bin holds a count > 0: the logarithm alone decides
         }
+#define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
 
-        // A operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
+        // coefficient operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
         double av[KG];
         {
             const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
@@ -1418,17 +1429,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
         }
         for (int it = 0; it < n_items; ++it) {
             const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
-            double an[KG];
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-            double mn[4] = {0.0, 0.0, 0.0, 0.0};     // running minimum of mu: a negative expectation makes the result nan
+            double s[4] = {0.0, 0.0, 0.0, 0.0};      // four chains, one point
+            double mn = 0.0;                          // running minimum of mu: a negative expectation makes the result nan
             bi_double4 acc[CB];
-            // software pipeline: the matrix pipe gets block cb + 1 before the VALU looks at block cb, and the next
-            // item's A operands are requested right behind the first chain, so they arrive under the others
+            // all chains first (no vector instruction executes beside an fp64 MFMA anyway), then the next item's
+            // coefficients are requested straight into the registers the chains have just read -- they arrive under the
+            // epilogues, and there is neither a second register set nor a rotation
 #define BI_CHAIN(cb)                                                                                               \
     do {                                                                                                           \
         acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
         _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
-            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], b[kg][cb], acc[cb], 0, 0, 0);                   \
+            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[kg][cb], av[kg], acc[cb], 0, 0, 0);                   \
     } while (0)
     /* (the linear part, -sum_b mu_b = -sum_k coef_k * rowsum_k, is in the per-point constant: k_plan_fill, linear_outside) */ \
 #define BI_EPILOGUE(cb)                                                                                            \
@@ -1437,58 +1448,46 @@ __global__ __launch_bounds__(kThreads) void k_scan_mfma(ScanArgs a) {
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
             if (__ballot(checked) == 0ull) {                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb], bin_log_fast(acc[cb][r]), s[r]);   \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb][r], bin_log_fast(acc[cb][r]), s[r]); \
             } else {                                                                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log(acc[cb][r]);                 \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb][r] * bin_log(acc[cb][r]);              \
             }                                                                                                      \
             break;                                                                                                 \
         }                                                                                                          \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) /* point (lane >> 4) + 4 r, bin cb * 16 + col */             \
-            mn[r] = fmin(mn[r], acc[cb][r]);                                                                       \
+        mn = fmin(mn, fmin(fmin(acc[cb][0], acc[cb][1]), fmin(acc[cb][2], acc[cb][3])));                           \
         if (special[cb]) {                                                                                         \
             bool checked = false;                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
-            if (__ballot(checked && kind[cb] == 1) == 0ull) {                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= BI_KIND(cb, r) == 1 && !pos_normal(acc[cb][r]);  \
+            if (__ballot(checked) == 0ull) {                                                                       \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                    \
                     const double lg = bin_log_fast(acc[cb][r]);                                                    \
-                    if (kind[cb] == 1) s[r] += n[cb] * lg;                                                         \
+                    if (BI_KIND(cb, r) == 1) s[r] += n[cb][r] * lg;                                                   \
                 }                                                                                                  \
-            } else if (kind[cb] == 1) {                                                                            \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb] * bin_log(acc[cb][r]);            \
+            } else {                                                                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+                    if (BI_KIND(cb, r) == 1) s[r] += n[cb][r] * bin_log(acc[cb][r]);                                  \
             }                                                                                                      \
-            if (kind[cb] > 1) {                                                                            \
-                const double v = kind[cb] == 2 ? -__builtin_inf() : __builtin_nan("");                             \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += v;                                           \
-            }                                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
+                if (BI_KIND(cb, r) > 1) s[r] += BI_KIND(cb, r) == 2 ? -__builtin_inf() : __builtin_nan("");              \
         }                                                                                                          \
     } while (0)
-            BI_CHAIN(0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) BI_CHAIN(cb);
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 const int k = kg * 4 + kq;
-                an[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) an[kg] = 0.0;
+                av[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) av[kg] = 0.0;
             }
 #pragma unroll
-            for (int cb = 1; cb < CB; ++cb) {
-                BI_CHAIN(cb);
-                BI_EPILOGUE(cb - 1);
-            }
-            BI_EPILOGUE(CB - 1);
+            for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
 #undef BI_CHAIN
 #undef BI_EPILOGUE
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (mn[r] < 0.0) s[r] = __builtin_nan("");
-                s[r] = row16_sum(s[r]);              // over the 16 bins held by the 16 lanes of a row
-            }
-            if (col == 0) {
-                double* __restrict__ dst = a.partial + ((item0 + it) * a.nslots + slot) * 16 + kq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + 4 * r, s[r]);
-            }
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg];
+#undef BI_KIND
+            double tot = (s[0] + s[1]) + (s[2] + s[3]);
+            if (mn < 0.0) tot = __builtin_nan("");
+            tot = rows4_sum(tot);                     // over the four DPP rows: the 16 bins of the block are spread 4 r + kq
+            if (kq == 0) unsafeAtomicAdd(a.partial + ((item0 + it) * a.nslots + slot) * 16 + col, tot);
         }
     }
 }

@@ -155,6 +155,7 @@ def summarize_scan(tag, dst):
                     'GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md)',
            'plain_runs': open(os.path.join(src, 'plain.txt')).read().strip().splitlines(),
            'this_round': _scan_block(src, 'k_scan_valid<4, 8, false>')}
+    summarize_scan_dense_data(tag, dst, src)
     prev = os.path.join(ROOT, 'gpurun_out', 'prof_scan_r1kernel')
     if os.path.exists(os.path.join(prev, 'pmc1')):
         out['previous_kernel'] = _scan_block(prev, 'k_scan_mfma<4, 8, false>')
@@ -168,6 +169,42 @@ def summarize_scan(tag, dst):
             print('%s %s: %.1f ms, %.0f evals/s, MFMA busy %.3f, %.1f other VALU instr per MFMA, clock %.2f GHz' % (
                 key, b['kernel'], b['kernel_trace']['average_us'] / 1e3, d['evaluations_per_s'], d['mfma_busy_fraction_of_SIMD_cycles'],
                 d['valu_instructions_per_mfma'], d['effective_clock_GHz']))
+
+
+def summarize_scan_dense_data(tag, dst, src):
+    """The same scan over data with events in every bin (k_scan_mfma computes every logarithm) -> rNN_scan_dense_data_pmc.json."""
+    path = os.path.join(src, 'pmcd', 'pmc_counter_collection.csv')
+    ktd = os.path.join(src, 'ktd', 'kt_kernel_stats.csv')
+    if not (os.path.exists(path) and os.path.exists(ktd)):
+        return
+    needle = 'k_scan_mfma<2, 8, false>'
+    c, _ = _kernel_counters(path, needle)
+    st = _kernel_stats(ktd, needle)
+    if not c or not st:
+        return
+    simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8
+    n_mfma = c['SQ_INSTS_MFMA']
+    plain = [l for l in open(os.path.join(src, 'plain.txt')).read().splitlines() if 'dense data' in l]
+    out = {'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT '
+                      'SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE / --kernel-trace --stats (own run) -- python3 tools/profile/scan_only.py 2 dense',
+           'workload': '131 072-point scan of C2, sparse = 0, ~10 events in EVERY bin (the split into a non-empty-bin pass and a '
+                       'validity pass does not apply: every bin needs its logarithm)',
+           'kernel': needle.replace(', ', ','), 'kernel_trace': st, 'counters_per_launch': c,
+           'derived': {'evaluations_per_s': 131072 / (st['average_us'] * 1e-6),
+                       'mfma_busy_fraction_of_SIMD_cycles': c['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles,
+                       'other_vector_instructions_per_mfma': (c['SQ_INSTS_VALU'] - n_mfma) / n_mfma,
+                       'other_vector_instructions_per_matrix_element': (c['SQ_INSTS_VALU'] - n_mfma) / n_mfma * 8 / 4,
+                       'lds_instructions_per_mfma': c['SQ_INSTS_LDS'] / n_mfma,
+                       'lds_bank_conflict_cycles_per_lds_instruction': c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_INSTS_LDS'], 1),
+                       'sum_of_parts_bound_evals_per_s': 1024 * (c['GRBM_GUI_ACTIVE'] / 8 / (st['average_us'] * 1e-6)) /
+                                                         ((c['SQ_VALU_MFMA_BUSY_CYCLES'] + 4.0 * (c['SQ_INSTS_VALU'] - n_mfma)) / 131072),
+                       'plain_run': plain}}
+    with open(os.path.join(dst, tag + '_scan_dense_data_pmc.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    d = out['derived']
+    print('dense-data scan %s: %.1f ms, %.0f evals/s, MFMA busy %.3f, %.1f other VALU per MFMA, bound if MFMA and VALU cycles simply add: %.0f evals/s' % (
+        needle, st['average_us'] / 1e3, d['evaluations_per_s'], d['mfma_busy_fraction_of_SIMD_cycles'],
+        d['other_vector_instructions_per_mfma'], d['sum_of_parts_bound_evals_per_s']))
 
 
 if __name__ == '__main__':
