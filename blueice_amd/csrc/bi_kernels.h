@@ -47,8 +47,13 @@ __device__ __forceinline__ double log_core(double x, int k_adjust) {
     const unsigned long long ix = __double_as_longlong(x);
     const int hi = (int)(ix >> 32);
     const int t = hi - 0x3FE60000;                  // bits(x) - bits(0.6875), high word
-    const int k = (t >> 20) + k_adjust;
-    const double z = __longlong_as_double(((unsigned long long)(unsigned)(hi - (t & 0xFFF00000)) << 32) | (ix & 0xFFFFFFFFull));
+    const int k0 = t >> 20;
+    const int k = k0 + k_adjust;
+    // high word of z = hi - (k0 << 20), as ONE 24-bit multiply-add (|k0| <= 2^10, 2^20 < 2^23; written as an instruction
+    // because the compiler turns the product back into a mask and a subtraction)
+    int zhi;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(zhi) : "v"(k0), "s"(-(1 << 20)), "v"(hi));
+    const double z = __longlong_as_double(((unsigned long long)(unsigned)zhi << 32) | (ix & 0xFFFFFFFFull));
     const double4 e = s_log_table[(t >> 13) & 127];
     const double kd = (double)k;
     const double r = fma(z, e.x, -1.0);
