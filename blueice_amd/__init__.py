@@ -6,6 +6,6 @@ from .exceptions import *  # noqa: F401,F403
 from .model import Model  # noqa: F401
 from .source import Source, HistogramPdfSource, DensityEstimatingSource, MonteCarloSource  # noqa: F401
 from .likelihood import (LogLikelihoodBase, BinnedLogLikelihood, UnbinnedLogLikelihood,  # noqa: F401
-                         LogLikelihoodSum)
+                         LogLikelihoodSum, LogLikelihoodReParam, LogAncillaryLikelihood)
 
 __version__ = '0.1.0'

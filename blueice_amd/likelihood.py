@@ -29,7 +29,8 @@ from .model import Model
 from .pdf_morphers import MORPHERS
 from .utils import combine_dicts, is_numeric
 
-__all__ = ['LogLikelihoodBase', 'BinnedLogLikelihood', 'UnbinnedLogLikelihood', 'LogLikelihoodSum']
+__all__ = ['LogLikelihoodBase', 'BinnedLogLikelihood', 'UnbinnedLogLikelihood', 'LogLikelihoodSum',
+           'LogLikelihoodReParam', 'LogAncillaryLikelihood']
 
 _BB_FLAGS = _capi.ST_BB_ROOT1 | _capi.ST_BB_NEG
 
@@ -62,8 +63,8 @@ class LogLikelihoodBase:
         self.pdf_base_config = combine_dicts(pdf_base_config, kwargs, deep_copy=True)
         self.config = {} if likelihood_config is None else likelihood_config
         self.config.setdefault('morpher', 'GridInterpolator')
-        if self.pdf_base_config.get('source_wise_interpolation', False):
-            raise NotImplementedError("Source-wise interpolation not implemented for binned likelihoods")
+        # every source morphs over the shape parameters IT depends on only (likelihood.py:76,152-171); unbinned likelihoods
+        self.source_wise_interpolation = self.pdf_base_config.get('source_wise_interpolation', False)
 
         self.base_model = Model(self.pdf_base_config)
         sources = self.base_model.sources
@@ -75,6 +76,7 @@ class LogLikelihoodBase:
         self.rate_parameters = OrderedDict()     # source name -> log prior (or None)
         self.shape_parameters = OrderedDict()    # setting name -> (anchors {z: setting}, log prior, base z)
         self.anchor_models = OrderedDict()       # z tuple -> Model
+        self.anchor_sources = OrderedDict()      # source-wise interpolation: source name -> own z tuple -> Source
         self.is_prepared = False
         self.is_data_set = False
         self._has_non_numeric = False
@@ -144,6 +146,68 @@ class LogLikelihoodBase:
         multipliers = [kwargs.get(s + '_rate_multiplier', 1) for s in self.source_name_list]
         return multipliers, settings
 
+    # -- source-wise interpolation -----------------------------------------------------------
+    @property
+    def source_shape_parameters(self):
+        """source name -> the shape parameters that source responds to: all of them except the settings its config
+        lists under dont_hash_settings (an efficiency setting the source applies always counts); sources that respond
+        to none are left out (likelihood.py:113-130)."""
+        out = OrderedDict()
+        for name, source, use_eff, eff_name in zip(self.source_name_list, self.base_model.sources,
+                                                   self.source_apply_efficiency, self.source_efficiency_names):
+            ignored = set(source.config['dont_hash_settings'])
+            if use_eff:
+                ignored.discard(eff_name)
+            own = OrderedDict((k, v) for k, v in self.shape_parameters.items() if k not in ignored)
+            if own:
+                out[name] = own
+        return out
+
+    def _get_shape_indices(self, source_name):
+        """Positions, among all shape parameters, of the ones `source_name` responds to."""
+        own = self.source_shape_parameters[source_name]
+        return [i for i, k in enumerate(self.shape_parameters) if k in own]
+
+    def _get_model_anchor(self, anchor, source_name):
+        """A source's own anchor -> the anchor of the model that holds it: None where the source does not care."""
+        full = [None] * len(self.shape_parameters)
+        for z, i in zip(anchor, self._get_shape_indices(source_name)):
+            full[i] = z
+        return tuple(full)
+
+    def _prepare_source_wise(self, build_all):
+        """Models only at the anchors some source needs (a setting no source of the model reads at that anchor stays at
+        its base value), then per full-grid anchor a view that takes every source from the model built at ITS
+        projection of the anchor.  The device tensor stays the full Cartesian grid: interpolating a source over an
+        axis it does not respond to returns its value unchanged (the weights along that axis sum to one), so the
+        result is the reference's per-source interpolation (likelihood.py:152-171,210-240,534-563) and the kernels
+        do not change; the reduced set of models is what the user's sources see built."""
+        own_params = self.source_shape_parameters
+        own_morphers = OrderedDict((name, MORPHERS[self.config['morpher']](self.config.get('morpher_config', {}), sp))
+                                   for name, sp in own_params.items())
+        wanted = []
+        for name, morpher in own_morphers.items():
+            for anchor in morpher.get_anchor_points(bounds=None):
+                zs = self._get_model_anchor(tuple(anchor), name)
+                if zs not in wanted:
+                    wanted.append(zs)
+        built = dict(zip(wanted, build_all(wanted)))
+        self.source_morphers = own_morphers
+        self.anchor_sources = OrderedDict()
+        for name, morpher in own_morphers.items():
+            i = self.source_name_list.index(name)
+            self.anchor_sources[name] = OrderedDict(
+                (tuple(anchor), built[self._get_model_anchor(tuple(anchor), name)].sources[i])
+                for anchor in morpher.get_anchor_points(bounds=None))
+        for zs in (tuple(z) for z in self.morpher.get_anchor_points(bounds=self.get_bounds())):
+            sources = []
+            for i, name in enumerate(self.source_name_list):
+                if name in own_params:
+                    sources.append(self.anchor_sources[name][tuple(zs[j] for j in self._get_shape_indices(name))])
+                else:
+                    sources.append(self.base_model.sources[i])
+            self.anchor_models[zs] = _SourceWiseModel(self.base_model, sources)
+
     # -- anchor models ---------------------------------------------------------------------
     def prepare(self, n_cores=1, ipp_client=None):
         """Compute the model at every anchor point.  n_cores > 1 builds the anchor models on a pool of THREADS
@@ -158,18 +222,23 @@ class LogLikelihoodBase:
             def build(zs):
                 conf = deepcopy(self.pdf_base_config)
                 for z, (name, (anchors, _, _)) in zip(zs, self.shape_parameters.items()):
-                    conf[name] = anchors[z]
+                    if z is not None:                      # None: no source built here reads this setting
+                        conf[name] = anchors[z]
                 return Model(conf)
 
-            points = [tuple(zs) for zs in self.morpher.get_anchor_points(bounds=self.get_bounds())]
-            if n_cores and n_cores > 1 and len(points) > 1:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=int(n_cores)) as pool:
-                    models = list(pool.map(build, points))
+            def build_all(points):
+                if n_cores and n_cores > 1 and len(points) > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=int(n_cores)) as pool:
+                        return list(pool.map(build, points))
+                return [build(zs) for zs in points]
+
+            if self.source_wise_interpolation:
+                self._prepare_source_wise(build_all)
             else:
-                models = [build(zs) for zs in points]
-            for zs, model in zip(points, models):          # anchor order, whatever order the pool finished in
-                self.anchor_models[zs] = model
+                points = [tuple(zs) for zs in self.morpher.get_anchor_points(bounds=self.get_bounds())]
+                for zs, model in zip(points, build_all(points)):   # anchor order, whatever order the pool finished in
+                    self.anchor_models[zs] = model
         self.is_data_set = False
         self.is_prepared = True
 
@@ -225,6 +294,33 @@ class LogLikelihoodBase:
                     zip(self.source_apply_efficiency, self.source_efficiency_names) if use]
             scale[self.source_apply_efficiency] *= np.array(effs)
         return prior, np.asarray(zs, dtype=float), scale
+
+
+class _SourceWiseModel:
+    """What a full-grid anchor looks like under source-wise interpolation: the base model's analysis space with every
+    source taken from the model built at that source's own anchor.  Scores are cached per source object, so a source
+    shared by many grid anchors is evaluated once per dataset."""
+
+    def __init__(self, base_model, sources):
+        self.config = base_model.config
+        self.sources = sources
+        self._base = base_model
+
+    def expected_events(self, s=None):
+        if s is None:
+            return np.array([src.expected_events for src in self.sources])
+        return s.expected_events
+
+    def score_events(self, d):
+        coords = self._base.to_analysis_dimensions(d)
+        rows = []
+        for src in self.sources:
+            cached = getattr(src, '_blueice_amd_score', None)
+            if cached is None or cached[0] is not d:
+                cached = (d, src.pdf(*coords))
+                src._blueice_amd_score = cached
+            rows.append(cached[1])
+        return np.vstack(rows)
 
 
 def _prior_of(log_prior, values):
@@ -465,6 +561,8 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
     def prepare(self, *args, **kwargs):
         super().prepare(*args, **kwargs)
         self.ps, self.n_model_events = self.base_model.pmf_grids()
+        if len(self.shape_parameters) and self.source_wise_interpolation:
+            raise NotImplementedError("Source-wise interpolation not implemented for binned likelihoods")   # likelihood.py:590-591
         self.bin_shape = self.ps.shape[1:]
         self._stream_models(lambda m: m.pmf_grids(), int(np.prod(self.bin_shape, dtype=np.int64)))
         self.ctx.set_analysis_space([edges for _, edges in self.base_model.config['analysis_space']])
@@ -721,9 +819,132 @@ class LogLikelihoodSum:
         raise InvalidParameter("Non-existing parameter %s" % parameter_name)
 
 
+class LogLikelihoodReParam:
+    """A likelihood seen through other parameters (reference: blueice/likelihood.py:715-864).  Host-side only: new
+    parameters are turned into rate multipliers of the wrapped likelihood before every call, so the device path is
+    the wrapped likelihood's.
+
+    conv_config maps
+      `<new parameter>`               -> (anchor values, log prior, base value): registers the new parameter (its
+                                         bounds are the extremes of the anchor values);
+      `<source>_rate_multiplier`      -> dict(params=[new parameters], func=f): the multiplier handed to the wrapped
+                                         likelihood is f(*values) / f(*base values), base values from the model config.
+    """
+
+    def __init__(self, likelihood, conv_config):
+        self._inner = likelihood
+        self.conv_config = conv_config
+        self.pdf_base_config = likelihood.pdf_base_config
+        self.check_conv_config()
+
+    @staticmethod
+    def _is_rate(key):
+        return key.endswith('_rate_multiplier')
+
+    def check_conv_config(self):
+        """The parameters the conversions read are exactly the new parameters declared, and each has a base value."""
+        declared = {k for k in self.conv_config if not self._is_rate(k)}
+        used = {p for v in self.conv_config.values() if isinstance(v, dict) for p in v['params']}
+        assert declared == used, "New parameters are not consistent, double check conv_config..."
+        config = self._inner.base_model.config
+        missing = [p for p in self.conv_config if not self._is_rate(p) and not config.get(p, False)]
+        assert not missing, "%s are missing in the config" % ', '.join(missing)
+
+    # -- what the inference helpers look at ---------------------------------------------------------
+    @property
+    def rate_parameters(self):
+        """The wrapped likelihood's rate parameters that are not computed from new parameters."""
+        return OrderedDict((k, v) for k, v in self._inner.rate_parameters.items()
+                           if k + '_rate_multiplier' not in self.conv_config)
+
+    @property
+    def shape_parameters(self):
+        out = OrderedDict(self._inner.shape_parameters)
+        for k, v in self.conv_config.items():
+            if not self._is_rate(k):
+                out[k] = ({z: z for z in v[0]}, v[1], v[2])
+        return out
+
+    @property
+    def base_model(self):
+        """A copy of the wrapped base model whose simulate() understands the new parameters."""
+        model = deepcopy(self._inner.base_model)
+        model.simulate = self._simulate
+        return model
+
+    def set_data(self, d):
+        self._inner.set_data(d)
+
+    def get_bounds(self, parameter_name=None):
+        if parameter_name is None:
+            return [self.get_bounds(p) for p in self.shape_parameters]
+        inner = self._inner
+        if parameter_name in inner.shape_parameters or parameter_name in inner.rate_parameters \
+                or self._is_rate(parameter_name):
+            return inner.get_bounds(parameter_name)
+        zs = list(self.shape_parameters[parameter_name][0].keys())
+        return min(zs), max(zs)
+
+    # -- conversion -----------------------------------------------------------------------------------
+    def _parameter_converter(self, with_suffix=True, **kwargs):
+        """New-parameter kwargs -> kwargs of the wrapped likelihood.  with_suffix=False: rate multipliers go in and
+        come out keyed by source name (the form Model.simulate takes)."""
+        if not with_suffix:
+            kwargs = {(k + '_rate_multiplier' if k in self._inner.rate_parameters else k): v for k, v in kwargs.items()}
+        out, consumed = OrderedDict(), set()
+        for key, spec in self.conv_config.items():
+            if not self._is_rate(key):
+                continue
+            base = [self.pdf_base_config.get(p) for p in spec['params']]
+            here = [kwargs.get(p, b) for p, b in zip(spec['params'], base)]
+            out[key] = spec['func'](*here) / spec['func'](*base)
+            consumed.update(spec['params'])
+        for k, v in kwargs.items():
+            if k not in consumed:
+                out[k] = v
+        if not with_suffix:
+            out = OrderedDict((k.split('_rate_multiplier')[0], v) for k, v in out.items())
+        return out
+
+    def __call__(self, compute_pdf=False, livetime_days=None, **kwargs):
+        return self._inner(compute_pdf=compute_pdf, livetime_days=livetime_days,
+                           **deepcopy(self._parameter_converter(**kwargs)))
+
+    def _simulate(self, kwargs=None, livetime_days=None):
+        converted = self._parameter_converter(with_suffix=False, **(kwargs or {}))
+        multipliers = {k: v for k, v in converted.items() if k in self._inner.rate_parameters}
+        return self._inner.base_model.simulate(rate_multipliers=multipliers, livetime_days=livetime_days)
+
+
+class LogAncillaryLikelihood:
+    """An analytic constraint term with the likelihood interface, for use inside a LogLikelihoodSum (reference:
+    blueice/likelihood.py:958-1001).  `func(OrderedDict parameter -> value, **func_kwargs)` returns the log
+    likelihood; parameters not given in a call take their value from `config`."""
+
+    def __init__(self, func, parameter_list, config=None, func_kwargs=None):
+        self.func = func
+        self.func_kwargs = {} if func_kwargs is None else func_kwargs
+        self.pdf_base_config = {} if config is None else config
+        self.rate_parameters = dict()
+        self.source_list = []
+        self.shape_parameters = OrderedDict((name, (None, None, None)) for name in parameter_list)
+
+    def get_bounds(self, parameter_name=None):
+        if parameter_name is None:
+            return [self.get_bounds(p) for p in self.shape_parameters]
+        if parameter_name in self.shape_parameters:
+            return -np.inf, np.inf                      # the other terms of a sum may be more restrictive
+        raise InvalidParameter("Non-existing parameter %s" % parameter_name)
+
+    def __call__(self, **kwargs):
+        values = OrderedDict((name, self.pdf_base_config[name]) for name in self.shape_parameters)
+        values.update(kwargs)
+        return self.func(values, **self.func_kwargs)
+
+
 # inference helpers double as methods, as in the reference (likelihood.py:1004-1007)
 from . import inference  # noqa: E402
 
 for _name in inference.__all__:
-    for _cls in (LogLikelihoodBase, LogLikelihoodSum):
+    for _cls in (LogLikelihoodBase, LogLikelihoodSum, LogAncillaryLikelihood, LogLikelihoodReParam):
         setattr(_cls, _name, getattr(inference, _name))

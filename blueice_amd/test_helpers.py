@@ -10,7 +10,7 @@ from scipy.stats import norm
 from .source import DensityEstimatingSource, MonteCarloSource, Source
 
 __all__ = ['GaussianSourceBase', 'GaussianSource', 'GaussianMCSource', 'FixedSampleSource',
-           'BASE_CONFIG', 'conf_for_test', 'almost_equal', 'make_data']
+           'BASE_CONFIG', 'BASE_CONV_CONFIG', 'conf_for_test', 'conf_for_reparam_test', 'almost_equal', 'make_data']
 
 _EVENT_DTYPE = [('x', float), ('source', int)]
 
@@ -83,6 +83,24 @@ def conf_for_test(n_sources=1, mc=False, **overrides):
         conf['default_source_class'] = GaussianMCSource
     conf.update(overrides)
     return conf
+
+
+def conf_for_reparam_test(n_source=1, mc=False, **overrides):
+    """Three sources op0, op1, op2 and two extra settings np0, np1 for LogLikelihoodReParam to convert from."""
+    conf = conf_for_test(n_source, mc, **overrides)
+    conf['sources'] = [{'name': 'op%d' % i} for i in range(3)]
+    conf['np0'] = conf['np1'] = 1
+    return conf
+
+
+# conversion: op0 = np0^2, op1 = np1^2, op2 = np0 np1 (relative to their values at np0 = np1 = 1)
+BASE_CONV_CONFIG = dict(
+    np0=(np.linspace(1e-12, 10, 2), None, None),
+    np1=(np.linspace(1e-12, 10, 2), None, None),
+    op0_rate_multiplier=dict(params=['np0'], func=lambda a: a ** 2),
+    op1_rate_multiplier=dict(params=['np1'], func=lambda b: b ** 2),
+    op2_rate_multiplier=dict(params=['np0', 'np1'], func=lambda a, b: a * b),
+)
 
 
 def almost_equal(a, b, fraction=1e-6):

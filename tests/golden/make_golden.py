@@ -5,7 +5,7 @@ Development-container only (the reference does not exist on the GPU box).  Run a
 
     mkdir -p /tmp/golden_scratch && cd /tmp/golden_scratch && PYTHONDONTWRITEBYTECODE=1 \
         PYTHONPATH=/root/repo/tools/oracle_shims:/root/reference:/root/repo/tests \
-        python /root/repo/tests/golden/make_golden.py
+        python /root/repo/tests/golden/make_golden.py [case names ...]
 
 The likelihoods are built by tests/model_zoo.py from the reference's own classes
 (`namespace_of('blueice')`); the same builders later run on blueice_amd in the drop-in tests.
@@ -170,18 +170,43 @@ def dump_api(name, lf, calls):
         except (AssertionError, ValueError, NotImplementedError) as e:
             lls.append(np.nan)
             errs.append(type(e).__name__)
-    np.savez_compressed(os.path.join(OUT, name + '.npz'), call_ll=np.array(lls), call_error=np.array(errs))
+    extra = {}
+    if getattr(lf, 'source_wise_interpolation', False) and hasattr(lf, 'ps_interpolators'):
+        # source-wise interpolation: every source's OWN anchor tensor (pdf at the events, expected events), as the
+        # reference's per-source interpolators hold them -- the host layer must upload their full-grid expansion
+        for i, sn in enumerate(lf.source_name_list):
+            it = lf.ps_interpolators[sn]
+            if callable(it):
+                rgi = it.__closure__[0].cell_contents
+                extra['sw_%d_ps' % i] = np.asarray(rgi.values, dtype=float)
+                for k, g in enumerate(rgi.grid):
+                    extra['sw_%d_z_%d' % (i, k)] = np.asarray(g, dtype=float)
+                extra['sw_%d_dims' % i] = np.array(lf._get_shape_indices(sn))
+                extra['sw_%d_mus' % i] = np.array([src.expected_events for src in lf.anchor_sources[sn].values()],
+                                                  dtype=float).reshape(rgi.values.shape[:-1])
+            else:
+                extra['sw_%d_ps' % i] = np.asarray(it, dtype=float)
+                extra['sw_%d_dims' % i] = np.array([], dtype=int)
+                extra['sw_%d_mus' % i] = np.array(lf.base_model.sources[i].expected_events, dtype=float)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), call_ll=np.array(lls), call_error=np.array(errs), **extra)
     print('%-28s calls=%d  %s' % (name, len(calls), [e or round(v, 6) for v, e in zip(lls, errs)]))
 
 
 if __name__ == '__main__':
     import scipy
     print('reference blueice', blueice.__version__, 'numpy', np.__version__, 'scipy', scipy.__version__)
+    import sys
+    only = set(sys.argv[1:])              # optional: names of the cases to (re)generate; default all
     ns = model_zoo.namespace_of('blueice')
     for name, builder in list(model_zoo.CASES.items()) + list(model_zoo.UNBINNED_CASES.items()):
+        if only and name not in only:
+            continue
         lf, calls, full = builder(ns)
         dump(name, lf, calls, full)
     for name, builder in model_zoo.API_CASES.items():
+        if only and name not in only:
+            continue
         lf, calls = builder(ns)
         dump_api(name, lf, calls)
-    fit_goldens(ns)
+    if not only or 'fit' in only:
+        fit_goldens(ns)

@@ -24,7 +24,9 @@ def namespace_of(package):
                            UnbinnedLogLikelihood=lk.UnbinnedLogLikelihood, GaussianSource=th.GaussianSource,
                            DensityEstimatingSource=src.DensityEstimatingSource,
                            FixedSampleSource=th.FixedSampleSource, GaussianMCSource=th.GaussianMCSource,
-                           conf_for_test=th.conf_for_test, make_data=th.make_data)
+                           conf_for_test=th.conf_for_test, make_data=th.make_data,
+                           LogLikelihoodSum=lk.LogLikelihoodSum, LogLikelihoodReParam=lk.LogLikelihoodReParam,
+                           LogAncillaryLikelihood=lk.LogAncillaryLikelihood)
 
 
 _morphed_cache = {}
@@ -70,13 +72,14 @@ def sample(rng, n, space):
     return d
 
 
-def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=None, bb_floor=False):
+def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=None, bb_floor=False, extra_config=None):
     strengths = [1.0, -0.6, 0.45, 1.7, -1.2, 0.8]
     conf = dict(sources=[], default_source_class=morphed_source_class(ns),
                 analysis_space=space, force_recalculation=True, never_save_to_cache=True,
                 shift=0., stretch=0., tilt=0.)
     if livetime is not None:
         conf['livetime_days'] = livetime
+    conf.update(extra_config or {})
     for s in range(S):
         d = sample(rng, n_mc, space)
         if bb_floor and s == 0:
@@ -492,7 +495,105 @@ def api_livetime_zero_with_data(ns):
     return lf, [dict(livetime_days=0.), dict(shift=-0.2), dict(livetime_days=1e-3)]
 
 
-API_CASES = OrderedDict((f.__name__, f) for f in (api_compute_pdf, api_livetime_zero, api_livetime_zero_with_data))
+def api_source_wise(ns):
+    """Source-wise interpolation of an unbinned likelihood (blueice/likelihood.py:152-171,210-240,534-563): source a
+    responds to mu only, b to sigma only, c to neither (its settings are fixed in its own spec); calls on and off the
+    anchors, with rate multipliers, and outside the box."""
+    rng = np.random.default_rng(61)
+    conf = ns.conf_for_test(n_sources=3, events_per_day=20., source_wise_interpolation=True)
+    conf['sources'] = [dict(name='a', extra_dont_hash_settings=['sigma']),
+                       dict(name='b', mu=1.5, extra_dont_hash_settings=['mu']),
+                       dict(name='c', mu=-2., sigma=2.5, events_per_day=5., extra_dont_hash_settings=['mu', 'sigma'])]
+    lf = ns.UnbinnedLogLikelihood(conf)
+    for n in 'abc':
+        lf.add_rate_parameter(n)
+    lf.add_shape_parameter('mu', (-1., 0., 1.))
+    lf.add_shape_parameter('sigma', (0.8, 1., 1.5))
+    lf.prepare()
+    xs = np.concatenate([rng.normal(0.2, 1.1, 30), rng.normal(1.5, 1.2, 25), rng.normal(-2., 2.5, 8)])
+    lf.set_data(_events(xs))
+    calls = [{}, dict(mu=0.5), dict(sigma=1.2), dict(mu=-0.7, sigma=0.9), dict(mu=1., sigma=1.5),
+             dict(mu=0.3, sigma=1.35, a_rate_multiplier=1.7, b_rate_multiplier=0.4, c_rate_multiplier=0.),
+             dict(mu=-1., sigma=0.8, c_rate_multiplier=2.), dict(mu=1.2), dict(sigma=0.5)]
+    return lf, calls
+
+
+def api_source_wise_binned(ns):
+    """The binned likelihood refuses source-wise interpolation in prepare() (blueice/likelihood.py:590-591)."""
+    conf = ns.conf_for_test(n_sources=2, source_wise_interpolation=True)
+    lf = ns.BinnedLogLikelihood(conf)
+    lf.add_shape_parameter('mu', (-1., 0., 1.))
+
+    class _Prepare:                       # dump_api / the parity test call lf(**kw): make prepare() the call
+        def __call__(self, **kw):
+            lf.prepare()
+            return 0.
+    return _Prepare(), [{}]
+
+
+def _conv_config():
+    return dict(np0=(np.linspace(1e-12, 10, 2), None, None), np1=(np.linspace(1e-12, 10, 2), None, None),
+                op0_rate_multiplier=dict(params=['np0'], func=lambda a: a ** 2),
+                op1_rate_multiplier=dict(params=['np1'], func=lambda b: b ** 2),
+                op2_rate_multiplier=dict(params=['np0', 'np1'], func=lambda a, b: a * b))
+
+
+def api_reparam_unbinned(ns):
+    """LogLikelihoodReParam over an unbinned likelihood of three sources (blueice/likelihood.py:715-864; the set-up of
+    the reference's tests/test_likelihood_reparam.py), with data that is not all at x = 0."""
+    rng = np.random.default_rng(62)
+    conf = ns.conf_for_test(events_per_day=1.)
+    conf['sources'] = [dict(name='op0'), dict(name='op1', mu=0.8), dict(name='op2', sigma=1.7)]
+    conf['np0'] = conf['np1'] = 1
+    inner = ns.UnbinnedLogLikelihood(conf)
+    for n in ('op0', 'op1', 'op2'):
+        inner.add_rate_parameter(n)
+    inner.prepare()
+    lf = ns.LogLikelihoodReParam(inner, _conv_config())
+    lf.set_data(_events(rng.normal(0.3, 1.3, 12)))
+    calls = [{}, dict(np0=2.), dict(np1=3.), dict(np0=2., np1=2.), dict(np0=0.5, np1=1.5), dict(np0=1e-12, np1=10.)]
+    return lf, calls
+
+
+def api_reparam_binned(ns):
+    """LogLikelihoodReParam over a BINNED likelihood with a shape parameter: the new parameters become rate multipliers,
+    the shape parameter passes through to the morph."""
+    from scipy import stats
+    rng = np.random.default_rng(63)
+    space = [['x', np.linspace(-4, 4, 17)], ['y', np.linspace(0, 5, 6)]]
+    inner = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 3000, 250, extra_config=dict(amp=1., tilt2=2.))
+    inner.rate_parameters['s0'] = stats.norm(1, 0.4).logpdf
+    conv = dict(amp=((0.5, 2.), None, None), tilt2=((1., 4.), None, None),
+                s0_rate_multiplier=dict(params=['amp'], func=lambda a: a ** 3),
+                s1_rate_multiplier=dict(params=['amp', 'tilt2'], func=lambda a, t: a + 0.5 * t))
+    lf = ns.LogLikelihoodReParam(inner, conv)
+    calls = [{}, dict(shift=0.4), dict(amp=1.5), dict(amp=0.7, tilt2=3., shift=-0.6), dict(tilt2=1., shift=1.),
+             dict(amp=2., tilt2=4., shift=1.3)]
+    return lf, calls
+
+
+def api_sum_ancillary(ns):
+    """LogLikelihoodSum of a binned likelihood and an analytic constraint (LogAncillaryLikelihood,
+    blueice/likelihood.py:867-1001), weighted."""
+    from scipy import stats
+    rng = np.random.default_rng(64)
+    space = [['x', np.linspace(-4, 4, 17)]]
+    binned = morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 2000, 120)
+
+    def constraint(values, width):
+        return stats.norm.logpdf(values['shift'], 0.1, width) - 0.5 * (values['nuisance'] / 2.) ** 2
+
+    anc = ns.LogAncillaryLikelihood(constraint, ['shift', 'nuisance'], config=dict(shift=0., nuisance=0.7),
+                                    func_kwargs=dict(width=0.3))
+    lf = ns.LogLikelihoodSum([binned, anc], likelihood_weights=[1, 0.5])
+    calls = [{}, dict(shift=0.35), dict(shift=-0.8, nuisance=-1.2), dict(shift=0.5, s1_rate_multiplier=1.4, nuisance=0.),
+             dict(shift=1.2, nuisance=3.)]
+    return lf, calls
+
+
+API_CASES = OrderedDict((f.__name__, f) for f in (api_compute_pdf, api_livetime_zero, api_livetime_zero_with_data,
+                                                  api_source_wise, api_source_wise_binned, api_reparam_unbinned,
+                                                  api_reparam_binned, api_sum_ancillary))
 
 CASES = OrderedDict((f.__name__, f) for f in (
     ref_single_bin, ref_zero_bin, ref_multi_bin_single_dim, ref_multi_bin, ref_bb_single_bin,

@@ -78,6 +78,82 @@ def test_api_cases_match_reference(ns, name):
             lf.eval_points(dict(shift=[0.3]), livetime_days=1.)
 
 
+def test_source_wise_interpolation_as_the_reference_tests_it(ns):
+    """tests/test_likelihood.py::test_source_wise_interpolation of the reference: when every source responds to every
+    shape parameter, source-wise interpolation returns exactly what the plain likelihood returns (value, rates,
+    per-event densities)."""
+    data = np.zeros(5, dtype=[('x', float), ('source', int)])
+    data['x'] = np.linspace(0, 1, 5)
+    out = []
+    for source_wise in (False, True):
+        config = ns.conf_for_test(events_per_day=1)
+        if source_wise:
+            config['source_wise_interpolation'] = True
+        lf = ns.UnbinnedLogLikelihood(config)
+        lf.add_shape_parameter('mu', anchors={-2: -2, 0: 0, 2: 2})
+        lf.prepare()
+        lf.set_data(data)
+        out.append((lf(full_output=True), lf(full_output=True, mu=1)))
+    for plain, sw in zip(*out):
+        assert plain[0] == sw[0]
+        assert (plain[1] == sw[1]).all() and (plain[2] == sw[2]).all()
+    # ... and the batched form agrees with single calls on the three-source case of the goldens
+    lf, calls = model_zoo.api_source_wise(ns)
+    keep = [kw for kw in calls if np.isfinite(lf(**kw))]
+    names = ['mu', 'sigma', 'a_rate_multiplier', 'b_rate_multiplier', 'c_rate_multiplier']
+    dflt = dict(mu=0., sigma=1.)
+    pts = {n: [kw.get(n, dflt.get(n, 1.0)) for kw in keep] for n in names}
+    for b, kw in zip(lf.eval_points(pts), keep):
+        assert same(b, lf(**kw), 1e-12)
+
+
+def test_reparam_as_the_reference_tests_it(ns):
+    """tests/test_likelihood_reparam.py of the reference: closed-form values, agreement with the wrapped likelihood,
+    the consistency assertions, and a fit in the new parameters."""
+    from copy import deepcopy
+    from scipy import stats
+    from blueice_amd import LogLikelihoodReParam
+    from blueice_amd.test_helpers import BASE_CONV_CONFIG, conf_for_reparam_test
+
+    def fresh():
+        lf_old = ns.UnbinnedLogLikelihood(conf_for_reparam_test(events_per_day=1))
+        for n in ('op0', 'op1', 'op2'):
+            lf_old.add_rate_parameter(n)
+        lf_old.prepare()
+        return lf_old
+
+    lf_old = fresh()
+    lf = LogLikelihoodReParam(lf_old, deepcopy(BASE_CONV_CONFIG))
+    lf.set_data(np.zeros(3, dtype=[('x', float), ('source', int)]))
+    for v in (1, 2, 3):
+        total = v ** 2 + v ** 2 + v * v
+        want = -total + 3 * np.log(total) + 3 * stats.norm.logpdf(0)
+        assert np.isclose(lf(np0=v, np1=v), want, atol=1e-8)
+    d = lf.base_model.simulate()
+    lf.set_data(d)
+    assert np.isclose(lf(), lf_old())
+    assert np.isclose(lf(np0=2), lf_old(op0_rate_multiplier=4, op2_rate_multiplier=2))
+    assert np.isclose(lf(np0=2, np1=2), lf_old(op0_rate_multiplier=4, op1_rate_multiplier=4, op2_rate_multiplier=4))
+    assert list(lf.rate_parameters) == [] and list(lf.shape_parameters) == ['np0', 'np1']
+    assert lf.get_bounds('np0') == (1e-12, 10) and len(lf.get_bounds()) == 2
+    assert len(lf.base_model.simulate(dict(np0=3., np1=0.5))) >= 0           # simulate() speaks the new parameters
+    bad = deepcopy(BASE_CONV_CONFIG)
+    bad['op2_rate_multiplier'] = dict(params=['np0', 'np7'], func=lambda a, b: a * b)
+    with pytest.raises(AssertionError):
+        LogLikelihoodReParam(fresh(), bad)
+    conf = conf_for_reparam_test(events_per_day=1)
+    del conf['np1']
+    inner = ns.UnbinnedLogLikelihood(conf)
+    inner.prepare()
+    with pytest.raises(AssertionError):
+        LogLikelihoodReParam(inner, deepcopy(BASE_CONV_CONFIG))
+    # the inference helpers are methods of the wrapper too
+    np.random.seed(3)
+    lf.set_data(lf.base_model.simulate(dict(np0=2., np1=1.5), livetime_days=40))
+    fit, ll_max = lf.bestfit_scipy(pass_bounds_to_minimizer=True)
+    assert set(fit) == {'np0', 'np1'} and ll_max >= lf(np0=2., np1=1.5) - 1e-9
+
+
 def test_gradient_fit_falls_back_without_gradient_support(ns):
     """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (Beeston-Barlow terms, a sum
     containing one) must take the numerical route instead of failing mid-fit."""

@@ -222,6 +222,107 @@ def test_unbinned_uploads_equal_reference_tensors(ns, name):
         np.testing.assert_array_equal(scale, c['raw']['call_scale'][j])
 
 
+def test_source_wise_interpolation_uploads_the_expansion_of_the_per_source_tensors(ns):
+    """Source-wise interpolation (likelihood.py:152-171,534-563): models are built only at the anchors some source
+    needs, and the device receives the full-grid tensor whose (anchor, source) row is that source's row at ITS
+    projection of the anchor -- compared with the per-source tensors the reference's interpolators hold."""
+    import os
+    import blueice_amd.model as model_module
+    built = []
+    original = model_module.Model.__init__
+
+    def counting(self, config, **kw):
+        built.append((config.get('mu'), config.get('sigma')))
+        original(self, config, **kw)
+
+    model_module.Model.__init__ = counting
+    try:
+        lf, calls = model_zoo.api_source_wise(ns)
+    finally:
+        model_module.Model.__init__ = original
+    # base model + 3 anchors of mu (sigma at its base value) + 3 anchors of sigma (mu at its base value)
+    assert built == [(0, 1), (-1., 1), (0., 1), (1., 1), (0, 0.8), (0, 1.), (0, 1.5)]
+    assert list(lf.source_shape_parameters) == ['a', 'b'] and lf._get_shape_indices('b') == [1]
+    assert lf._get_model_anchor((0.8,), 'b') == (None, 0.8)
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'api_source_wise.npz'))
+    rec = lf.ctx
+    grid = [np.array([-1., 0., 1.]), np.array([0.8, 1., 1.5])]
+    assert rec.S == 3 and rec.B == 63 and len(rec.anchors) == 9
+    for lin, multi in enumerate(np.ndindex(3, 3)):
+        ps, mus, _ = rec.anchors[lin]
+        for i in range(3):
+            dims = list(f['sw_%d_dims' % i])
+            own = tuple(multi[k] for k in dims)
+            np.testing.assert_array_equal(ps[i], f['sw_%d_ps' % i][own])
+            assert mus[i] == f['sw_%d_mus' % i][own]
+            for pos, k in enumerate(dims):
+                np.testing.assert_array_equal(f['sw_%d_z_%d' % (i, pos)], grid[k])
+    # the binned likelihood refuses, as the reference does
+    refuse, _ = model_zoo.api_source_wise_binned(ns)
+    with pytest.raises(NotImplementedError):
+        refuse()
+
+
+def test_reparam_and_ancillary_host_logic():
+    from blueice_amd import LogAncillaryLikelihood, LogLikelihoodReParam, LogLikelihoodSum
+    from blueice_amd.exceptions import InvalidParameter
+
+    class Inner:
+        rate_parameters = OrderedDict(op0=None, op1=None, bg=None)
+        shape_parameters = OrderedDict(shift=({-1: -1, 1: 1}, None, None))
+        pdf_base_config = dict(np0=2., np1=4., shift=0.)
+
+        class base_model:
+            config = dict(np0=2., np1=4., shift=0.)
+
+            @staticmethod
+            def simulate(rate_multipliers=None, livetime_days=None):
+                return rate_multipliers, livetime_days
+
+        def get_bounds(self, name):
+            return (-1, 1) if name == 'shift' else (0, float('inf'))
+
+        def set_data(self, d):
+            self.data = d
+
+        def __call__(self, compute_pdf=False, livetime_days=None, **kw):
+            self.seen = (compute_pdf, livetime_days, dict(kw))
+            return -1.5
+
+    conv = dict(np0=((0.5, 8.), None, None), np1=((1., 6.), 'prior', 4.),
+                op0_rate_multiplier=dict(params=['np0'], func=lambda a: a ** 2),
+                op1_rate_multiplier=dict(params=['np0', 'np1'], func=lambda a, b: a * b))
+    inner = Inner()
+    lf = LogLikelihoodReParam(inner, conv)
+    assert lf(np0=4., shift=0.3, bg_rate_multiplier=1.2, livetime_days=3.) == -1.5
+    assert inner.seen == (False, 3., dict(op0_rate_multiplier=4., op1_rate_multiplier=2., shift=0.3, bg_rate_multiplier=1.2))
+    lf()
+    assert inner.seen[2] == dict(op0_rate_multiplier=1., op1_rate_multiplier=1.)
+    assert list(lf.rate_parameters) == ['bg'] and list(lf.shape_parameters) == ['shift', 'np0', 'np1']
+    assert lf.shape_parameters['np1'] == ({1.: 1., 6.: 6.}, 'prior', 4.)
+    assert lf.get_bounds('np0') == (0.5, 8.) and lf.get_bounds('shift') == (-1, 1)
+    assert lf.get_bounds() == [(-1, 1), (0.5, 8.), (1., 6.)]
+    assert lf._simulate(dict(np1=8., bg=3.), livetime_days=2.) == (dict(op0=1., op1=2., bg=3.), 2.)
+    lf.set_data('d')
+    assert inner.data == 'd'
+    names = lf.make_objective()[1]
+    assert names == ['bg_rate_multiplier', 'shift', 'np0', 'np1']
+    with pytest.raises(AssertionError):
+        LogLikelihoodReParam(inner, dict(conv, extra=((0., 1.), None, None)))          # declared, never used
+    with pytest.raises(AssertionError):
+        LogLikelihoodReParam(inner, dict(np0=conv['np0'], np7=conv['np1'], op0_rate_multiplier=conv['op0_rate_multiplier'],
+                                         op1_rate_multiplier=dict(params=['np0', 'np7'], func=lambda a, b: a * b)))
+
+    anc = LogAncillaryLikelihood(lambda v, k: k * v['a'] + v['b'], ['a', 'b'], config=dict(a=2., b=10.), func_kwargs=dict(k=3.))
+    assert anc() == 16. and anc(a=1.) == 13. and anc(b=0., a=0.5) == 1.5
+    assert anc.get_bounds('a') == (-np.inf, np.inf) and len(anc.get_bounds()) == 2
+    with pytest.raises(InvalidParameter):
+        anc.get_bounds('c')
+    tot = LogLikelihoodSum([lf, anc], likelihood_weights=[2., 1.])
+    assert tot(np0=4., a=1.) == 2 * -1.5 + 13.
+    assert inner.seen[2] == dict(op0_rate_multiplier=4., op1_rate_multiplier=2.)
+
+
 def test_likelihood_sum_host_logic():
     from blueice_amd import LogLikelihoodSum
     from blueice_amd.exceptions import InvalidParameter
