@@ -675,6 +675,14 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
         lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
     ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
     ex['api_bestfit_max_loglikelihood'] = ll
+    zz, rr = model.random_points(1000000, seed=11)       # configs[3] through lf.eval_points: dict of arrays in, ll [P] out
+    pts = {'shape%d' % i: zz[:, i] for i in range(zz.shape[1])}
+    pts.update({'s%d_rate_multiplier' % s: rr[:, s] for s in range(model.S)})
+    lf.eval_points(pts)
+    t = time.perf_counter()
+    out = lf.eval_points(pts)
+    ex['api_eval_points_1e6_s'] = time.perf_counter() - t
+    assert out.shape == (1000000,) and np.all(np.isfinite(out))
     lf.ctx.set_param('sparse', 0)                       # the same fit with every bin visited on every call
     lf.set_binned_data(counts.reshape(model.bins))
     lf.bestfit_scipy(**fixed)
