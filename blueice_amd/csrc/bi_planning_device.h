@@ -383,7 +383,9 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->valid = true;
             plan->n_groups = n_groups;
             plan->scan_cb = 4;
-            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), c->scan_waves_per_cu);
+            // (four times the waves of the non-empty-bin pass: the finer the split, the shorter the last, partly filled
+            // round of blocks -- +1.7 % at C2, tools/tune_scan_waves.py; the pass keeps no per-wave partial sums)
+            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), c->scan_waves_per_cu * 4);
             plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
             plan->launches += 1;
             e = hipStreamSynchronize(c->stream);
@@ -397,8 +399,16 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->use_scan = true;
             plan->scan_cb = cb;
             plan->n_groups = n_groups;
-            // (dense data: a third more waves -- 505 k instead of 476 k evaluations/s at C2, tools/tune_scan_dense.py)
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), (mostly_empty || sparse) ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4 / 3);       // every wave owns one partial slot per item
+            // Dense data: four times the waves -- a block of this kernel lasts long (a logarithm per matrix element) and
+            // only three waves per SIMD are resident, so the last round of blocks is a visible tail: 571 k instead of
+            // 531 k evaluations/s at C2 with 96 instead of 32 waves per CU (tools/tune_scan_waves.py).  Every wave owns
+            // one partial slot per item, so the split is bounded by the memory the slots may take (1 GiB).
+            int64_t wpc = (mostly_empty || sparse) ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4;
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), wpc);
+            while (wpc > c->scan_waves_per_cu && (int64_t)ni * k.nbx * kDevG * (int64_t)sizeof(double) > ((int64_t)1 << 30)) {
+                wpc = std::max<int64_t>(c->scan_waves_per_cu, wpc / 2);
+                k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), wpc);
+            }
             dev_free(k.partial);
             dev_free(k.pflags);
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||

@@ -10,8 +10,8 @@ m.upload(ctx, threads=8)
 ctx.set_param('sparse', 0)
 ctx.upload_counts(m.counts(dense=True))
 z, r = m.random_points(131072, seed=11)
-for cb in (2, 4):
-    for wpc in (16, 24, 32):
+for cb in (2,):
+    for wpc in (24, 45, 60, 90, 135):          # dense data gets a third more: 12 .. 60 waves per CU
         ctx.set_param('scan_cb', cb)
         ctx.set_param('scan_waves_per_cu', wpc)
         p = ctx.plan(z, r)
