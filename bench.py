@@ -270,7 +270,7 @@ def toy_leg(ctx, ranks, model, T, steps):
                 gather=ranks.kind)
 
 
-def bb_leg(ctx_dev, steps=10):
+def bb_leg(ctx_dev, steps=24):
     """The Beeston-Barlow kernel (`k_morph_reduce<1,true,true>`) on one grid cell of configs[4]: 2^4 anchors, 6 sources,
     50^4 bins -- all 113 stream rows of an evaluation, 5.65 GB per pass (blueice/likelihood.py:618-660)."""
     from blueice_amd.device import DeviceContext
@@ -283,8 +283,8 @@ def bb_leg(ctx_dev, steps=10):
         ctx.upload_counts(m.counts(dense=True))
         z, r = m.random_points(4, seed=2)
         plans = [ctx.plan(z[i], r[i]) for i in range(4)]
-        for p in plans:
-            p.run()
+        for i in range(8):                     # warm-up: the first passes over a freshly uploaded 4.8 GB tensor run slow
+            plans[i % 4].run()
         ctx.sync()
         ctx.profile(True)
         for i in range(steps):
@@ -675,6 +675,19 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
         lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
     ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
     ex['api_bestfit_max_loglikelihood'] = ll
+    # template building: the binning of one source's Monte Carlo sample (10^6 events, 3 dimensions, 100^3 bins) -- what
+    # prepare() does once per source and anchor model (blueice/source.py:287-299)
+    rng = np.random.default_rng(21)
+    edges = [np.linspace(-4, 4, 101)] * 3
+    sample = [rng.normal(size=1000000) for _ in range(3)]
+    ctx.histogram_events(edges, sample)
+    t = time.perf_counter()
+    on_device = ctx.histogram_events(edges, sample)
+    ex['template_histogram_1e6_events_device_ms'] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    on_host = np.histogramdd(np.stack(sample, 1), bins=edges)[0]
+    ex['template_histogram_1e6_events_numpy_ms'] = (time.perf_counter() - t) * 1e3
+    assert np.array_equal(on_device, on_host)
     zz, rr = model.random_points(1000000, seed=11)       # configs[3] through lf.eval_points: dict of arrays in, ll [P] out
     pts = {'shape%d' % i: zz[:, i] for i in range(zz.shape[1])}
     pts.update({'s%d_rate_multiplier' % s: rr[:, s] for s in range(model.S)})

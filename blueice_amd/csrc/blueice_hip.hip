@@ -463,6 +463,51 @@ int bi_upload_events(bi_ctx* c, int64_t N, const double* coords) {
     return finish_counts(c, 1);
 }
 
+int bi_histogram_events(bi_ctx* c, int k, const int32_t* n_edges, const double* edges, int64_t N, const double* coords,
+                        double* counts) {
+    if (!c) return BI_ERR_INVALID;
+    if (c->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding on this context: call bi_eval_end first");
+    if (k < 1 || k > kMaxDim || !n_edges || !edges || !counts) return fail(c, BI_ERR_INVALID, "need 1..%d axes with edges, and a counts buffer", kMaxDim);
+    if (N < 0 || (N > 0 && !coords)) return fail(c, BI_ERR_INVALID, "bad N / coords");
+    HistArgs h{};
+    h.k = k;
+    int64_t bins = 1;
+    int off = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n_edges[i] < 2) return fail(c, BI_ERR_INVALID, "axis %d needs at least two edges", i);
+        for (int j = 1; j < n_edges[i]; ++j)
+            if (!(edges[off + j] > edges[off + j - 1])) return fail(c, BI_ERR_INVALID, "bin edges of axis %d are not strictly ascending", i);
+        h.n_edges[i] = n_edges[i];
+        h.edge_off[i] = off;
+        off += n_edges[i];
+        bins *= n_edges[i] - 1;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf d_ev, d_edges, d_counts;
+    int rc;
+    if ((rc = dev_alloc(c, d_counts, (size_t)bins * sizeof(double))) || (rc = dev_alloc(c, d_edges, (size_t)off * sizeof(double))) ||
+        (N > 0 && (rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double))))) {
+        dev_free(d_counts); dev_free(d_edges); dev_free(d_ev);
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(d_counts.p, 0, (size_t)bins * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_edges.p, edges, (size_t)off * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && N > 0) {
+        e = hipMemcpyAsync(d_ev.p, coords, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_histogram, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                               (const double*)d_ev.p, N, h, (const double*)d_edges.p, (double*)d_counts.p);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts.p, (size_t)bins * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    dev_free(d_counts); dev_free(d_edges); dev_free(d_ev);
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_histogram_events: %s", hipGetErrorString(e));
+    return BI_OK;
+}
+
 // ---- planning ------------------------------------------------------------------------------
 
 void bi_plan_destroy(bi_ctx* c, bi_plan* p) {

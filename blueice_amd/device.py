@@ -169,6 +169,20 @@ class DeviceContext:
         self._check(self._lib.bi_upload_events(self._h, cols.shape[1], ptr(cols)))
         self.T = 1
 
+    def histogram_events(self, edges, coords):
+        """numpy.histogramdd(events, bins=edges)[0] on the device, independent of the context's model and data:
+        edges = one ascending array per axis, coords = one coordinate array per axis -> counts [*bins] (float64)."""
+        edges = [np.ascontiguousarray(e, dtype=np.float64) for e in edges]
+        cols = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64).ravel() for c in coords]))
+        if cols.shape[0] != len(edges):
+            raise ValueError("need %d coordinate arrays" % len(edges))
+        n_edges = np.array([len(e) for e in edges], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(edges))
+        counts = np.empty([len(e) - 1 for e in edges], dtype=np.float64)
+        self._check(self._lib.bi_histogram_events(self._h, len(edges), ptr(n_edges), ptr(flat), cols.shape[1], ptr(cols),
+                                                  ptr(counts)))
+        return counts
+
     def set_unbinned(self, outlier_likelihood=1e-12):
         """Treat the uploaded rows as pdf values at the events: extended unbinned likelihood."""
         self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))

@@ -227,11 +227,12 @@ class LogLikelihoodBase:
                 return Model(conf)
 
             def build_all(points):
-                if n_cores and n_cores > 1 and len(points) > 1:
-                    from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=int(n_cores)) as pool:
-                        return list(pool.map(build, points))
-                return [build(zs) for zs in points]
+                with self._template_building():
+                    if n_cores and n_cores > 1 and len(points) > 1:
+                        from concurrent.futures import ThreadPoolExecutor
+                        with ThreadPoolExecutor(max_workers=int(n_cores)) as pool:
+                            return list(pool.map(build, points))
+                    return [build(zs) for zs in points]
 
             if self.source_wise_interpolation:
                 self._prepare_source_wise(build_all)
@@ -241,6 +242,12 @@ class LogLikelihoodBase:
                     self.anchor_models[zs] = model
         self.is_data_set = False
         self.is_prepared = True
+
+    def _template_building(self):
+        """Context manager around the construction of the anchor models (a hook: the device likelihoods bin the
+        sources' Monte Carlo samples on the GPU meanwhile)."""
+        from contextlib import nullcontext
+        return nullcontext()
 
     @_needs_preparation
     def set_data(self, d):
@@ -350,6 +357,18 @@ class DeviceLogLikelihood(LogLikelihoodBase):
 
     def _bb_source_index(self):
         return -1
+
+    def _template_building(self):
+        """While the anchor models are built, density-estimating sources histogram their samples on the device
+        (`histdd.device_histograms`; blueice/source.py:287-299 does it with multihist on the host -- at C2 size that is
+        500 source templates x ~1 s).  likelihood_config['device_histograms'] = False keeps numpy.histogramdd."""
+        from contextlib import nullcontext
+        from .histdd import device_histograms
+        if not self.config.get('device_histograms', True):
+            return nullcontext()
+        if self.ctx is None:
+            self.ctx = DeviceContext(self.config.get('device'))
+        return device_histograms(self.ctx, self.config.get('device_histograms_min_events', 32768))
 
     def _stream_models(self, pmf_of, n_bins):
         """Fill the device context from the anchor models (or the base model when nothing morphs).

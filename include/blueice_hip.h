@@ -102,6 +102,15 @@ int bi_upload_counts(bi_ctx* ctx, int64_t T, const double* counts /*[T][B]*/);
 int bi_set_analysis_space(bi_ctx* ctx, int k, const int32_t* n_edges /*[k]*/, const double* edges /*concatenated*/);
 int bi_upload_events(bi_ctx* ctx, int64_t N, const double* coords);
 
+/* Template building: the same binning as a stand-alone service, for the histograms the sources fill while the anchor
+ * models are built -- DensityEstimatingSource.build_histogram's `mh.add(...)`, blueice/source.py:287-299, i.e.
+ * numpy.histogramdd of N events in k dimensions (about a second per 10^6 three-dimensional events on a host core, times
+ * sources x anchor models; ~3 ms here, most of it PCIe).  Needs no model and touches none of the context's state:
+ * coords [k][N] and the edges are borrowed for the call, counts [prod(n_edges - 1)] (C order, host) is OVERWRITTEN with
+ * the number of events per bin.  Unweighted events only. */
+int bi_histogram_events(bi_ctx* ctx, int k, const int32_t* n_edges /*[k]*/, const double* edges /*concatenated*/,
+                        int64_t N, const double* coords, double* counts);
+
 /* Extended unbinned likelihood on the same machinery (UnbinnedLogLikelihood, blueice/likelihood.py:528-573;
  * extended_loglikelihood :678-690).  Upload the model with B = number of events and `ps` = the pdf values
  * of every source at every event for every anchor (what `Model.score_events(d)` returns,

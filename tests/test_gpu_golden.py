@@ -146,6 +146,71 @@ def test_device_histogram_equals_numpy_histogramdd(ctx):
         ctx.set_analysis_space([np.array([0., 1.])])                    # bin count mismatch
 
 
+def test_template_histograms_on_the_device():
+    """bi_histogram_events -- the binning service behind Histdd.add while anchor models are built -- against
+    numpy.histogramdd (what multihist's add applies, blueice/source.py:287-299): model-free context, 1 to 4 axes,
+    non-uniform edges, events on inner and outer edges, out of range, nan and inf, no events at all."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.histdd import Histdd, device_histograms
+    rng = np.random.default_rng(8)
+    c = DeviceContext(0)
+    try:
+        for edges in ([np.linspace(-3, 3, 41)],
+                      [np.array([0., 1., 2.5, 7.]), np.linspace(-1, 1, 6)],
+                      [np.array([0., 1., 2.5, 7.]), np.linspace(-1, 1, 6), np.array([-3., 0., 0.5, 4., 4.25])],
+                      [np.linspace(0, 1, 8), np.linspace(0, 2, 5), np.array([0., 0.1, 1.]), np.linspace(-1, 0, 4)]):
+            N = 50000
+            cols = [rng.uniform(e[0] - 0.3, e[-1] + 0.3, N) for e in edges]
+            for k, e in enumerate(edges):                       # exact edge values, first and last included
+                cols[k][:len(e)] = e
+            cols[0][len(edges[0]) + 1] = np.nan
+            cols[-1][len(edges[-1]) + 2] = np.inf
+            got = c.histogram_events(edges, cols)
+            keep = np.all([np.isfinite(x) for x in cols], axis=0)
+            want = np.histogramdd(np.stack([x[keep] for x in cols], 1), bins=edges)[0]
+            np.testing.assert_array_equal(got, want)
+            assert got.shape == want.shape and 0 < got.sum() < N
+            np.testing.assert_array_equal(c.histogram_events(edges, [np.zeros(0)] * len(edges)), np.zeros(want.shape))
+            # through Histdd: large batches go to the device, small ones and weighted ones stay with numpy
+            host = Histdd(bins=edges).add(*[x[keep] for x in cols])
+            with device_histograms(c, min_events=1000):
+                dev = Histdd(bins=edges).add(*cols).add(*[x[:10] for x in cols])
+                weighted = Histdd(bins=edges).add(*[x[keep] for x in cols], weights=np.full(int(keep.sum()), 0.5))
+            host.add(*[x[:10] for x in cols])
+            np.testing.assert_array_equal(dev.histogram, host.histogram)
+            np.testing.assert_array_equal(weighted.histogram * 2, want)
+        with pytest.raises(ValueError):
+            c.histogram_events([np.array([0., 1., 1.])], [np.zeros(3)])     # edges not strictly ascending
+    finally:
+        c.close()
+
+
+def test_prepare_builds_the_same_templates_with_device_histograms():
+    """prepare() of a likelihood whose sources estimate their densities from 10^5 Monte Carlo events each: templates,
+    MC counts and rates uploaded with the device binning the samples equal those of the numpy.histogramdd route
+    bit for bit -- and so does the likelihood."""
+    import model_zoo
+    ns = model_zoo.namespace_of('blueice_amd')
+    values = []
+    for on in (True, False):
+        np.random.seed(12)
+        conf = ns.conf_for_test(n_sources=2, mc=True, n_events_for_pdf=100000, events_per_day=50.,
+                                analysis_space=[['x', np.linspace(-5, 5, 201)]])
+        lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(device_histograms=on))
+        lf.add_rate_parameter('s0')
+        lf.add_shape_parameter('mu', (-1., 0., 1.))
+        lf.prepare()
+        d = np.zeros(400, dtype=[('x', float), ('source', int)])
+        d['x'] = np.random.default_rng(3).normal(0.2, 1.1, 400)
+        lf.set_data(d)
+        values.append((lf(mu=0.3, s0_rate_multiplier=1.2), lf.ps_interpolator(np.array([0.3])),
+                       lf.anchor_models[(1.0,)].sources[1]._n_events_histogram.histogram))
+    assert values[0][0] == values[1][0] and np.isfinite(values[0][0])
+    np.testing.assert_array_equal(values[0][1], values[1][1])
+    np.testing.assert_array_equal(values[0][2], values[1][2])
+    assert values[0][2].sum() > 90000
+
+
 def test_device_log_accuracy(ctx):
     """The lean logarithm of the per-bin terms against numpy (glibc) over the whole double range:
     <= 1 ulp on normal arguments, library behaviour on 0 / denormal / negative / inf / nan."""

@@ -181,6 +181,36 @@ def test_histdd_matches_numpy_semantics():
     assert h.similar_blank_hist().histogram.sum() == 0
 
 
+def test_histdd_routes_large_unweighted_batches_to_the_binning_service():
+    """Inside `device_histograms(ctx)` Histdd.add hands unweighted batches of at least min_events events to
+    ctx.histogram_events and keeps everything else on numpy.histogramdd; outside nothing is routed."""
+    from blueice_amd.histdd import Histdd, device_histograms
+
+    class Service:
+        calls = []
+
+        def histogram_events(self, edges, cols):
+            self.calls.append(len(cols[0]))
+            return np.histogramdd(np.stack(cols, 1), bins=edges)[0]
+
+    rng = np.random.default_rng(4)
+    edges = [np.linspace(0, 1, 5), np.array([0., 0.2, 1.])]
+    big = [rng.random(500), rng.random(500)]
+    small = [rng.random(20), rng.random(20)]
+    want = Histdd(bins=edges).add(*big).add(*small).add(*big, weights=np.full(500, 2.)).histogram
+    svc = Service()
+    with device_histograms(svc, min_events=100):
+        h = Histdd(bins=edges).add(*big).add(*small).add(*big, weights=np.full(500, 2.))
+        with device_histograms(None):
+            Histdd(bins=edges).add(*big)
+        Histdd(bins=edges).add(*big)
+    Histdd(bins=edges).add(*big)
+    np.testing.assert_array_equal(h.histogram, want)
+    assert svc.calls == [500, 500]
+    with device_histograms(object()):                     # something that cannot bin: ignored
+        np.testing.assert_array_equal(Histdd(bins=edges).add(*big).histogram, Histdd(bins=edges).add(*big).histogram)
+
+
 def test_model_simulate_and_source_rates():
     from blueice_amd import Model
     from blueice_amd.test_helpers import conf_for_test, GaussianMCSource
