@@ -59,7 +59,7 @@ __device__ __forceinline__ double log_core(double x, int k_adjust) {
     const double r = fma(z, e.x, -1.0);
     const double w = fma(kd, kLn2Hi, e.y);         // exact
     const double tail = fma(kd, kLn2Lo, e.z);
-    double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
+    double p = fma(r, -1.0 / 8.0, e.w);            // e.w = 1/7: arrives in a vector register with the table entry
     p = fma(r, p, -1.0 / 6.0);
     p = fma(r, p, 1.0 / 5.0);
     p = fma(r, p, -1.0 / 4.0);
