@@ -1190,6 +1190,72 @@ __global__ __launch_bounds__(kThreads) void k_histogram(const double* __restrict
     atomicAdd(&counts[bin], 1.0);
 }
 
+// ---- unbinned set_data: histogram pdfs evaluated at the events ------------------------------------------------
+// HistogramPdfSource.pdf (blueice/source.py:218-243) for every (anchor, source) row at once.  One thread = one event:
+// the per-axis cell and weights are found once, then the thread walks the template rows (blockIdx.y strides over them).
+//   method 0: density of the bin holding the event -- numpy.searchsorted(edges, x) - 1, clipped (nan sorts last);
+//   method 1: scipy RegularGridInterpolator over the bin centres, its arithmetic: i = largest index with g[i] <= x
+//             (at most n - 2), t = (x - g[i]) / (g[i+1] - g[i]); corners in itertools.product order (axis 0 slowest),
+//             weight = ((1 * w_0) * w_1) ..., value = value + V * weight from 0 -- no contraction (the build sets
+//             -ffp-contract=off), so the bits are scipy's.
+struct ScoreArgs {
+    int k, method;
+    int n_grid[kMaxDim];
+    int grid_off[kMaxDim];
+    int64_t stride[kMaxDim];     // bins (C order) per step along the axis
+};
+
+__global__ __launch_bounds__(kThreads) void k_score_events(const double* __restrict__ coords /*[k][N]*/, int64_t N, ScoreArgs a,
+                                                           const double* __restrict__ grid, const double* __restrict__ rows,
+                                                           int64_t row_stride, int n_rows, double* __restrict__ out,
+                                                           int64_t out_stride) {
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= N) return;
+    int64_t base = 0;
+    double t[kMaxDim];
+    for (int ax = 0; ax < a.k; ++ax) {
+        const double x = coords[(int64_t)ax * N + e];
+        const double* __restrict__ g = grid + a.grid_off[ax];
+        const int n = a.n_grid[ax];
+        int lo = 0, hi = n;
+        if (a.method == 0) {                       // first index with g[idx] >= x  (side = 'left')
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (g[mid] < x) lo = mid + 1; else hi = mid;
+            }
+            if (x != x) lo = n;
+        } else {                                   // first index with g[idx] > x
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (g[mid] <= x) lo = mid + 1; else hi = mid;
+            }
+        }
+        const int i = min(max(lo - 1, 0), n - 2);
+        t[ax] = a.method == 1 ? (x - g[i]) / (g[i + 1] - g[i]) : 0.0;
+        base += i * a.stride[ax];
+    }
+    for (int r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const double* __restrict__ src = rows + (int64_t)r * row_stride + base;
+        double value;
+        if (a.method == 0) {
+            value = src[0];
+        } else {
+            value = 0.0;
+            for (int corner = 0; corner < (1 << a.k); ++corner) {
+                double weight = 1.0;
+                int64_t off = 0;
+                for (int ax = 0; ax < a.k; ++ax) {
+                    const bool up = (corner >> (a.k - 1 - ax)) & 1;
+                    weight = weight * (up ? t[ax] : 1.0 - t[ax]);
+                    if (up) off += a.stride[ax];
+                }
+                value = value + src[off] * weight;
+            }
+        }
+        out[(int64_t)r * out_stride + e] = value;
+    }
+}
+
 // densify one dataset from its non-empty-bin list
 __global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __restrict__ n, int64_t nnz,
                                double* __restrict__ out) {

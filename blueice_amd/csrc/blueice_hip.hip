@@ -1154,6 +1154,69 @@ int bi_set_unbinned(bi_ctx* c, double outlier_likelihood) {
     return BI_OK;
 }
 
+int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_grid, const double* grid, int64_t N,
+                    const double* coords, double outlier_likelihood) {
+    if (!c) return BI_ERR_INVALID;
+    if (!tp || tp == c) return fail(c, BI_ERR_INVALID, "need a templates context different from the target");
+    if (c->pending || tp->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding: call bi_eval_end first");
+    if (!tp->model_ready) return fail(c, BI_ERR_STATE, "the templates context holds no model");
+    if (tp->device != c->device) return fail(c, BI_ERR_INVALID, "templates and target live on different devices");
+    if (tp->bb_source >= 0) return fail(c, BI_ERR_INVALID, "Beeston-Barlow applies to binned likelihoods only");
+    if (method != 0 && method != 1) return fail(c, BI_ERR_INVALID, "method must be 0 (piecewise) or 1 (linear)");
+    if (k < 1 || k > kMaxDim || !n_grid || !grid) return fail(c, BI_ERR_INVALID, "need 1..%d axes with grid values", kMaxDim);
+    if (N < 0 || (N > 0 && !coords)) return fail(c, BI_ERR_INVALID, "bad N / coords");
+    ScoreArgs a{};
+    a.k = k;
+    a.method = method;
+    int64_t bins = 1;
+    int off = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n_grid[i] < 2) return fail(c, BI_ERR_INVALID, "axis %d needs at least two grid values", i);
+        for (int j = 1; j < n_grid[i]; ++j)
+            if (!(grid[off + j] > grid[off + j - 1])) return fail(c, BI_ERR_INVALID, "grid values of axis %d are not strictly ascending", i);
+        a.n_grid[i] = n_grid[i];
+        a.grid_off[i] = off;
+        off += n_grid[i];
+        bins *= method == 0 ? n_grid[i] - 1 : n_grid[i];
+    }
+    if (bins != tp->B) return fail(c, BI_ERR_INVALID, "the grid describes %lld bins, the templates have %lld", (long long)bins, (long long)tp->B);
+    int64_t step = 1;
+    for (int i = k - 1; i >= 0; --i) { a.stride[i] = step; step *= method == 0 ? n_grid[i] - 1 : n_grid[i]; }
+    // the target becomes a model on the same anchor grid with one "bin" per event
+    std::vector<int32_t> na(tp->n_anchor.begin(), tp->n_anchor.end());
+    std::vector<double> az;
+    for (int i = 0; i < tp->d; ++i) az.insert(az.end(), tp->grid[(size_t)i].begin(), tp->grid[(size_t)i].end());
+    int rc = bi_model_begin(c, tp->d, na.data(), az.data(), tp->S, N, -1);
+    if (rc) return rc;
+    if (N > 0) {
+        DevBuf d_ev, d_grid;
+        if ((rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double)))) {
+            dev_free(d_ev); dev_free(d_grid);
+            return rc;
+        }
+        hipError_t e = hipMemcpyAsync(d_ev.p, coords, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_grid.p, grid, (size_t)off * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(tp->stream);            // whatever filled the templates is complete
+        if (e == hipSuccess) {
+            const int n_rows = (int)(tp->A * tp->S);
+            const unsigned bx = (unsigned)((N + kThreads - 1) / kThreads);
+            const unsigned by = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)c->prop.multiProcessorCount * 8 / bx));
+            hipLaunchKernelGGL(k_score_events, dim3(bx, by), dim3(kThreads), 0, c->stream, (const double*)d_ev.p, N, a,
+                               (const double*)d_grid.p, (const double*)tp->ps.p, tp->Bp, n_rows, (double*)c->ps.p, c->Bp);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);              // coords are borrowed for the call only
+        else (void)hipStreamSynchronize(c->stream);
+        dev_free(d_ev); dev_free(d_grid);
+        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_score_events: %s", hipGetErrorString(e));
+    }
+    c->h_mus = tp->h_mus;
+    std::fill(c->anchor_set.begin(), c->anchor_set.end(), 1);
+    if ((rc = bi_model_end(c))) return rc;
+    c->allow_neg = tp->allow_neg;
+    return bi_set_unbinned(c, outlier_likelihood);
+}
+
 // ---- compatibility mode --------------------------------------------------------------------
 
 int bi_interpolate(bi_ctx* c, int which, const double* z, double* out) {

@@ -183,6 +183,23 @@ class DeviceContext:
                                                   ptr(counts)))
         return counts
 
+    def score_events(self, target, method, grid, coords, outlier_likelihood=1e-12):
+        """This context holds density histograms as its model rows: evaluate all of them at the events and make the
+        result the (unbinned) model of `target` -- `Model.score_events` for every anchor, on the device.
+        method 'piecewise' (grid = bin edges per axis) or 'linear' (grid = bin centres per axis; coords clipped to
+        them and finite)."""
+        code = {'piecewise': 0, 'linear': 1}[method]
+        grid = [np.ascontiguousarray(g, dtype=np.float64) for g in grid]
+        cols = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64).ravel() for c in coords]))
+        if cols.shape[0] != len(grid):
+            raise ValueError("need %d coordinate arrays" % len(grid))
+        n_grid = np.array([len(g) for g in grid], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(grid))
+        target._check(self._lib.bi_score_events(self._h, target._h, code, len(grid), ptr(n_grid), ptr(flat), cols.shape[1],
+                                                ptr(cols), float(outlier_likelihood)))
+        target.d, target.S, target.B, target.bb_source, target.T = self.d, self.S, int(cols.shape[1]), -1, 1
+        target.anchor_z = self.anchor_z
+
     def set_unbinned(self, outlier_likelihood=1e-12):
         """Treat the uploaded rows as pdf values at the events: extended unbinned likelihood."""
         self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))

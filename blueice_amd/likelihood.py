@@ -722,6 +722,13 @@ class UnbinnedLogLikelihood(DeviceLogLikelihood):
     def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
         super().__init__(pdf_base_config, likelihood_config, **kwargs)
         self.outlier_likelihood = self.config.get('outlier_likelihood', 1e-12)
+        self._templates = None            # DeviceContext holding the sources' density histograms, or False: not applicable
+
+    def prepare(self, *args, **kwargs):
+        super().prepare(*args, **kwargs)
+        if self._templates:
+            self._templates[0].close()
+        self._templates = None
 
     def _rows_of(self, model):
         return model.score_events(self._data), None
@@ -729,12 +736,68 @@ class UnbinnedLogLikelihood(DeviceLogLikelihood):
     def _attach_data(self, ctx):
         ctx.set_unbinned(self.outlier_likelihood)
 
+    # -- set_data on the device, when every source's pdf is a histogram -------------------------------------------
+    def _histogram_templates(self):
+        """-> (templates context, method, grid) when every source of every anchor model takes its pdf from a histogram
+        over the model's analysis space through HistogramPdfSource.pdf itself, all with the same interpolation method;
+        None otherwise (analytic pdfs, overridden pdf(), mixed methods): then the events are scored on the host."""
+        from .source import HistogramPdfSource
+        if self._templates is False or not self.config.get('device_scoring', True) or not hasattr(DeviceContext, 'score_events'):
+            return None
+        if self._templates is None:
+            self._templates = False
+            models = list(self.anchor_models.values()) if len(self.shape_parameters) else [self.base_model]
+            sources = {id(s): s for m in models for s in m.sources}.values()
+            edges = [np.asarray(e, dtype=float) for _, e in self.base_model.config['analysis_space']]
+            methods = set()
+            for s in sources:
+                if not isinstance(s, HistogramPdfSource) or type(s).pdf is not HistogramPdfSource.pdf \
+                        or not s.pdf_has_been_computed or s._pdf_histogram is None:
+                    return None
+                he = s._pdf_histogram.bin_edges
+                if len(he) != len(edges) or any(len(a) != len(b) or np.any(a != b) for a, b in zip(he, edges)):
+                    return None
+                methods.add(s.config['pdf_interpolation_method'])
+            if len(methods) != 1 or methods - {'linear', 'piecewise'}:
+                return None
+            method = methods.pop()
+            if method == 'linear' and any(len(e) < 3 for e in edges):
+                return None                      # one bin on an axis: scipy refuses such a grid, let the host say so
+            tp = DeviceContext(self.config.get('device'))
+            S = len(self.source_name_list)
+            n_bins = int(np.prod([len(e) - 1 for e in edges], dtype=np.int64))
+            densities = lambda m: (np.stack([s._pdf_histogram.histogram.ravel() for s in m.sources]), None)
+            if len(self.shape_parameters):
+                self.morpher.stream_to_device(tp, self.anchor_models, S, n_bins, rows_of=densities)
+            else:
+                tp.begin_model([], S, n_bins)
+                tp.set_anchor(0, densities(self.base_model)[0], self.base_model.expected_events())
+                tp.end_model()
+            tp.set_allow_negative([1 if x else 0 for x in self.source_allowed_negative])
+            grid = edges if method == 'piecewise' else [0.5 * (e[:-1] + e[1:]) for e in edges]
+            self._templates = (tp, method, grid)
+        return self._templates
+
     @_needs_preparation
     def set_data(self, d):
+        """Score the events at every anchor model (likelihood.py:531-563).  Sources whose pdf is a histogram are
+        evaluated ON THE DEVICE -- their density histograms are uploaded once, then every set_data sends the event
+        coordinates only and one kernel fills the [anchor][source][event] tensor in HBM (`bi_score_events`); other
+        sources are scored on the host, anchor by anchor, and the tensor is streamed up."""
         LogLikelihoodBase.set_data(self, d)
         self.bin_shape = (len(d),)
         if not len(self.shape_parameters):
             self.ps = self.base_model.score_events(d)
+        coords = [np.asarray(c, dtype=float) for c in self.base_model.to_analysis_dimensions(d)]
+        tpl = self._histogram_templates() if all(np.all(np.isfinite(c)) for c in coords) else None
+        if tpl:
+            tp, method, grid = tpl
+            if method == 'linear':               # constant density in the outer half of the boundary bins (source.py:232-241)
+                coords = [np.clip(c, g[0], g[-1]) for c, g in zip(coords, grid)]
+            if self.ctx is None:
+                self.ctx = DeviceContext(self.config.get('device'))
+            tp.score_events(self.ctx, method, grid, coords, self.outlier_likelihood)
+            return
         self._stream_models(self._rows_of, len(d))
         self.ctx.set_unbinned(self.outlier_likelihood)
 

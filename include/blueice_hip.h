@@ -118,9 +118,25 @@ int bi_histogram_events(bi_ctx* ctx, int k, const int32_t* n_edges /*[k]*/, cons
  *     ll = -sum_s mu_s + sum_events log( sum_s mu_s p_s(x_e) ),
  * events whose summed density is not > 0 get `outlier_likelihood` instead when it is non-zero
  * (config 'outlier_likelihood', default 1e-12, likelihood.py:573,687-689).  No counts are needed;
- * bi_eval / bi_plan_* / bi_interpolate / bi_eval_full work as for the binned case.  pdf values must be
- * finite (the reference's nansum over sources is not reproduced).  B = 0 (no events) is allowed. */
+ * bi_eval / bi_plan_* / bi_interpolate / bi_eval_full work as for the binned case.  A nan pdf value drops that
+ * source's term for that event (numpy.nansum, likelihood.py:686).  B = 0 (no events) is allowed. */
 int bi_set_unbinned(bi_ctx* ctx, double outlier_likelihood);
+
+/* set_data of the unbinned likelihood on the device, for sources whose pdf is a histogram (HistogramPdfSource.pdf,
+ * blueice/source.py:218-243): `templates` holds the DENSITY histograms of every source at every anchor as its model
+ * rows ([A..][S][B], uploaded once like a binned model); this call evaluates all of them at N events and leaves the
+ * result -- the [A..][S][N] tensor `Model.score_events(d)` would have produced anchor by anchor on the host,
+ * likelihood.py:557-560 -- as the model of `target` (same device), copies the expected-event table, and switches
+ * `target` to the unbinned likelihood as bi_set_unbinned does.  Only the k x N event coordinates cross PCIe.
+ *   method 0 'piecewise': the density of the bin the event falls in; `grid` = the bin EDGES of every axis; an event
+ *            on an edge belongs to the bin on its left, events outside take the first / last bin (the lookup of the
+ *            package's Histdd);
+ *   method 1 'linear':    scipy's RegularGridInterpolator over the bin CENTRES (`grid` = the centres of every axis,
+ *            as the host computed them; >= 2 per axis), in its operation order; coords must already be clipped to
+ *            [first centre, last centre] and finite, as source.py:232-241 does.
+ * n_grid[k], grid concatenated; coords [k][N]. */
+int bi_score_events(bi_ctx* templates, bi_ctx* target, int method, int k, const int32_t* n_grid, const double* grid,
+                    int64_t N, const double* coords, double outlier_likelihood);
 
 /* Toy-MC datasets generated on the device: n_{t,b} ~ Poisson(mu_b), mu_b = sum_s r_s p_{s,b}(z) -- the binned
  * equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of events per source, each drawn from

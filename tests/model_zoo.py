@@ -72,7 +72,8 @@ def sample(rng, n, space):
     return d
 
 
-def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=None, bb_floor=False, extra_config=None):
+def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=None, bb_floor=False, extra_config=None,
+             unbinned=False):
     strengths = [1.0, -0.6, 0.45, 1.7, -1.2, 0.8]
     conf = dict(sources=[], default_source_class=morphed_source_class(ns),
                 analysis_space=space, force_recalculation=True, never_save_to_cache=True,
@@ -91,7 +92,7 @@ def morph_lf(ns, rng, S, space, shape_anchors, n_mc, n_data, lc=None, livetime=N
             d = np.concatenate([d, lat])
         conf['sources'].append(dict(name='s%d' % s, events_per_day=40. * (s + 1), data=d,
                                     strength=0.0 if (bb_floor and s == 0) else strengths[s]))
-    lf = ns.BinnedLogLikelihood(conf, likelihood_config=dict(lc) if lc else None)
+    lf = (ns.UnbinnedLogLikelihood if unbinned else ns.BinnedLogLikelihood)(conf, likelihood_config=dict(lc) if lc else None)
     for s in range(S):
         lf.add_rate_parameter('s%d' % s)
     for nm, anchors in shape_anchors.items():
@@ -449,8 +450,30 @@ def unb_nan_pdf(ns):
     return lf, calls, (3,)
 
 
+def unb_mc_hist(ns):
+    """Sources whose pdf is a HISTOGRAM of their own Monte Carlo, read with the default linear interpolation between
+    bin centres (blueice/source.py:218-243): the set_data the device does itself (bi_score_events).  Events on bin
+    centres, on edges, in the outer half of the boundary bins and on the range limits."""
+    np.random.seed(7)
+    rng = np.random.default_rng(71)
+    conf = ns.conf_for_test(n_sources=2, mc=True, events_per_day=30., n_events_for_pdf=int(1e5),
+                            analysis_space=[['x', np.linspace(-6, 6, 49)]],
+                            force_recalculation=True, never_save_to_cache=True)   # no pdf cache: every source draws its own sample
+    conf['sources'] = [dict(name='s0'), dict(name='s1', mu=1.0, sigma=1.8, events_per_day=12.)]
+    lf = ns.UnbinnedLogLikelihood(conf)
+    lf.add_rate_parameter('s0')
+    lf.add_rate_parameter('s1')
+    lf.add_shape_parameter('mu', (-1., 0., 1.5))
+    lf.prepare()
+    xs = np.concatenate([rng.normal(0.2, 1.2, 40), [-6., 6., -5.9, 5.95, 0.125, 0.25, -0.375, 3.0]])
+    lf.set_data(_events(xs))
+    calls = [{}, dict(mu=-1.), dict(mu=1.5), dict(mu=0.6), dict(mu=-0.45, s0_rate_multiplier=1.3, s1_rate_multiplier=0.5),
+             dict(mu=1.1, s1_rate_multiplier=0.)]
+    return lf, calls, (3,)
+
+
 UNBINNED_CASES = OrderedDict((f.__name__, f) for f in (unb_ref_value, unb_shape_2src, unb_d0_three_sources, unb_no_events,
-                                                       unb_nan_pdf))
+                                                       unb_nan_pdf, unb_mc_hist))
 
 
 # ---------------------------------------------------------------------------------------------

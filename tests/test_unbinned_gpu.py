@@ -57,6 +57,64 @@ def test_unbinned_likelihood_class_matches_reference(ns, name):
         np.testing.assert_array_equal(ps, c['raw']['full_%d_ps' % j])
 
 
+@pytest.mark.parametrize('dims,method,shapes', [(1, 'linear', 1), (1, 'piecewise', 2), (2, 'linear', 2), (3, 'linear', 1),
+                                                (3, 'piecewise', 0), (2, 'linear', 0)])
+def test_events_scored_on_the_device_equal_host_scoring(ns, dims, method, shapes):
+    """set_data of the unbinned likelihood for histogram-pdf sources (bi_score_events) against the host route
+    (Model.score_events anchor by anchor, HistogramPdfSource.pdf = blueice/source.py:218-243): the same
+    [anchor][source][event] tensor and the same likelihood.  Events on bin centres / edges / range limits included.
+    Two-dimensional linear interpolation: scipy evaluates 2-D scalar fields with a separate routine that associates the
+    products differently, so there the agreement is to rounding, elsewhere to the bit."""
+    from collections import OrderedDict
+    space = [['x', np.linspace(-4, 4, 17)], ['y', np.array([0., 0.4, 1., 2.2, 3.5, 5.])], ['w', np.linspace(-1, 1, 6)]][:dims]
+    anchors = OrderedDict(list(OrderedDict(shift=(-1., 0., 1.), stretch=(0., 0.5, 1.)).items())[:shapes])
+    out = []
+    for on_device in (True, False):
+        rng = np.random.default_rng(90 + dims)
+        lf = model_zoo.morph_lf(ns, rng, 3, space, anchors, 4000, 150, unbinned=True,
+                                lc=dict(device_scoring=on_device), extra_config=dict(pdf_interpolation_method=method))
+        d = model_zoo.sample(rng, 200, space)
+        for nm, e in space:                                  # special places: limits, an inner edge, a bin centre
+            d[nm][:4] = [e[0], e[-1], e[2], 0.5 * (e[1] + e[2])]
+        lf.set_data(d)
+        assert (lf._templates not in (None, False)) == on_device
+        calls = [{}, dict(s0_rate_multiplier=1.4, s2_rate_multiplier=0.3)]
+        if shapes:
+            calls += [dict(shift=0.35), dict(shift=-1., s1_rate_multiplier=0.)]
+        if shapes > 1:
+            calls += [dict(shift=0.6, stretch=0.8)]
+        z = np.array([0.35, 0.8][:shapes])
+        out.append(([lf(**kw) for kw in calls], lf.ps_interpolator(z) if shapes else lf(full_output=True)[2]))
+        lf.set_data(d[:37])                                  # a second dataset re-uses the templates on the device
+        out[-1] += (lf(),)
+    (ll_dev, ps_dev, ll2_dev), (ll_host, ps_host, ll2_host) = out
+    assert ps_dev.shape == ps_host.shape and np.all(np.isfinite(ps_dev)) and ps_dev.max() > 0
+    if dims == 2 and method == 'linear':
+        np.testing.assert_allclose(ps_dev, ps_host, rtol=1e-14, atol=0)
+    else:
+        np.testing.assert_array_equal(ps_dev, ps_host)
+    for a, b in zip(ll_dev + [ll2_dev], ll_host + [ll2_host]):
+        assert same(a, b, 1e-13), (a, b)
+
+
+def test_device_scoring_is_skipped_where_it_does_not_apply(ns):
+    """Analytic pdfs, overridden pdf() and non-finite event coordinates take the host route."""
+    lf = ns.UnbinnedLogLikelihood(ns.conf_for_test(events_per_day=3.))          # GaussianSource: analytic pdf
+    lf.add_shape_parameter('some_multiplier', (0.5, 1, 2))
+    lf.prepare()
+    lf.set_data(model_zoo._events([0.1, -0.4, 2.]))
+    assert lf._templates is False and np.isfinite(lf())
+    conf = ns.conf_for_test(mc=True, n_events_for_pdf=20000, events_per_day=3.)  # histogram pdf: device
+    lf = ns.UnbinnedLogLikelihood(conf)
+    lf.add_shape_parameter('mu', (-1., 0., 1.))
+    lf.prepare()
+    lf.set_data(model_zoo._events([0.1, -0.4, 2.]))
+    assert lf._templates not in (None, False)
+    value = lf(mu=0.3)
+    lf.prepare()                                                                 # a new prepare() drops the templates
+    assert lf._templates is None
+
+
 def test_reference_unbinned_tests_closed_forms(ns):
     """test_likelihood_value, test_rate_uncertainty, test_shape_uncertainty, test_multisource_likelihood,
     test_livetime_scaling, test_error_handling of the reference's tests/test_likelihood.py, restated."""
