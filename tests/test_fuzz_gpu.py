@@ -456,3 +456,75 @@ def test_likelihood_api_random_calls_match_oracle_plus_priors(seed):
         tot = LogLikelihoodSum([lf, lf], likelihood_weights=[1, 0.5])      # same context twice: the sequential form
         kw = plain[0][0]
         assert tot(**kw) == lf(**kw) + 0.5 * lf(**kw)
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(8))
+def test_fuzz_event_scoring(seed):
+    """bi_score_events (unbinned set_data on the device) against scipy's RegularGridInterpolator over the bin centres /
+    the bin lookup of the package's Histdd: random numbers of axes, sources, anchors, non-uniform edges, events on
+    centres, edges and range limits.  The interpolating method is held to the bit wherever scipy takes its general
+    routine (not 2 axes); the likelihood built from the scored tensor is compared with the oracle's."""
+    from scipy.interpolate import RegularGridInterpolator
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.histdd import Histdd
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.integers(1, 4))
+    S = int(rng.integers(1, 4))
+    d = int(rng.integers(0, 3))
+    method = 'linear' if rng.random() < 0.6 else 'piecewise'
+    edges = [np.sort(rng.uniform(-3, 3, int(rng.integers(3, 8)))) for _ in range(k)]
+    edges = [e + 1e-3 * np.arange(len(e)) for e in edges]                     # strictly ascending
+    shape = tuple(len(e) - 1 for e in edges)
+    B = int(np.prod(shape))
+    anchor_z = [np.sort(rng.uniform(-2, 2, int(rng.integers(2, 4)))) + 1e-3 * np.arange(1) for _ in range(d)]
+    anchor_z = [np.unique(g) for g in anchor_z]
+    if any(len(g) < 2 for g in anchor_z):
+        anchor_z = [np.array([-1., 0.5, 1.25])[:max(2, len(g))] for g in anchor_z]
+    A = int(np.prod([len(g) for g in anchor_z])) if d else 1
+    dens = rng.random((A, S) + shape) ** 2
+    dens[rng.random(dens.shape) < 0.1] = 0.0
+    mus = rng.uniform(1, 30, (A, S))
+    N = int(rng.integers(1, 300))
+    cols = [rng.uniform(e[0], e[-1], N) for e in edges]
+    for ax, e in enumerate(edges):                                             # limits, an inner edge, a bin centre
+        special = np.array([e[0], e[-1], e[1], 0.5 * (e[0] + e[1]), 0.5 * (e[-2] + e[-1])])[:N]
+        cols[ax][:len(special)] = special
+    centres = [0.5 * (e[:-1] + e[1:]) for e in edges]
+    grid = edges if method == 'piecewise' else centres
+    pts = cols if method == 'piecewise' else [np.clip(c, g[0], g[-1]) for c, g in zip(cols, grid)]
+    want = np.empty((A, S, N))
+    for a in range(A):
+        for s in range(S):
+            if method == 'linear':
+                want[a, s] = RegularGridInterpolator(centres, dens[a, s])(np.transpose(pts))
+            else:
+                h = Histdd(bins=edges)
+                h.histogram = dens[a, s]
+                want[a, s] = h.lookup(*pts)
+    tp, ctx = DeviceContext(0), DeviceContext(0)
+    try:
+        tp.begin_model(anchor_z, S, B)
+        for a in range(A):
+            tp.set_anchor(a, dens[a].reshape(S, B), mus[a])
+        tp.end_model()
+        outlier = 1e-12
+        tp.score_events(ctx, method, grid, pts, outlier)
+        z = np.array([rng.uniform(g[0], g[-1]) for g in anchor_z])
+        for a, multi in enumerate(np.ndindex(*[len(g) for g in anchor_z])):     # the scored tensor, anchor by anchor
+            za = np.array([g[i] for g, i in zip(anchor_z, multi)])
+            got = ctx.interpolate('ps', za).reshape(S, N)
+            if method == 'linear' and k == 2:
+                np.testing.assert_allclose(got, want[a], rtol=1e-14, atol=1e-300)
+            else:
+                np.testing.assert_array_equal(got, want[a])
+            np.testing.assert_array_equal(ctx.interpolate('mus', za), mus[a])
+        model = dict(anchor_z=anchor_z, ps=want.reshape(tuple(len(g) for g in anchor_z) + (S, N)),
+                     mus=mus.reshape(tuple(len(g) for g in anchor_z) + (S,)))
+        r = rng.uniform(0.2, 2.0, S)
+        ll, st = ctx.eval(z if d else None, r)
+        ref = orc.loglikelihood_unbinned(model, z, r, outlier)
+        assert st[0] == 0 and (ll[0] == ref or abs(ll[0] - ref) <= RTOL * max(1, abs(ref))), (seed, ll[0], ref)
+    finally:
+        tp.close()
+        ctx.close()
