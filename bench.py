@@ -537,6 +537,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(model, counts, (z, r))
         result['cpu_baseline']['host_cores_available'] = os.cpu_count()
+        calls = result.get('extras', {}).get('api_bestfit_scipy_likelihood_calls')
+        if calls:                # the same fit on the host = that many evaluations at the measured single-thread rate
+            result['cpu_baseline']['bestfit_scipy_estimate_s'] = calls / result['cpu_baseline']['value']
+            result['cpu_baseline']['bestfit_scipy_estimate_note'] = (
+                '%d likelihood calls of the device fit (extras.api_bestfit_scipy_s) x the single-thread time per '
+                'evaluation measured above; an estimate, the fit itself is not run on the host' % calls)
         try:
             share = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
             n_procs = max(1, min(16, share))
@@ -664,9 +670,11 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
     lf.set_binned_data(counts.reshape(model.bins))
     fixed = {'s%d_rate_multiplier' % s: 1 for s in range(1, model.S)}
     lf.bestfit_scipy(**fixed)
+    lf.ctx.set_param('single_timing_reset', 1)
     t = time.perf_counter()
     best, ll = lf.bestfit_scipy(**fixed)
     ex['api_bestfit_scipy_s'] = time.perf_counter() - t
+    ex['api_bestfit_scipy_likelihood_calls'] = int(lf.ctx.get_param('single_calls'))
     t = time.perf_counter()
     lf.bestfit_scipy(use_gradient=True, **fixed)
     ex['api_bestfit_scipy_with_gradient_s'] = time.perf_counter() - t
