@@ -126,7 +126,8 @@ struct bi_ctx {
     bool plan_tables_sparse = false;
     int64_t n_valid_launches = 0;                // how often the validity pass of a split scan ran
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
-    int64_t scan_waves_per_cu = 24;              // scan kernel: waves per CU over all cells
+    int64_t last_scan_nslots = 0, last_scan_resident = 0, last_valid_nslots = 0;   // what the planner chose last (read-only parameters)
+    int64_t scan_waves_per_cu = 0;               // scan kernels: 0 = the planner sizes the split by occupancy; > 0 forces that many waves per CU
     int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
     int64_t last_single_cell = -1, last_single_ds = -1;
     int64_t poll_result = 1;                     // single evaluations: poll the pinned result word instead of a stream sync

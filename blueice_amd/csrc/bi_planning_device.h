@@ -10,6 +10,39 @@
 
 namespace {
 
+// Blocks of a matrix-core scan kernel variant that one CU holds at a time (registers decide it), asked from the runtime
+// once per variant: the planner sizes the split of a cell's strips so that the blocks run in full rounds.
+int scan_resident_blocks(bool valid, int cb, int NS) {
+    static std::atomic<int> cache[2][2][4][2];
+    const int kg = NS <= 4 ? 0 : (NS <= 8 ? 1 : (NS <= 16 ? 2 : 3));
+    const int mask = NS == (4 << kg) ? 0 : 1;
+    std::atomic<int>& slot = cache[valid ? 1 : 0][cb == 2 ? 0 : 1][kg][mask];
+    int v = slot.load();
+    if (v > 0) return v;
+    const void* f = nullptr;
+#define BI_PICK(KERNEL, CB)                                                                                        \
+    do {                                                                                                           \
+        switch (kg * 2 + mask) {                                                                                   \
+            case 0: f = (const void*)KERNEL<CB, 1, false>; break;                                                  \
+            case 1: f = (const void*)KERNEL<CB, 1, true>; break;                                                   \
+            case 2: f = (const void*)KERNEL<CB, 2, false>; break;                                                  \
+            case 3: f = (const void*)KERNEL<CB, 2, true>; break;                                                   \
+            case 4: f = (const void*)KERNEL<CB, 4, false>; break;                                                  \
+            case 5: f = (const void*)KERNEL<CB, 4, true>; break;                                                   \
+            case 6: f = (const void*)KERNEL<CB, 8, false>; break;                                                  \
+            default: f = (const void*)KERNEL<CB, 8, true>; break;                                                  \
+        }                                                                                                          \
+    } while (0)
+    if (valid) BI_PICK(k_scan_valid, 4);
+    else if (cb == 2) BI_PICK(k_scan_mfma, 2);
+    else BI_PICK(k_scan_mfma, 4);
+#undef BI_PICK
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, kThreads, 0) != hipSuccess || blocks < 1) blocks = 2;
+    slot.store(blocks);
+    return blocks;
+}
+
 constexpr int kDevG = 16;   // every device-planned work item has 16 slots (the last of a group is padded)
 
 struct PlanMeta {
@@ -369,23 +402,47 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                                (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p);
             return BI_OK;
         };
-        // scan_waves_per_cu waves per CU over all groups, evened out so that every wave gets the same number of
-        // strips (a block lasts as long as its busiest wave)
-        auto waves_per_group = [&](int64_t strips, int64_t waves_per_cu) -> int64_t {
-            int64_t blocks = std::max<int64_t>(1, (waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
-            blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, strips / 4));
-            const int64_t per_wave = (strips + 4 * blocks - 1) / (4 * blocks);
-            blocks = (strips + 4 * per_wave - 1) / (4 * per_wave);
-            return blocks * 4;
+        // A group's strips are spread over W = 4 b waves (b blocks); a block lasts as long as its busiest wave, ceil(strips / W)
+        // strips, and the blocks of all groups run in ceil(b * n_groups / resident blocks) rounds -- the last of which is
+        // as long as the others however few blocks it holds.  Choose b for the smallest rounds x strips-per-wave (ties: the
+        // fewer waves): at C2 the 320 compacted strips of a cell go to 12 blocks of 7 strips in ONE round instead of 20 blocks
+        // of 4 strips in two, dense data gets 8 full rounds instead of 2.7.  `resident` = blocks of that kernel variant a CU
+        // holds (asked from the runtime); slot_cap bounds the waves where every wave owns a partial slot per item.
+        auto waves_per_group = [&](int64_t strips, int resident, int64_t slot_cap) -> int64_t {
+            const int64_t capacity = (int64_t)c->prop.multiProcessorCount * std::max(1, resident);
+            const int64_t b_max = std::max<int64_t>(1, std::min<int64_t>(strips / 4, slot_cap / 4));
+            if (c->scan_waves_per_cu > 0) {      // forced (tuning): that many waves per CU over all groups, evened out
+                int64_t blocks = std::max<int64_t>(1, (c->scan_waves_per_cu * c->prop.multiProcessorCount + 4 * n_groups - 1) / (4 * n_groups));
+                blocks = std::min<int64_t>(blocks, b_max);
+                const int64_t per_wave = (strips + 4 * blocks - 1) / (4 * blocks);
+                return (strips + 4 * per_wave - 1) / (4 * per_wave) * 4;
+            }
+            auto cost_of = [&](int64_t b) -> double {
+                const int64_t per_wave = (strips + 4 * b - 1) / (4 * b);
+                if ((strips + 4 * per_wave - 1) / (4 * per_wave) != b) return 1e300;          // not an evened-out split
+                return (double)((b * n_groups + capacity - 1) / capacity) * (double)per_wave;
+            };
+            double best_cost = 1e300;
+            int64_t best_b = 1;
+            for (int64_t b = 1; b <= b_max; ++b)
+                if (cost_of(b) < best_cost) { best_cost = cost_of(b); best_b = b; }
+            // Among the splits within 1 % of the best take the FINEST that still leaves a wave 8 strips per item list:
+            // the blocks of one cell are dispatched together, so many short rounds keep few cells -- and their
+            // coefficient lists -- in flight at a time (L2), where one long round has every cell's list streaming at
+            // once (measured at C2, dense data: 598 k evaluations/s with 8 rounds of 96 blocks per cell against 539 k
+            // with one round of 12); below ~8 strips per wave the re-read of the coefficient lists by every wave shows.
+            for (int64_t b = b_max; b > best_b; --b)
+                if (cost_of(b) <= 1.01 * best_cost && (strips + 4 * b - 1) / (4 * b) >= 8) { best_b = b; break; }
+            return best_b * 4;
         };
         if (split) {
             if ((rc = group_tables()) || (rc = dev_alloc(c, plan->bad, ni * kDevG * sizeof(unsigned)))) return abort_plan(rc);
             plan->valid = true;
             plan->n_groups = n_groups;
             plan->scan_cb = 4;
-            // (four times the waves of the non-empty-bin pass: the finer the split, the shorter the last, partly filled
-            // round of blocks -- +1.7 % at C2, tools/tune_scan_waves.py; the pass keeps no per-wave partial sums)
-            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), c->scan_waves_per_cu * 4);
+            plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), scan_resident_blocks(true, 4, NS),
+                                                      (int64_t)1 << 40);       // (the pass keeps no per-wave partial sums)
+            c->last_valid_nslots = plan->valid_nslots;
             plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
             plan->launches += 1;
             e = hipStreamSynchronize(c->stream);
@@ -399,16 +456,11 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->use_scan = true;
             plan->scan_cb = cb;
             plan->n_groups = n_groups;
-            // Dense data: four times the waves -- a block of this kernel lasts long (a logarithm per matrix element) and
-            // only three waves per SIMD are resident, so the last round of blocks is a visible tail: 571 k instead of
-            // 531 k evaluations/s at C2 with 96 instead of 32 waves per CU (tools/tune_scan_waves.py).  Every wave owns
-            // one partial slot per item, so the split is bounded by the memory the slots may take (1 GiB).
-            int64_t wpc = (mostly_empty || sparse) ? c->scan_waves_per_cu : c->scan_waves_per_cu * 4;
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), wpc);
-            while (wpc > c->scan_waves_per_cu && (int64_t)ni * k.nbx * kDevG * (int64_t)sizeof(double) > ((int64_t)1 << 30)) {
-                wpc = std::max<int64_t>(c->scan_waves_per_cu, wpc / 2);
-                k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), wpc);
-            }
+            // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
+            const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), scan_resident_blocks(false, cb, NS), slot_cap);
+            c->last_scan_nslots = k.nbx;
+            c->last_scan_resident = scan_resident_blocks(false, cb, NS);
             dev_free(k.partial);
             dev_free(k.pflags);
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||

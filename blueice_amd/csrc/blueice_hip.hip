@@ -169,7 +169,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_sparse_max_items")) { c->scan_sparse_max_items = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
-    if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 1 ? 1 : v; return BI_OK; }
+    if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
@@ -197,6 +197,9 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "single_ns_launch")) return c->single_ns[1];
     if (!strcmp(name, "single_ns_wait")) return c->single_ns[2];
     if (!strcmp(name, "single_calls")) return c->single_calls;
+    if (!strcmp(name, "last_scan_nslots")) return c->last_scan_nslots;
+    if (!strcmp(name, "last_scan_resident")) return c->last_scan_resident;
+    if (!strcmp(name, "last_valid_nslots")) return c->last_valid_nslots;
     if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
     if (!strcmp(name, "single_blocks_per_cu")) return c->single_blocks_per_cu;
     if (!strcmp(name, "xcd_affine")) return c->xcd_affine;

@@ -265,7 +265,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   xcd_affine        round block counts to multiples of 8
  *   device_plan_min   batches of at least this many points are planned on the device (512)
  *   scan_mfma, scan_min_items, scan_cb, scan_waves_per_cu   the matrix-core scan kernel: on/off, items per cell from
- *                     which it is used (4; x2 for dense data), strip width (0 = by the data), launch width
+ *                     which it is used (4; x2 for dense data), strip width (0 = by the data), waves per CU the
+ *                     strips of all cells are spread over (0 = sized by the kernel's occupancy so that the blocks run in
+ *                     full rounds, default)
  *   bb_exact          single-point Beeston-Barlow evaluations: N(z) = sum_b n_model[i, b] in numpy's own summation order (one more
  *                     pass over the 2^d rows of MC counts), so that the root formula sees the reference's bits: 0 never, 1
  *                     always, 2 when some bin can have U_b == 0 at the point (default)
