@@ -253,6 +253,11 @@ class LogLikelihoodBase:
     def set_data(self, d):
         self._data = d
         self.is_data_set = True
+        for per_source in self.anchor_sources.values():        # scores cached for the previous dataset (_SourceWiseModel)
+            for source in per_source.values():
+                source.__dict__.pop('_blueice_amd_score', None)
+        for source in self.base_model.sources:
+            source.__dict__.pop('_blueice_amd_score', None)
 
     def _compute_single_model(self, **kwargs):
         _, settings = self._kwargs_to_settings(**kwargs)

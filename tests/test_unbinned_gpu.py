@@ -111,6 +111,9 @@ def test_device_scoring_is_skipped_where_it_does_not_apply(ns):
     lf.set_data(model_zoo._events([0.1, -0.4, 2.]))
     assert lf._templates not in (None, False)
     value = lf(mu=0.3)
+    lf.set_data(model_zoo._events([]))                                           # no events at all: ll = -sum of the rates
+    assert lf._templates not in (None, False)
+    assert same(lf(mu=0.3), -float(np.sum(lf.mus_interpolator(np.array([0.3])))), 1e-14) and np.isfinite(value)
     lf.prepare()                                                                 # a new prepare() drops the templates
     assert lf._templates is None
 
