@@ -462,12 +462,9 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             c->last_scan_nslots = k.nbx;
             c->last_scan_resident = scan_resident_blocks(false, cb, NS);
             dev_free(k.partial);
-            dev_free(k.pflags);
-            if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||
-                (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))))
-                return abort_plan(rc);
-            e = hipMemsetAsync(k.pflags.p, 0, ni * k.nbx * kDevG * sizeof(unsigned), c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            dev_free(k.pflags);                     // the scan kernel raises no per-block flags (k_finish_scan reads none)
+            if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double)))) return abort_plan(rc);
+            e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
             plan->launches = 1;
         }

@@ -576,12 +576,9 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
 #undef BI_SCAN_KG
 #undef BI_SCAN
         }
-        const int64_t n_slots = k.n_items * k.G;
-        const int lanes = k.nbx > 64 ? kThreads : 64;
-        const int per_block = kThreads / lanes;
-        hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
-                           (const double*)k.partial.p, (const unsigned*)k.pflags.p, k.nbx, k.G, lanes, n_slots,
-                           (const int64_t*)k.perm.p, (const double*)k.slot_lg.p, out, (int32_t*)plan->status.p);
+        hipLaunchKernelGGL(k_finish_scan, dim3((unsigned)((k.n_items + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0,
+                           c->stream, (const double*)k.partial.p, k.nbx, k.n_items, (const int64_t*)k.perm.p,
+                           (const double*)k.slot_lg.p, out);
     }
     for (auto& k : plan->classes) {
         if (plan->use_scan) break;
