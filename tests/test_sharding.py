@@ -149,6 +149,25 @@ def test_three_socket_ranks(tmp_path):
         assert 11 <= g[3] <= 14
 
 
+def test_eight_socket_ranks(tmp_path):
+    """The driver's largest world size (N = 8) through the rendezvous, the sharded scan, the toy split (5 toys over 8
+    ranks: three ranks get none) and the reductions."""
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    got = _run_ranks(_worker, 'socket', 8, tmp_path)
+    m = SyntheticModel.named('mini3')
+    z, r = m.random_points(37, seed=2)
+    want = orc.loglikelihood_batch(m.dense_model(), m.counts(dense=True), z, r)
+    assert sorted(g[0] for g in got) == list(range(8))
+    assert sum(g[3] for g in got) == 37                       # every point evaluated exactly once
+    for g in got:
+        np.testing.assert_array_equal(g[1], want)
+        assert len(g[2]) == 5
+        np.testing.assert_array_equal(g[4], [7., 0.])
+        np.testing.assert_array_equal(g[5], [255, 0])
+        assert g[6] == b'id-of-rank-0'
+
+
 def _bins_worker(kind, rank, world, port, rdzv, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
