@@ -259,7 +259,7 @@ def toy_leg(ctx, ranks, model, T, steps):
     checked = []
     for t in sorted({spans[(rank + 1) % world][0], spans[(rank + world - 1) % world][1] - 1, T // 2}):
         ctx.set_param('toy_offset', t)
-        ctx.generate_toys(z, r, 1, seed=4242)
+        ctx.generate_toys(z, r, 64, seed=4242)         # 64: the batch size from which the tiled kernel takes the call, as above
         one, _ = ctx.eval_datasets(zk, r)
         assert one[0] == out[t], 'toy %d: %r on this rank, %r gathered' % (t, one[0], out[t])
         checked.append(t)

@@ -99,6 +99,10 @@ struct bi_ctx {
     // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
     bool csr_ready = false, compact_ready = false;
     DevBuf nz_idx, nz_n, nz_off, ps_c, cnt_c;
+    DevBuf tm_entries, tm_off;                // tile-major copy of the non-empty-bin lists (k_dataset_dot_tiled): 4-byte entries, [n_tiles * T + 1] offsets
+    int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
+    bool tm_ok = false;                       // ... and whether every count fits its 19 bits
+    int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
     std::vector<int64_t> h_nz_off;            // [T+1]
     std::vector<int64_t> h_c_off, h_cnt_off;  // [T] element offsets into ps_c / cnt_c
     std::vector<int64_t> h_c_np;              // [T] padded non-empty bins per dataset

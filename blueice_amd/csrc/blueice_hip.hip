@@ -117,7 +117,7 @@ void bi_destroy(bi_ctx* c) {
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     dev_free(c->pack_dev);
-    dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c);
+    dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
     dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum);
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
@@ -169,6 +169,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
     if (!strcmp(name, "scan_sparse_max_items")) { c->scan_sparse_max_items = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
+    if (!strcmp(name, "dot_tiled")) { c->dot_tiled = v != 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
@@ -938,8 +939,50 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     auto cleanup = [&]() { dev_free(d_out); };
     const bool csr = (c->sparse && c->csr_ready) || !c->dense_counts;
     if (csr && !c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
-    const int64_t chunk = csr ? 1048576 : 16384;
-    const int nbx = csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
+    // Non-empty-bin lists with enough entries per (dataset, bin tile): the tiled kernel (log mu staged through LDS, the
+    // lists re-ordered tile by tile once per data upload).
+    const int n_tl = (int)((c->B + kDotTile - 1) / kDotTile);
+    bool tiled = csr && c->dot_tiled && n >= 64 && n_tl >= 4 && c->h_nz_off.size() == (size_t)c->T + 1 &&
+                 c->h_nz_off.back() >= (int64_t)16 * c->T * n_tl && (int64_t)c->T * (n_tl + 1) <= ((int64_t)1 << 28);
+    if (tiled && c->nz_tile_epoch != c->epoch) {
+        const int64_t nnz = c->h_nz_off.back(), cells = (int64_t)n_tl * c->T;
+        DevBuf d_tile, d_cnt, d_tmp, d_bad;
+        auto drop = [&]() { dev_free(d_tile); dev_free(d_cnt); dev_free(d_tmp); dev_free(d_bad); };
+        size_t scan_bytes = 0;
+        (void)rocprim::exclusive_scan(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(cells + 1),
+                                      rocprim::plus<int64_t>(), c->stream);
+        if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
+            (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
+            (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t))) ||
+            (rc = dev_alloc(c, c->tm_entries, (size_t)std::max<int64_t>(nnz, 1) * sizeof(uint32_t)))) {
+            drop();
+            return rc;
+        }
+        hipError_t e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
+        hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                           (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p);
+        hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
+                           n_tl, (int64_t*)d_cnt.p);
+        size_t tb = d_tmp.bytes;
+        if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1),
+                                                         rocprim::plus<int64_t>(), c->stream);
+        hipLaunchKernelGGL(k_tm_scatter, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                           (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
+                           (const int64_t*)c->tm_off.p, (uint32_t*)c->tm_entries.p, (int*)d_bad.p);
+        int bad = 0;
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        else (void)hipStreamSynchronize(c->stream);
+        drop();
+        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets (tile-major lists): %s", hipGetErrorString(e));
+        c->tm_ok = bad == 0;
+        if (!c->tm_ok) { dev_free(c->tm_entries); dev_free(c->tm_off); }
+        c->nz_tile_epoch = c->epoch;
+    }
+    tiled = tiled && c->tm_ok;
+    const int64_t chunk = tiled ? std::max<int64_t>(64, ((int64_t)1 << 27) / n_tl) : (csr ? 1048576 : 16384);
+    const int nbx = tiled ? n_tl : csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
     // descriptors in one packed copy; up to 4 MB of results are written straight into pinned host memory
     const bool host_out = !out_dev && (size_t)n * sizeof(double) <= ((size_t)4 << 20);
     PackedUpload pu;
@@ -968,7 +1011,13 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
         const int64_t ni = std::min(chunk, n - s0);
         {
             EventScope ev(c);
-            if (csr)
+            if (tiled) {
+                // datasets split over blockIdx.y so that ~4 blocks per CU exist; every block stages its tile once
+                const unsigned by = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ni + 255) / 256, 4 * (int64_t)c->prop.multiProcessorCount / n_tl));      // two resident blocks per CU (64 KB of LDS each): two full rounds
+                hipLaunchKernelGGL(k_dataset_dot_tiled, dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
+                                   (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
+                                   (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
+            } else if (csr)
                 hipLaunchKernelGGL(k_dataset_dot_csr, dim3((unsigned)ni), dim3(kThreads), 0, c->stream,
                                    (const int32_t*)c->nz_idx.p, (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p,
                                    (const double*)c->logmu.p, t0 + s0, (double*)c->scratch2.p);

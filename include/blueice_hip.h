@@ -271,6 +271,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   bb_exact          single-point Beeston-Barlow evaluations: N(z) = sum_b n_model[i, b] in numpy's own summation order (one more
  *                     pass over the 2^d rows of MC counts), so that the root formula sees the reference's bits: 0 never, 1
  *                     always, 2 when some bin can have U_b == 0 at the point (default)
+ *   dot_tiled         bi_eval_datasets over non-empty-bin lists: batches of >= 64 datasets take the kernel that stages bin tiles
+ *                     of log mu in LDS over tile-major lists (1, default); 0 = always one block per dataset
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows
  *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
  *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)

@@ -109,6 +109,15 @@ def test_c3_ten_thousand_toys(c2):
     assert ctx.eval_datasets_device(buf.ptr, z_eval, r) == 0
     np.testing.assert_array_equal(buf.to_host(), ll)           # results left in HBM for the gather: same numbers
     buf.free()
+    # the call above ran the tiled kernel (bin tiles of log mu staged through LDS over the tile-major lists); the row
+    # kernel (one block per dataset gathering from the 8 MB table) must give the same sums in another order, and ranges
+    # of datasets must be the same numbers as the whole
+    ctx.set_param('dot_tiled', 0)
+    rows, _ = ctx.eval_datasets(z_eval, r)
+    ctx.set_param('dot_tiled', 1)
+    np.testing.assert_allclose(rows, ll, rtol=1e-13, atol=0)
+    part, _ = ctx.eval_datasets(z_eval, r, 2500, 7800)
+    np.testing.assert_array_equal(part, ll[2500:7800])
     # (the per-dataset POINT form needs compacted templates: 41 MB per toy, beyond the budget at 10^4 toys -- it is
     # covered at T = 48 in test_fullsize_gpu.py::test_c3_toy_batch; here the library must say so, not guess)
     from blueice_amd.exceptions import NotPreparedException

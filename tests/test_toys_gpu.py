@@ -98,3 +98,51 @@ def test_simulate_toys_through_the_likelihood_class():
     # the truth should, on average, be favoured over a displaced hypothesis
     other = lf.eval_toys(shift=-0.8, stretch=0.7, tilt=-0.5, s1_rate_multiplier=0.5)
     assert np.mean(ll - other) > 0
+
+
+def test_uploaded_dataset_batches_tiled_and_row_kernels():
+    """bi_eval_datasets over UPLOADED sparse datasets large enough for the tiled kernel (bin tiles of log mu staged through
+    LDS over tile-major 4-byte entries): every dataset against the oracle; a count beyond the 19 bits of an entry, a
+    non-integer and a nan count send the whole batch back to the row kernel, with scipy's values for those datasets."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel(2, (3,), (64, 32, 32), seed=5)                 # 65 536 bins = 8 tiles
+    ctx = DeviceContext(0)
+    try:
+        m.upload(ctx)
+        rng = np.random.default_rng(6)
+        T, B = 80, m.B
+        counts = np.zeros((T, B))
+        for t in range(T):
+            hit = rng.choice(B, size=int(rng.integers(1500, 3000)), replace=False)
+            counts[t, hit] = rng.integers(1, 6, size=len(hit))
+        counts[7, :] = 0                                              # an empty dataset in the middle
+        counts[11, 123] = 524287.                                     # the largest count an entry holds
+        z, r = m.random_points(1, seed=3)
+        z, r = z[0], r[0]
+        dense = m.dense_model()
+        ctx.set_param('sparse', 1)
+        ctx.upload_counts(counts)
+        ll, st = ctx.eval_datasets(z, r)
+        assert st == 0
+        for t in (0, 7, 11, 40, T - 1):
+            want = orc.loglikelihood(dense, counts[t], z, r)
+            assert abs(ll[t] - want) <= 1e-10 * max(1.0, abs(want)), (t, ll[t], want)
+        ctx.set_param('dot_tiled', 0)
+        rows, _ = ctx.eval_datasets(z, r)
+        ctx.set_param('dot_tiled', 1)
+        np.testing.assert_allclose(rows, ll, rtol=1e-13, atol=0)
+        counts[11, 123] = 524288.                                     # one more: does not fit
+        counts[12, 77] = 2.5                                          # scipy: -inf
+        counts[13, 5] = np.nan                                        # scipy: nan
+        ctx.upload_counts(counts)
+        ll2, st = ctx.eval_datasets(z, r)
+        assert ll2[12] == -np.inf and np.isnan(ll2[13])
+        want = orc.loglikelihood(dense, counts[11], z, r)
+        assert abs(ll2[11] - want) <= 1e-10 * abs(want)
+        keep = np.ones(T, bool)
+        keep[[11, 12, 13]] = False
+        np.testing.assert_array_equal(ll2[keep], rows[keep])          # the row kernel again: same bits as before
+    finally:
+        ctx.close()
