@@ -146,3 +146,40 @@ def test_uploaded_dataset_batches_tiled_and_row_kernels():
         np.testing.assert_array_equal(ll2[keep], rows[keep])          # the row kernel again: same bits as before
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_tiled_dataset_kernel_random_shapes(seed):
+    """The tiled kernel against the row kernel over random bin counts (last tile partial), dataset counts, fill levels,
+    empty datasets, datasets living in a single tile, and sub-ranges of datasets."""
+    from blueice_amd.device import DeviceContext
+    rng = np.random.default_rng(700 + seed)
+    B = int(rng.integers(4 * 8192, 9 * 8192)) + int(rng.integers(0, 5000))
+    T = int(rng.integers(64, 160))
+    mu = rng.random(B) ** 2 * 3 + 0.05
+    ctx = make_ctx(mu)
+    try:
+        counts = np.zeros((T, B))
+        for t in range(T):
+            k = int(rng.integers(3000, 9000))
+            hit = rng.choice(B, size=k, replace=False)
+            counts[t, hit] = rng.integers(1, 40, size=k)
+        counts[int(rng.integers(T))] = 0
+        one_tile = int(rng.integers(T))
+        counts[one_tile] = 0
+        counts[one_tile, 8192 * 2 + rng.choice(8192, 500, replace=False)] = 3
+        ctx.set_param('sparse', 1)
+        ctx.upload_counts(counts)
+        tiled, st = ctx.eval_datasets(None, [1.3])
+        assert st == 0 and np.all(np.isfinite(tiled))
+        ctx.set_param('dot_tiled', 0)
+        rows, _ = ctx.eval_datasets(None, [1.3])
+        ctx.set_param('dot_tiled', 1)
+        np.testing.assert_allclose(tiled, rows, rtol=1e-13, atol=0)
+        lo, hi = sorted(rng.choice(T - 64, 2, replace=False))
+        part, _ = ctx.eval_datasets(None, [1.3], int(lo), int(hi) + 64)
+        np.testing.assert_array_equal(part, tiled[lo:hi + 64])
+        want = np.array([np.sum(stats.poisson(1.3 * mu).logpmf(counts[t])) for t in (0, one_tile, T - 1)])
+        np.testing.assert_allclose(tiled[[0, one_tile, T - 1]], want, rtol=1e-10)
+    finally:
+        ctx.close()
