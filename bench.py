@@ -182,11 +182,14 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     send, _ = ranks.buffers(n_max)
     send.from_host(np.zeros(n_max))
 
+    moved = [0]
+
     def step(w):
         # host buffers in -> full result vector on every rank: H2D of the points, device planning, kernels, gather, assembly
         z, r, deal, z_mine, r_mine = w
         plan = ctx.plan(z_mine, r_mine) if len(z_mine) else None
         if plan is not None:
+            moved[0] = plan.bytes                     # bytes the launches of this rank's share stream (work items x rows)
             plan.run(send.ptr)
         parts = ranks.gather(n_max)
         out = np.empty(len(z))
@@ -216,7 +219,7 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     share = [len(d) for d in work[-1][2]]
     return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
                 ms_per_step=elapsed / steps * 1e3, points_per_rank_min_max=[min(share), max(share)],
-                sample_max_rel_diff_vs_single_point_kernel=worst, gather=ranks.kind)
+                sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(moved[0]), gather=ranks.kind)
 
 
 def toy_leg(ctx, ranks, model, T, steps):
@@ -236,6 +239,7 @@ def toy_leg(ctx, ranks, model, T, steps):
     tg = time.perf_counter()
     ctx.generate_toys(z, r, t1_ - t0_, seed=4242)
     gen_s = ranks.max_over_ranks(time.perf_counter() - tg)
+    nnz = int(ctx.get_param('nnz_total'))              # non-empty bins over this rank's datasets
     n_max = max(b - a for a, b in spans)
     send, _ = ranks.buffers(n_max)
     send.from_host(np.zeros(n_max))
@@ -267,7 +271,7 @@ def toy_leg(ctx, ranks, model, T, steps):
     return dict(workload='C3: 10^4 toy datasets (drawn on the device), one parameter point per call, datasets split '
                          'by range over the ranks', scaling='strong', datasets=T, steps=steps, value=T * steps / elapsed,
                 unit='evals/s', ms_per_step=elapsed / steps * 1e3, generate_s=gen_s, toys_rechecked_bitwise=checked,
-                gather=ranks.kind)
+                nonempty_bins_this_rank=nnz, gather=ranks.kind)
 
 
 def bb_leg(ctx_dev, steps=24):
@@ -374,10 +378,34 @@ def main():
                            '%s: Beeston-Barlow, 6 sources, %s anchors, 50^4 bins; 256 points dealt by grid cell' % (
                                args.config, 'x'.join(str(n) for n in model.n_anchor)), sample=1)
             metric = 'Beeston-Barlow likelihood evals/sec, 6-src 50^4-bin model, ' + args.config
+        # what bounds the leg, over the WHOLE step (planning, kernels, gather): algorithmic work / step time
+        step_s = leg['ms_per_step'] * 1e-3
+        if args.config in ('C4', 'C4-dense'):
+            bins = model.B if args.config == 'C4-dense' else ctx.get_param('nnz_total')
+            tf = 2.0 * (2 ** model.d * model.S) * bins * leg['points'] / step_s / 1e12
+            roof = dict(bound='mfma', unit='TFLOP/s', peak=FP64_PEAK_TFLOPS, achieved=tf, frac=tf / FP64_PEAK_TFLOPS, traffic=None,
+                        note='fp64 FMA work of the morph (2 * 2^d*S flop per visited bin and point; %d bins visited per point) '
+                             'over the whole step; the per-bin logarithm on the vector ALU shares the fp64 units and does '
+                             'not overlap with the MFMAs (DESIGN.md section 4)' % bins)
+        elif args.config == 'C3':
+            nbytes = 8.0 * (2 ** model.d * model.S) * model.B + 4.0 * leg['nonempty_bins_this_rank']
+            gbs = nbytes / step_s / 1e9
+            roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, achieved=gbs, frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        note='algorithmic bytes of a call: the 2^d*S template rows once (log mu) + 4 bytes per non-empty bin '
+                             'of every dataset; the call is short (0.3 ms, three launches) and its gather runs out of LDS, '
+                             'so the fraction of the HBM peak is small by construction')
+        else:
+            gbs = leg['streamed_bytes_this_rank'] / step_s / 1e9
+            roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, achieved=gbs, frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        note='bytes the work items of this rank stream (a work item = up to 16 points of one grid '
+                             'cell = one pass over its 2^d * (S + 1) + 1 rows of 50^4 bins) over the whole step; with many points '
+                             'per cell the Beeston-Barlow arithmetic per bin and point (root formula, logarithm) on the fp64 '
+                             'vector ALU takes over from HBM as the bound')
         result = {'metric': metric, 'value': leg['value'], 'unit': 'evals/s', 'n_gpus': world, 'steps': leg['steps'],
                   'warmup': 1, 'ms_per_step': leg['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
                   'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                  'config': {'workload': leg['workload'], 'device': info['arch']}, 'leg': leg, 'cpu_baseline': None}
+                  'config': {'workload': leg['workload'], 'device': info['arch']}, 'roofline': roof, 'leg': leg,
+                  'cpu_baseline': None}
         emit(result)
         ranks.close()
         ctx.close()
