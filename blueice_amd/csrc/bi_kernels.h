@@ -1604,8 +1604,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
                 if (MASK && k >= a.NS) av[kg] = 0.0;
             }
         }
+        // (the item's coefficient block and its partial slot advance by fixed steps: pointers, not products per item)
+        const double* __restrict__ coef_next = a.coef + item0 * a.NS * 16;
+        double* __restrict__ dst = a.partial + (item0 * a.nslots + slot) * 16 + col;
+        const int64_t coef_step = (int64_t)a.NS * 16, dst_step = (int64_t)a.nslots * 16;
         for (int it = 0; it < n_items; ++it) {
-            const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
+            if (it + 1 < n_items) coef_next += coef_step;
             double s[4] = {0.0, 0.0, 0.0, 0.0};      // four chains, one point
             double mn = 0.0;                          // running minimum of mu: a negative expectation makes the result nan
             bi_double4 acc[CB];
@@ -1664,7 +1668,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             double tot = (s[0] + s[1]) + (s[2] + s[3]);
             if (mn < 0.0) tot = __builtin_nan("");
             tot = rows4_sum(tot);                     // over the four DPP rows: the 16 bins of the block are spread 4 r + kq
-            if (kq == 0) unsafeAtomicAdd(a.partial + ((item0 + it) * a.nslots + slot) * 16 + col, tot);
+            if (kq == 0) unsafeAtomicAdd(dst, tot);
+            dst += dst_step;
         }
     }
 }
