@@ -1750,16 +1750,21 @@ __global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
                 if (MASK && k >= a.NS) av[kg] = 0.0;
             }
         }
-        for (int it = 0; it < n_items; ++it) {
-            const double* __restrict__ coef_next = a.coef + (item0 + min(it + 1, n_items - 1)) * a.NS * 16;
-            double an[KG];
+        // The next item's coefficients are requested behind the first chain and arrive under the others; two copies of the
+        // item body alternate the two register sets (no rotation), and the coefficient block / flag words advance as pointers.
+        double an[KG];
+        const double* __restrict__ coef_next = a.coef + item0 * a.NS * 16;
+        unsigned* __restrict__ bad = a.bad + item0 * 16 + kq;
+        const int64_t coef_step = (int64_t)a.NS * 16;
+        auto item = [&](double (&cur)[KG], double (&nxt)[KG], bool more) __attribute__((always_inline)) {
+            if (more) coef_next += coef_step;
             bi_double4 acc[CB];
             unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};      // per r: lanes whose element is not >= 0
 #define BI_VCHAIN(cb)                                                                                              \
     do {                                                                                                           \
         acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
         _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
-            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], b[kg][cb], acc[cb], 0, 0, 0);                   \
+            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[kg], b[kg][cb], acc[cb], 0, 0, 0);                  \
     } while (0)
 #define BI_VCHECK(cb)                                                                                              \
     do {                                                                                                           \
@@ -1769,8 +1774,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 const int k = kg * 4 + kq;
-                an[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) an[kg] = 0.0;
+                nxt[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
+                if (MASK && k >= a.NS) nxt[kg] = 0.0;
             }
 #pragma unroll
             for (int cb = 1; cb < CB; ++cb) {
@@ -1785,12 +1790,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
                 if (col == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((m[r] >> (16 * kq)) & 0xFFFFull) atomicOr(a.bad + (item0 + it) * 16 + kq + 4 * r, 1u);
+                        if ((m[r] >> (16 * kq)) & 0xFFFFull) atomicOr(bad + 4 * r, 1u);
                 }
             }
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = an[kg];
+            bad += 16;
+        };
+        int it = 0;
+        for (; it + 1 < n_items; it += 2) {
+            item(av, an, true);
+            item(an, av, it + 2 < n_items);
         }
+        if (it < n_items) item(av, an, false);
     }
 }
 
