@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
         // (the four kinds of a lane's bins packed into one register, 2 bits each: registers decide the occupancy here)
         int kinds[CB];
-        bool special[CB], alldata[CB];
+        bool special[CB], alldata[CB], ones_twos[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             kinds[cb] = 0;
@@ -1590,6 +1590,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             }
             special[cb] = __ballot(kinds[cb] != 0) != 0ull;       // wave-uniform: does any bin of this block need more
             alldata[cb] = __ballot(kinds[cb] == 0x55) == ~0ull;   // ... every bin holds a count > 0: the logarithm alone decides
+            // ... and every count is 1 or 2 (the non-empty bins of sparse data): sum n log mu = log prod mu^n, and the four
+            // bins of a lane belong to one point, so four logarithms become five multiplications and one logarithm.  The
+            // factors are positive normal numbers (checked per item); a product that leaves that range takes the bin-wise form.
+            bool small = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) small &= n[cb][r] == 1.0 || n[cb][r] == 2.0;
+            ones_twos[cb] = __ballot(small) == ~0ull;
         }
 #define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
 
@@ -1629,6 +1636,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
             if (__ballot(checked) == 0ull) {                                                                       \
+                if (ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
+                    double f[4];                                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                        f[r] = n[cb][r] == 2.0 ? acc[cb][r] * acc[cb][r] : acc[cb][r];                             \
+                    const double prod = (f[0] * f[1]) * (f[2] * f[3]);                                             \
+                    if (__ballot(!pos_normal(prod)) == 0ull) { s[cb & 3] += bin_log_fast(prod); break; }           \
+                }                                                                                                  \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb][r], bin_log_fast(acc[cb][r]), s[r]); \
             } else {                                                                                               \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb][r] * bin_log(acc[cb][r]);              \
