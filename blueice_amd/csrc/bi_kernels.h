@@ -1550,7 +1550,9 @@ __device__ __forceinline__ double rows4_sum(double v) {
 // in-lane additions and two cross-row exchanges per item (rows4_sum: ~10 vector instructions) -- with the operands the
 // other way round (bins along the lanes of a row) it took four 16-lane rotations per accumulator element, ~60
 // instructions per item, a fifth of the kernel's vector work when every bin has data.
-template <int CB, int KG, bool MASK>
+// PROD: the rows are the compacted non-empty bins of sparse data -- blocks whose counts are all 1 or 2 take one logarithm of
+// the product mu^n over a lane's four bins (a separate instantiation, so that the dense-data kernel keeps its code).
+template <int CB, int KG, bool MASK, bool PROD = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
     constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
@@ -1596,7 +1598,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             bool small = true;
 #pragma unroll
             for (int r = 0; r < 4; ++r) small &= n[cb][r] == 1.0 || n[cb][r] == 2.0;
-            ones_twos[cb] = __ballot(small) == ~0ull;
+            ones_twos[cb] = PROD && __ballot(small) == ~0ull;
         }
 #define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
 
@@ -1636,7 +1638,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
             if (__ballot(checked) == 0ull) {                                                                       \
-                if (ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
+                if (PROD && ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
                     double f[4];                                                                                   \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                         f[r] = n[cb][r] == 2.0 ? acc[cb][r] * acc[cb][r] : acc[cb][r];                             \

@@ -566,7 +566,10 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
 #define BI_SCAN(CB, KG)                                                                                           \
     do {                                                                                                          \
-        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+        if (CB == 2 && plan->sparse) { /* compacted rows: the instantiation with the product form of the logarithms */ \
+            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, true>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, true>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
+        } else if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
         else hipLaunchKernelGGL((k_scan_mfma<CB, KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
     } while (0)
 #define BI_SCAN_KG(CB)                                                                                            \
