@@ -177,7 +177,7 @@ def summarize_scan_dense_data(tag, dst, src):
     ktd = os.path.join(src, 'ktd', 'kt_kernel_stats.csv')
     if not (os.path.exists(path) and os.path.exists(ktd)):
         return
-    needle = 'k_scan_mfma<2, 8, false>'
+    needle = 'k_scan_mfma<2, 8, false, false>'
     c, _ = _kernel_counters(path, needle)
     st = _kernel_stats(ktd, needle)
     if not c or not st:
