@@ -1099,7 +1099,7 @@ constexpr int kDotThreads = 1024;
 __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_t* __restrict__ tm_entries,
                                                                    const int64_t* __restrict__ tm_off, int64_t T, int n_tl,
                                                                    const double* __restrict__ logmu, int64_t B, int64_t t0,
-                                                                   int64_t n, double* __restrict__ partial /*[n][n_tl]*/) {
+                                                                   int64_t n, double* __restrict__ partial /*[n_tl][n]*/) {
     __shared__ double s_mu[kDotTile];
     const int tl = blockIdx.x;
     const int64_t bin0 = (int64_t)tl * kDotTile;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
             s += (double)(e >> 13) * s_mu[e & (kDotTile - 1)];
         }
         s = row16_sum(s);
-        if (gl == 0) partial[q * n_tl + tl] = s;
+        if (gl == 0) partial[(int64_t)tl * n + q] = s;
     }
 }
 
@@ -1465,7 +1465,9 @@ __global__ __launch_bounds__(kThreads) void k_dataset_dot(const double* __restri
 
 // out[t] = sum_blocks partial[t][:] - summu - lgsum[t0 + t]   (nan if any mu invalid).  256 threads per block: the
 // block first sums the mu partials of pass 1 together (fixed tree), then every thread finishes one dataset.
-__global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __restrict__ partial, int nbx,
+// (partial[t * t_stride + b * b_stride]: dataset-major from the row kernels, block-major from the tiled one, whose 123
+// partials per dataset would otherwise be read with a stride of 123 doubles between neighbouring threads)
+__global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __restrict__ partial, int nbx, int64_t t_stride, int64_t b_stride,
                                                              const double* __restrict__ mu_partial,
                                                              const unsigned* __restrict__ mu_flags, int nmu,
                                                              const double* __restrict__ lgsum, int64_t t0, int64_t n,
@@ -1486,7 +1488,7 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __res
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (t >= n) return;
     double s = 0.0;
-    for (int b = 0; b < nbx; ++b) s += partial[t * nbx + b];
+    for (int b = 0; b < nbx; ++b) s += partial[t * t_stride + b * b_stride];
     double r = (s - m) - lgsum[t0 + t];
     if (f) r = __builtin_nan("");
     out[t] = r;

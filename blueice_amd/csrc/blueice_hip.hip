@@ -1030,7 +1030,8 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
                                    (double*)c->scratch2.p);
         }
         hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->scratch2.p, nbx, (const double*)a.partial, (const unsigned*)a.pflags, nmu,
+                           (const double*)c->scratch2.p, nbx, tiled ? (int64_t)1 : (int64_t)nbx, tiled ? ni : (int64_t)1,
+                           (const double*)a.partial, (const unsigned*)a.pflags, nmu,
                            (const double*)c->lgsum.p, t0 + s0, ni, res + s0);
     }
     hipError_t e = hipGetLastError();
