@@ -103,6 +103,8 @@ struct bi_ctx {
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
     bool tm_ok = false;                       // ... and whether every count fits its 19 bits
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
+    int64_t toy_events = 1;                   // parameter: toys of sparse expectations are drawn event by event (0 = always one draw per bin)
+    int64_t last_toy_method = 0;              // read-only: 1 = the last bi_generate_toys drew event by event, 0 = bin by bin
     std::vector<int64_t> h_nz_off;            // [T+1]
     std::vector<int64_t> h_c_off, h_cnt_off;  // [T] element offsets into ps_c / cnt_c
     std::vector<int64_t> h_c_np;              // [T] padded non-empty bins per dataset
@@ -112,6 +114,7 @@ struct bi_ctx {
     DevBuf slot_dev, slot_partial, slot_pflags, slot_counter;
     DevBuf mail, mail_flags;    // mailbox slots / status words of in-launch finishing: empty / zero between launches
     void* pack_host = nullptr;  // pinned staging of packed_upload (small-batch descriptors in, results out)
+    void* bounce_host = nullptr;  // pinned bounce buffer of bi_memcpy_to_host / _to_device for copies of up to kBounceBytes
     size_t pack_host_bytes = 0;
     DevBuf pack_dev;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out

@@ -1264,6 +1264,119 @@ __global__ __launch_bounds__(kThreads) void k_toy_scatter(const double* __restri
     if (threadIdx.x == 0) lg_partial[(int64_t)blockIdx.y * nchunks + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
 }
 
+// ---- toy-MC generation, event by event (sparse expectations) ----------------------------------------------------
+// Independent n_b ~ Poisson(mu_b) is the same law as N ~ Poisson(M = sum_b mu_b) events thrown onto the bins with
+// probabilities mu_b / M.  Where M << B (10^4 expected events in 10^6 bins at C2) that is 100 times fewer random numbers
+// than one draw per bin: one block per toy draws N, finds every event's bin by bisection in the cumulative sums of mu
+// (8 MB, L2), sorts the bin numbers in LDS (bitonic, up to 32 768 keys = 128 KB of the CU's 160 KB) and run-length
+// encodes them into the non-empty-bin list of the toy -- sorted by bin, as the per-bin generator leaves it.  Two passes
+// with the same counters (Philox4x32-10 keyed by the seed; counter = (event, toy)): the first only counts the non-empty
+// bins of every toy, the second writes them behind the offsets a scan made of the counts.
+constexpr int kEvThreads = 512;
+constexpr uint32_t kEvTag = 0x45564E54u;        // separates the event counters from the per-bin ones
+
+__device__ __forceinline__ int toy_event_count(double M, uint64_t seed, int64_t t) {
+    if (M >= 10.0) return (int)poisson_ptrs(M, seed, t, ((int64_t)1 << 40) + 7);          // a "bin" no model has
+    uint32_t r[4];
+    philox4x32_10(0xFFFFFFFFu, kEvTag, (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (int)poisson_small(M, exp(-M), u53(r[0], r[1]));
+}
+
+// events per toy (an upper bound of its non-empty bins: the room it gets in the provisional lists)
+__global__ void k_toy_event_counts(double M, uint64_t seed, int64_t t0, int64_t T, int npow2, int64_t* __restrict__ n_ev,
+                                   int* __restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > T) return;
+    if (i == T) { n_ev[i] = 0; return; }
+    const int n = toy_event_count(M, seed, t0 + i);
+    if (n > npow2) atomicOr(overflow, 1);
+    n_ev[i] = min(n, npow2);
+}
+
+__global__ __launch_bounds__(kEvThreads) void k_toy_events(const double* __restrict__ cdf, int64_t B, double M, uint64_t seed,
+                                                           int64_t t0, int npow2, const int64_t* __restrict__ room_off,
+                                                           int32_t* __restrict__ idx_out, double* __restrict__ n_out,
+                                                           int64_t* __restrict__ nnz_out, double* __restrict__ lgsum) {
+    extern __shared__ uint32_t s_keys[];                       // [npow2] keys, then kEvThreads ints / doubles of scratch
+    int* s_scan = reinterpret_cast<int*>(s_keys + npow2);
+    double* s_lg = reinterpret_cast<double*>(s_scan + kEvThreads);
+    __shared__ int s_N;
+    const int64_t t = t0 + blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_N = min(toy_event_count(M, seed, t), npow2);
+    __syncthreads();
+    const int N = s_N;
+    int n2 = 1024;                                             // the power of two this toy needs (the sort is the cost)
+    while (n2 < N) n2 <<= 1;
+    for (int e = tid; e < n2; e += kEvThreads) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (e < N) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)e, kEvTag, (uint32_t)t, (uint32_t)(t >> 32) & 0xFFFFu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            const double target = u53(r[0], r[1]) * M;
+            int64_t lo = 0, hi = B;                                         // first bin whose cumulative sum exceeds the target
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cdf[mid] <= target) lo = mid + 1; else hi = mid;
+            }
+            key = (uint32_t)min(lo, B - 1);
+        }
+        s_keys[e] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += kEvThreads) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = s_keys[i], b = s_keys[x];
+                    if ((a > b) == ((i & k) == 0)) { s_keys[i] = b; s_keys[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // run-length encoding: every thread owns a contiguous segment of the sorted keys
+    const int seg = n2 / kEvThreads;
+    const int a0 = tid * seg, a1 = a0 + seg;
+    int heads = 0;
+    for (int i = a0; i < a1 && i < N; ++i) heads += (i == 0 || s_keys[i] != s_keys[i - 1]);
+    s_scan[tid] = heads;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < tid; ++q) base += s_scan[q];                        // (512 additions per thread: nothing beside the sort)
+    int64_t pos = room_off[blockIdx.x] + base;
+    double lg = 0.0;
+    for (int i = a0; i < a1 && i < N; ++i) {
+        if (i != 0 && s_keys[i] == s_keys[i - 1]) continue;
+        int j = i + 1;
+        while (j < N && s_keys[j] == s_keys[i]) ++j;
+        const double n = (double)(j - i);
+        idx_out[pos] = (int32_t)s_keys[i];
+        n_out[pos] = n;
+        ++pos;
+        if (n > 1.0) lg += lgamma(n + 1.0);
+    }
+    s_lg[tid] = lg;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int q = 0; q < kEvThreads; ++q) tot += s_lg[q];
+        lgsum[blockIdx.x] = tot;
+        int nn = 0;
+        for (int q = 0; q < kEvThreads; ++q) nn += s_scan[q];
+        nnz_out[blockIdx.x] = nn;
+    }
+}
+
+// the provisional lists (room for one entry per EVENT) packed into the final ones (one entry per non-empty bin)
+__global__ __launch_bounds__(kThreads) void k_toy_pack(const int64_t* __restrict__ room_off, const int64_t* __restrict__ nz_off,
+                                                       const int32_t* __restrict__ idx_in, const double* __restrict__ n_in,
+                                                       int32_t* __restrict__ nz_idx, double* __restrict__ nz_n) {
+    const int64_t t = blockIdx.x;
+    const int64_t src = room_off[t], dst = nz_off[t], n = nz_off[t + 1] - dst;
+    for (int64_t j = threadIdx.x; j < n; j += kThreads) { nz_idx[dst + j] = idx_in[src + j]; nz_n[dst + j] = n_in[src + j]; }
+}
+
 // set_data on the device: bin events into the analysis space with numpy.histogramdd semantics (what
 // Histdd.add does in blueice/likelihood.py:608-609): per axis the bin is searchsorted(edges, x, 'right') - 1,
 // the right-most edge is inclusive, events outside any axis range (or nan) are dropped.  Adding 1.0 with an fp64
@@ -1360,6 +1473,12 @@ __global__ __launch_bounds__(kThreads) void k_score_events(const double* __restr
         }
         out[(int64_t)r * out_stride + e] = value;
     }
+}
+
+// small device -> pinned-host copies as a kernel (bi_memcpy_to_host): a copy-engine transfer of 80 KB costs 15 ... 110 us on
+// this runtime, a launch writing through the host mapping about 10
+__global__ void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t n_words) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // densify one dataset from its non-empty-bin list

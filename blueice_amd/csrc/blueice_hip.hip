@@ -116,6 +116,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->mail); dev_free(c->mail_flags);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
+    if (c->bounce_host) (void)hipHostFree(c->bounce_host);
     dev_free(c->pack_dev);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
@@ -170,6 +171,7 @@ int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "scan_sparse_max_items")) { c->scan_sparse_max_items = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
     if (!strcmp(name, "dot_tiled")) { c->dot_tiled = v != 0; return BI_OK; }
+    if (!strcmp(name, "toy_events")) { c->toy_events = v != 0; return BI_OK; }
     if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 0 ? 0 : v; return BI_OK; }
     if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
     if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
@@ -198,6 +200,7 @@ int64_t bi_get_param(bi_ctx* c, const char* name) {
     if (!strcmp(name, "single_ns_launch")) return c->single_ns[1];
     if (!strcmp(name, "single_ns_wait")) return c->single_ns[2];
     if (!strcmp(name, "single_calls")) return c->single_calls;
+    if (!strcmp(name, "last_toy_method")) return c->last_toy_method;
     if (!strcmp(name, "last_scan_nslots")) return c->last_scan_nslots;
     if (!strcmp(name, "last_scan_resident")) return c->last_scan_resident;
     if (!strcmp(name, "last_valid_nslots")) return c->last_valid_nslots;
@@ -1116,6 +1119,91 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
     const double* mu = (const double*)c->logmu.p;
     const double* p0 = (const double*)d_p0.p;
     hipLaunchKernelGGL(k_exp_neg, dim3((unsigned)((c->Bp + 255) / 256)), dim3(256), 0, c->stream, mu, c->Bp, (double*)d_p0.p);
+    // Sparse expectations (M = sum mu << B, templates and rates >= 0): event by event -- N ~ Poisson(M), the bins by bisection
+    // in the cumulative sums, sorted and run-length encoded per toy (k_toy_events); else one draw per bin.
+    c->last_toy_method = 0;
+    if (c->toy_events && c->ps_nonneg && B >= 4096) {
+        DevBuf d_cdf, d_tmp, d_nev, d_room, d_nnz, d_ovf, d_tidx, d_tn;
+        auto drop = [&]() { dev_free(d_cdf); dev_free(d_tmp); dev_free(d_nev); dev_free(d_room); dev_free(d_nnz); dev_free(d_ovf); dev_free(d_tidx); dev_free(d_tn); };
+        size_t sb1 = 0, sb2 = 0;
+        (void)rocprim::inclusive_scan(nullptr, sb1, (const double*)nullptr, (double*)nullptr, (size_t)B, rocprim::plus<double>(), c->stream);
+        (void)rocprim::exclusive_scan(nullptr, sb2, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+        if ((rc = dev_alloc(c, d_cdf, (size_t)B * sizeof(double))) || (rc = dev_alloc(c, d_tmp, std::max<size_t>({sb1, sb2, 256}))) ||
+            (rc = dev_alloc(c, d_ovf, 64))) { drop(); cleanup(); return rc; }
+        size_t tb = d_tmp.bytes;
+        hipError_t e = rocprim::inclusive_scan(d_tmp.p, tb, mu, (double*)d_cdf.p, (size_t)B, rocprim::plus<double>(), c->stream);
+        double M = 0.0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&M, (const double*)d_cdf.p + (B - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_ovf.p, 0, 64, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { drop(); cleanup(); return fail(c, BI_ERR_HIP, "toy generation (cumulative sums): %s", hipGetErrorString(e)); }
+        const double bound = M + 12.0 * std::sqrt(std::max(M, 1.0)) + 32.0;
+        int npow2 = 1024;
+        while (npow2 < bound && npow2 < 65536) npow2 <<= 1;
+        if (M > 0.0 && M == M && M < (double)B / 8.0 && npow2 <= 32768) {
+            const size_t lds = (size_t)npow2 * sizeof(uint32_t) + kEvThreads * (sizeof(int) + sizeof(double)) + 64;
+            HIP_TRY(c, hipFuncSetAttribute((const void*)k_toy_events, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if ((rc = dev_alloc(c, d_nev, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, d_room, (size_t)(T + 1) * sizeof(int64_t))) ||
+                (rc = dev_alloc(c, d_nnz, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, c->nz_off, (size_t)(T + 1) * sizeof(int64_t)))) {
+                drop(); cleanup(); return rc;
+            }
+            // (1) events per toy -> room in the provisional lists
+            hipLaunchKernelGGL(k_toy_event_counts, dim3((unsigned)((T + 1 + 255) / 256)), dim3(256), 0, c->stream, M, seed, c->toy_offset, T,
+                               npow2, (int64_t*)d_nev.p, (int*)d_ovf.p);
+            tb = d_tmp.bytes;
+            e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nev.p, (int64_t*)d_room.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+            int64_t n_events = 0;
+            int ovf = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&n_events, (const int64_t*)d_room.p + T, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { drop(); cleanup(); return fail(c, BI_ERR_HIP, "toy generation (events per toy): %s", hipGetErrorString(e)); }
+            if (!ovf) {
+                if ((rc = dev_alloc(c, d_tidx, (size_t)std::max<int64_t>(n_events, 1) * sizeof(int32_t))) ||
+                    (rc = dev_alloc(c, d_tn, (size_t)std::max<int64_t>(n_events, 1) * sizeof(double)))) { drop(); cleanup(); return rc; }
+                // (2) one block per toy: events -> sorted bins -> (bin, count) runs, written into the toy's room
+                const int64_t tchunk_ev = 65535;
+                for (int64_t t0 = 0; t0 < T; t0 += tchunk_ev) {
+                    const int64_t n = std::min(tchunk_ev, T - t0);
+                    hipLaunchKernelGGL(k_toy_events, dim3((unsigned)n), dim3(kEvThreads), lds, c->stream, (const double*)d_cdf.p, B, M, seed,
+                                       t0 + c->toy_offset, npow2, (const int64_t*)d_room.p + t0, (int32_t*)d_tidx.p, (double*)d_tn.p,
+                                       (int64_t*)d_nnz.p + t0, (double*)c->lgsum.p + t0);
+                }
+                // (3) non-empty bins per toy -> final offsets; pack
+                HIP_TRY(c, hipMemsetAsync((int64_t*)d_nnz.p + T, 0, sizeof(int64_t), c->stream));
+                tb = d_tmp.bytes;
+                e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nnz.p, (int64_t*)c->nz_off.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+                c->h_nz_off.assign((size_t)T + 1, 0);
+                if (e == hipSuccess) e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(c->h_nz_off.data(), c->nz_off.p, (size_t)(T + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { drop(); cleanup(); return fail(c, BI_ERR_HIP, "toy generation (events): %s", hipGetErrorString(e)); }
+                const int64_t run = c->h_nz_off[(size_t)T];
+                if ((rc = dev_alloc(c, c->nz_idx, (size_t)std::max<int64_t>(run, 1) * sizeof(int32_t))) ||
+                    (rc = dev_alloc(c, c->nz_n, (size_t)std::max<int64_t>(run, 1) * sizeof(double)))) { drop(); cleanup(); return rc; }
+                for (int64_t t0 = 0; t0 < T; t0 += tchunk_ev) {
+                    const int64_t n = std::min(tchunk_ev, T - t0);
+                    hipLaunchKernelGGL(k_toy_pack, dim3((unsigned)n), dim3(kThreads), 0, c->stream, (const int64_t*)d_room.p + t0,
+                                       (const int64_t*)c->nz_off.p + t0, (const int32_t*)d_tidx.p, (const double*)d_tn.p,
+                                       (int32_t*)c->nz_idx.p, (double*)c->nz_n.p);
+                }
+                c->h_lgsum.assign((size_t)T, 0.0);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(c->h_lgsum.data(), c->lgsum.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                drop();
+                cleanup();
+                if (e != hipSuccess) return fail(c, BI_ERR_HIP, "toy generation (events, pack): %s", hipGetErrorString(e));
+                c->last_toy_method = 1;
+                c->T = T;
+                c->csr_ready = true;
+                if ((rc = build_compact_templates(c))) return rc;
+                c->data_ready = true;
+                return BI_OK;
+            }
+        }
+        drop();            // not sparse enough, or a toy beyond the sort buffer (12 sigma): one draw per bin below
+    }
     const int64_t tchunk = 32768;
     for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
         const int64_t n = std::min(tchunk, T - t0);
@@ -1390,9 +1478,34 @@ int bi_device_free(bi_ctx* c, void* p) {
     return BI_OK;
 }
 
+// Copies of up to 4 MB between a device buffer and pageable host memory go through a pinned bounce buffer of the context:
+// the runtime's own handling of pageable memory costs 15 ... 110 us per small copy (it varies from call to call), the
+// bounce a DMA plus a memcpy -- the per-call gather of 10^4 toy results (80 KB) is such a copy.
+constexpr int64_t kBounceBytes = (int64_t)4 << 20;
+
+static int bounce_of(bi_ctx* c) {
+    if (!c->bounce_host) HIP_TRY(c, hipHostMalloc(&c->bounce_host, (size_t)kBounceBytes, hipHostMallocDefault));
+    return BI_OK;
+}
+
 int bi_memcpy_to_host(bi_ctx* c, void* dst, const void* src, int64_t bytes) {
     if (!c || bytes < 0 || (bytes > 0 && (!dst || !src))) return BI_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes > 0 && bytes <= kBounceBytes) {
+        int rc = bounce_of(c);
+        if (rc) return rc;
+        if (bytes % 4 == 0 && ((uintptr_t)src & 3) == 0) {      // a kernel writing through the host mapping (see k_copy_words)
+            const int64_t n_words = bytes / 4;
+            hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<int64_t>(1024, (n_words + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint32_t*)src, (uint32_t*)c->bounce_host, n_words);
+            HIP_TRY(c, hipGetLastError());
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(c->bounce_host, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(dst, c->bounce_host, (size_t)bytes);
+        return BI_OK;
+    }
     if (bytes) HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BI_OK;
@@ -1401,6 +1514,15 @@ int bi_memcpy_to_host(bi_ctx* c, void* dst, const void* src, int64_t bytes) {
 int bi_memcpy_to_device(bi_ctx* c, void* dst, const void* src, int64_t bytes) {
     if (!c || bytes < 0 || (bytes > 0 && (!dst || !src))) return BI_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes > 0 && bytes <= kBounceBytes) {
+        int rc = bounce_of(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // an earlier copy out of the bounce buffer is complete
+        memcpy(c->bounce_host, src, (size_t)bytes);
+        HIP_TRY(c, hipMemcpyAsync(dst, c->bounce_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return BI_OK;
+    }
     if (bytes) HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BI_OK;

@@ -271,6 +271,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   bb_exact          single-point Beeston-Barlow evaluations: N(z) = sum_b n_model[i, b] in numpy's own summation order (one more
  *                     pass over the 2^d rows of MC counts), so that the root formula sees the reference's bits: 0 never, 1
  *                     always, 2 when some bin can have U_b == 0 at the point (default)
+ *   toy_events        bi_generate_toys: sparse expectations (sum mu < B/8, templates and rates >= 0) are drawn event by event --
+ *                     N ~ Poisson(sum mu), bins by bisection in the cumulative sums, sorted and run-length encoded per toy (1,
+ *                     default); 0 = always one Poisson draw per bin.  Read-only `last_toy_method`: 1 / 0 for the last call.
  *   dot_tiled         bi_eval_datasets over non-empty-bin lists: batches of >= 64 datasets take the kernel that stages bin tiles
  *                     of log mu in LDS over tile-major lists (1, default); 0 = always one block per dataset
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows

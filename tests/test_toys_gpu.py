@@ -183,3 +183,65 @@ def test_tiled_dataset_kernel_random_shapes(seed):
         np.testing.assert_allclose(tiled[[0, one_tile, T - 1]], want, rtol=1e-10)
     finally:
         ctx.close()
+
+
+def test_event_by_event_generation_of_sparse_toys():
+    """Toys of sparse expectations are drawn event by event (N ~ Poisson(sum mu), bins by bisection in the cumulative
+    sums, sorted and run-length encoded per toy): the same law as one Poisson draw per bin.  Checked: totals, per-bin
+    and per-group means and variances, zero fractions, sorted unique bin lists, reproducibility and the dataset-number
+    semantics of toy_offset, the data-only lgamma term through the likelihood, and the per-bin generator on request."""
+    rng = np.random.default_rng(41)
+    B = 40000
+    mu = np.where(rng.random(B) < 0.3, 0.0, rng.random(B) ** 4 * 0.2)      # many exact zeros, sum ~ 1100
+    mu[:40] = np.linspace(0.5, 6.0, 40)                                     # a few busy bins
+    M = mu.sum()
+    ctx = make_ctx(mu)
+    try:
+        T = 5000
+        ctx.set_param('sparse', 1)
+        ctx.generate_toys(None, None, T, seed=99)
+        assert ctx.get_param('last_toy_method') == 1
+        toys = np.stack([ctx.download_counts(t) for t in range(0, T, 5)])   # 1000 of them, densely
+        assert np.all(toys == np.floor(toys)) and np.all(toys >= 0) and np.all(toys[:, mu == 0] == 0)
+        tot = toys.sum(axis=1)
+        assert abs(tot.mean() - M) < 5 * np.sqrt(M / len(toys)) and abs(tot.var(ddof=1) / M - 1) < 6 * np.sqrt(2 / len(toys))
+        busy = toys[:, :40]
+        se = np.sqrt(mu[:40] / len(toys))
+        assert np.all(np.abs(busy.mean(axis=0) - mu[:40]) < 5 * se)
+        assert np.all(np.abs(busy.var(axis=0, ddof=1) / mu[:40] - 1) < 6 * np.sqrt(2 / len(toys)) + 3 / (mu[:40] * np.sqrt(len(toys))))
+        groups = np.array_split(np.arange(40, B), 60)                        # the sparse bulk, in 60 groups of bins
+        for gidx in groups:
+            m = mu[gidx].sum()
+            x = toys[:, gidx].sum(axis=1)
+            assert abs(x.mean() - m) < 5 * np.sqrt(m / len(toys)) + 1e-9
+            assert abs(x.var(ddof=1) / m - 1) < 6 * np.sqrt(2 / len(toys)) + 3 / (m * np.sqrt(len(toys)))
+        for b in (0, 10, 39):
+            p = np.exp(-mu[b])
+            assert abs(np.mean(toys[:, b] == 0) - p) < 5 * np.sqrt(p * (1 - p) / len(toys)) + 1e-3
+        c = np.corrcoef(toys[:, 5], toys[:, 6])[0, 1]
+        assert abs(c) < 5 / np.sqrt(len(toys))
+        # the likelihood of the toys (data-only lgamma term included) against scipy on the fetched counts
+        ll, st = ctx.eval_datasets(None, [1.1])
+        assert st == 0
+        for k, t in enumerate(range(0, 50, 5)):
+            want = np.sum(stats.poisson(1.1 * mu).logpmf(toys[k]))
+            assert abs(ll[t] - want) <= 1e-10 * abs(want)
+        # same seed -> same toys; a range drawn with toy_offset is that range of the ensemble
+        first = ctx.download_counts(3), ctx.download_counts(T - 1)
+        ctx.generate_toys(None, None, T, seed=99)
+        np.testing.assert_array_equal(ctx.download_counts(3), first[0])
+        ctx.set_param('toy_offset', T - 10)
+        ctx.generate_toys(None, None, 10, seed=99)
+        np.testing.assert_array_equal(ctx.download_counts(9), first[1])
+        ctx.set_param('toy_offset', 0)
+        ctx.generate_toys(None, None, 50, seed=100)
+        assert np.any(ctx.download_counts(3) != first[0])
+        # bin by bin on request: another stream of random numbers, the same statistics
+        ctx.set_param('toy_events', 0)
+        ctx.generate_toys(None, None, 1000, seed=99)
+        assert ctx.get_param('last_toy_method') == 0
+        per_bin = np.stack([ctx.download_counts(t) for t in range(1000)])
+        assert abs(per_bin.sum(axis=1).mean() - M) < 5 * np.sqrt(M / 1000)
+        ctx.set_param('toy_events', 1)
+    finally:
+        ctx.close()

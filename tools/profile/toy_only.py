@@ -12,6 +12,8 @@ ctx = DeviceContext(0)
 m.upload(ctx, threads=8)
 z, r = m.default_point()
 ctx.set_param('sparse', 1)
+if len(sys.argv) > 2:
+    ctx.set_param('toy_events', int(sys.argv[2]))      # 0: the bin-by-bin generator
 ctx.generate_toys(z, r, 10000, seed=4242)
 out = ctx.device_alloc(8 * 10000)
 for k in range(3):
