@@ -245,3 +245,32 @@ def test_event_by_event_generation_of_sparse_toys():
         ctx.set_param('toy_events', 1)
     finally:
         ctx.close()
+
+
+def test_event_by_event_generation_with_very_few_events():
+    """sum mu = 2.5 over 8 000 bins: N comes from the inversion sampler, most toys have a handful of events or none."""
+    rng = np.random.default_rng(43)
+    B = 8000
+    mu = np.zeros(B)
+    live = rng.choice(B, 400, replace=False)
+    mu[live] = rng.random(400)
+    mu *= 2.5 / mu.sum()
+    ctx = make_ctx(mu)
+    try:
+        T = 20000
+        ctx.set_param('sparse', 1)
+        ctx.generate_toys(None, None, T, seed=5)
+        assert ctx.get_param('last_toy_method') == 1
+        nnz = ctx.get_param('nnz_total')
+        toys = np.stack([ctx.download_counts(t) for t in range(0, T, 10)])
+        tot = toys.sum(axis=1)
+        assert np.all(toys[:, mu == 0] == 0)
+        assert abs(tot.mean() - 2.5) < 5 * np.sqrt(2.5 / len(toys)) and abs(np.mean(tot == 0) - np.exp(-2.5)) < 0.03
+        assert abs(nnz / T - 2.5) < 0.1                         # (hardly any bin is hit twice)
+        ll, st = ctx.eval_datasets(None, [0.8])
+        assert st == 0
+        for k in (0, 1, 2, 3):
+            want = np.sum(stats.poisson(0.8 * mu).logpmf(toys[k]))
+            assert abs(ll[10 * k] - want) <= 1e-10 * max(1.0, abs(want))
+    finally:
+        ctx.close()
