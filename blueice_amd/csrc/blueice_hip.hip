@@ -599,7 +599,11 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             b.item_tiles = (const int32_t*)k.item_tiles.p + i0;
             b.partial = (double*)k.partial.p + i0 * k.nbx * k.G;
             b.pflags = (unsigned*)k.pflags.p + i0 * k.nbx * k.G;
-            const bool nt = !plan->sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && plan->no_reuse));
+            // nontemporal row loads when no two items touch the same anchor model -- or when an item streams more than the
+            // Infinity Cache can keep (> 1 GiB: a shared anchor's rows are gone before the other item asks for them;
+            // C5's 5.65 GB passes: 6.4 instead of 6.2 TB/s with 4 ... 16 items per call)
+            const bool huge_items = (int64_t)sizeof(double) * (NS + 1) * c->Bp > ((int64_t)1 << 30);
+            const bool nt = !plan->sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && (plan->no_reuse || huge_items)));
             // few items (a fit's or a bench step's batch): the last block of every item finishes it inside the launch
             // (at most 256 collecting blocks at a time: they wait for their siblings, and must never be able to hold
             // every slot of the chip while siblings still need one, whatever order the blocks are dispatched in)
