@@ -1145,7 +1145,8 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
         int npow2 = 1024;
         while (npow2 < bound && npow2 < 65536) npow2 <<= 1;
         if (M > 0.0 && M == M && M < (double)B / 8.0 && npow2 <= 32768) {
-            const size_t lds = (size_t)npow2 * sizeof(uint32_t) + kEvThreads * (sizeof(int) + sizeof(double)) + 64;
+            const size_t lds = (npow2 <= 16384 ? (size_t)2 * npow2 * sizeof(uint32_t) + 16 * kEvThreads * sizeof(uint16_t)
+                                               : (size_t)npow2 * sizeof(uint32_t)) + kEvThreads * (sizeof(int) + sizeof(double)) + 64;
             HIP_TRY(c, hipFuncSetAttribute((const void*)k_toy_events, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if ((rc = dev_alloc(c, d_nev, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, d_room, (size_t)(T + 1) * sizeof(int64_t))) ||
                 (rc = dev_alloc(c, d_nnz, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, c->nz_off, (size_t)(T + 1) * sizeof(int64_t)))) {
