@@ -274,3 +274,33 @@ def test_event_by_event_generation_with_very_few_events():
             assert abs(ll[10 * k] - want) <= 1e-10 * max(1.0, abs(want))
     finally:
         ctx.close()
+
+
+def test_event_by_event_generation_with_many_events_per_toy():
+    """sum mu = 20 000 over 200 000 bins: more than 16 384 events per toy, the size from which the per-toy sort is the
+    bitonic network instead of the radix sort."""
+    rng = np.random.default_rng(47)
+    B = 200000
+    mu = rng.random(B) * 0.2
+    mu *= 20000.0 / mu.sum()
+    ctx = make_ctx(mu)
+    try:
+        T = 300
+        ctx.set_param('sparse', 1)
+        ctx.generate_toys(None, None, T, seed=11)
+        assert ctx.get_param('last_toy_method') == 1
+        toys = np.stack([ctx.download_counts(t) for t in range(T)])
+        tot = toys.sum(axis=1)
+        assert abs(tot.mean() - 20000) < 5 * np.sqrt(20000 / T) and 0.7 < tot.var(ddof=1) / 20000 < 1.4
+        for gidx in np.array_split(np.arange(B), 40):
+            m = mu[gidx].sum()
+            x = toys[:, gidx].sum(axis=1)
+            assert abs(x.mean() - m) < 5 * np.sqrt(m / T)
+        ll, st = ctx.eval_datasets(None, [0.9])
+        want = np.sum(stats.poisson(0.9 * mu).logpmf(toys[7]))
+        assert st == 0 and abs(ll[7] - want) <= 1e-10 * abs(want)
+        again = ctx.download_counts(5).copy()
+        ctx.generate_toys(None, None, 10, seed=11)
+        np.testing.assert_array_equal(ctx.download_counts(5), again)
+    finally:
+        ctx.close()
