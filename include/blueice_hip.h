@@ -284,6 +284,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
  * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_bb_exact, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
+ *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
+ *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
  *                     bi_eval(P = 1): host half (geometry, rates, descriptors), launch calls, wait for the result */
 int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
