@@ -51,7 +51,11 @@ SIGNATURES = {
     'bi_eval_full': (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
     'bi_plan_points': (C.c_int, [_p, _i64, _p, _p, _p, C.POINTER(_p)]),
     'bi_run_plan': (C.c_int, [_p, _p, _p]),
+    'bi_plan_points_share': (C.c_int, [_p, _i64, _p, _p, _p, C.c_int, C.c_int, C.POINTER(_p)]),
+    'bi_plan_share_info': (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'bi_plan_unsort': (C.c_int, [_p, _p, _p, _i64, _p]),
     'bi_plan_read': (C.c_int, [_p, _p, _p, _p]),
+    'bi_plan_status': (C.c_int, [_p, _p, C.POINTER(_i32)]),
     'bi_plan_bytes': (_i64, [_p]),
     'bi_plan_launches': (_i64, [_p]),
     'bi_plan_destroy': (None, [_p, _p]),
@@ -72,6 +76,7 @@ SIGNATURES = {
     'bi_profile_read': (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_f64)]),
     'bi_set_param': (C.c_int, [_p, C.c_char_p, _i64]),
     'bi_get_param': (_i64, [_p, C.c_char_p]),
+    'bi_list_params': (C.c_int, [C.c_char_p, C.c_int]),
 }
 
 _lib = None

@@ -31,13 +31,19 @@ import time
 
 import numpy as np
 
-__all__ = ['SoloCommunicator', 'SocketCommunicator', 'RcclCommunicator', 'connect', 'CommError']
+__all__ = ['SoloCommunicator', 'SocketCommunicator', 'RcclCommunicator', 'connect', 'CommError', 'CommInitTimeout']
 
 _OPS = ('sum', 'max', 'min', 'bor')
 
 
 class CommError(RuntimeError):
     pass
+
+
+class CommInitTimeout(CommError):
+    """ncclCommInitRank did not return on some rank.  `stuck` is True on the ranks whose init thread is still inside
+    RCCL: such a process cannot shut down cleanly and must leave with os._exit (bench.py does)."""
+    stuck = False
 
 
 def _reduce(parts, op):
@@ -80,13 +86,19 @@ class SoloCommunicator:
 # sockets
 # ---------------------------------------------------------------------------------------------------
 def _send(sock, payload):
-    sock.sendall(struct.pack('<q', len(payload)) + payload)
+    try:
+        sock.sendall(struct.pack('<q', len(payload)) + payload)
+    except OSError as e:                                   # socket.timeout included
+        raise CommError("send to peer failed: %s" % (e or type(e).__name__))
 
 
 def _recv_exact(sock, n):
     chunks, got = [], 0
     while got < n:
-        b = sock.recv(min(n - got, 1 << 20))
+        try:
+            b = sock.recv(min(n - got, 1 << 20))
+        except OSError as e:                               # socket.timeout included: a peer that never answers
+            raise CommError("no answer from peer: %s" % (e or type(e).__name__))
         if not b:
             raise CommError("peer closed the connection")
         chunks.append(b)
@@ -116,7 +128,9 @@ class SocketCommunicator:
 
     kind = 'socket'
 
-    def __init__(self, rank, world, path=None, timeout=180.0, host='127.0.0.1'):
+    def __init__(self, rank, world, path=None, timeout=180.0, host='127.0.0.1', io_timeout=None):
+        # timeout: the rendezvous; io_timeout: how long a receive waits for a peer afterwards (default: the same)
+        io_timeout = timeout if io_timeout is None else io_timeout
         self.rank, self.world = int(rank), int(world)
         self._peers = []          # rank 0: socket of every other rank, by rank
         self._up = None           # other ranks: socket to rank 0
@@ -149,6 +163,7 @@ class SocketCommunicator:
                 if w != self.world or not 0 < r < self.world or r in peers:
                     conn.close()
                     raise CommError("rendezvous: unexpected peer (rank %d of %d)" % (r, w))
+                conn.settimeout(io_timeout)
                 peers[r] = conn
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
@@ -172,6 +187,7 @@ class SocketCommunicator:
                     _send(s, struct.pack('<ii', self.rank, self.world))
                     if _recv(s) != b'go':
                         raise CommError("bad handshake")
+                    s.settimeout(io_timeout)
                     self._up = s
                     break
                 except (OSError, ValueError, CommError) as e:     # no file yet, a stale file, or rank 0 not listening yet
@@ -269,24 +285,23 @@ def load_rccl():
 
 
 class RcclCommunicator:
-    """Device-side collectives on the context's stream.  `bootstrap` is an already connected host communicator (it
-    carries the unique id, and host-side odds and ends such as the max-over-ranks of a wall time)."""
+    """Device-side collectives on the context's stream.  The constructor only calls ncclCommInitRank with a unique id the
+    caller has already distributed (`exchange_unique_id`): it touches no socket, so it can run on a helper thread while
+    the bootstrap channel stays with the main thread.  `boot` is the connected host communicator (host-side odds and ends
+    such as the max-over-ranks of a wall time); attach it after construction."""
 
     kind = 'rccl'
 
-    def __init__(self, ctx, bootstrap):
-        self.ctx, self.boot = ctx, bootstrap
-        self.rank, self.world = bootstrap.rank, bootstrap.world
+    def __init__(self, ctx, rank, world, unique_id, boot=None):
+        self.ctx, self.boot = ctx, boot
+        self.rank, self.world = int(rank), int(world)
         self._lib = load_rccl()
         self._comm = C.c_void_p()
         self._send = self._recv = None
+        if len(unique_id) != 128:
+            raise CommError("unique id of %d bytes, expected 128" % len(unique_id))
         uid = _UniqueId()
-        if self.rank == 0:
-            self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
-        blob = bootstrap.broadcast_bytes(C.string_at(C.addressof(uid), 128) if self.rank == 0 else None)
-        if len(blob) != 128:
-            raise CommError("unique id of %d bytes received, expected 128" % len(blob))
-        C.memmove(C.addressof(uid), blob, 128)
+        C.memmove(C.addressof(uid), unique_id, 128)
         scratch = ctx.device_alloc(16)                 # also makes the context's GPU the calling thread's current device
         scratch.free()
         self._ok(self._lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
@@ -341,7 +356,7 @@ class RcclCommunicator:
         return recv.to_host(local.dtype, local.size).reshape(local.shape)
 
     def broadcast_bytes(self, data=None):
-        return self.boot.broadcast_bytes(data)
+        return self.boot.broadcast_bytes(data) if self.boot is not None else data
 
     def barrier(self):
         self.ctx.sync()
@@ -356,74 +371,103 @@ class RcclCommunicator:
             self.ctx.sync()
             self._lib.ncclCommDestroy(self._comm)
             self._comm = C.c_void_p()
-        self.boot.close()
+        if self.boot is not None:
+            self.boot.close()
 
 
-class _BroadcastOnly:
-    """The bootstrap channel as RcclCommunicator's constructor sees it: rank / world and ONE broadcast."""
+def exchange_unique_id(boot, lib):
+    """Rank 0 draws the RCCL unique id and EVERY rank receives either it or the reason there is none: rank 0 always
+    broadcasts -- one status byte, then the 128 id bytes or a message -- so no peer waits for an id that will never come
+    (a rank 0 that failed in ncclGetUniqueId used to leave the others blocked on the channel).
+    -> (id bytes or None, reason)."""
+    payload = None
+    if boot.rank == 0:
+        try:
+            uid = _UniqueId()
+            rc = lib.ncclGetUniqueId(C.byref(uid))
+            if rc == 0:
+                payload = b'\x01' + C.string_at(C.addressof(uid), 128)
+            else:
+                payload = b'\x00' + ('ncclGetUniqueId failed: %s' % lib.ncclGetErrorString(rc).decode()).encode()
+        except Exception as e:                                # ctypes / loader trouble: still tell the others
+            payload = b'\x00' + ('ncclGetUniqueId raised %r' % (e,)).encode()
+    blob = boot.broadcast_bytes(payload)
+    if blob[:1] == b'\x01' and len(blob) == 129:
+        return blob[1:], ''
+    return None, (blob[1:].decode(errors='replace') if blob[:1] == b'\x00' else 'malformed unique-id message from rank 0')
 
-    def __init__(self, boot):
-        self.rank, self.world, self._boot = boot.rank, boot.world, boot
 
-    def broadcast_bytes(self, data=None):
-        return self._boot.broadcast_bytes(data)
-
-    def close(self):
-        pass
+_INIT_OK, _INIT_FAILED, _INIT_STUCK = 0.0, 1.0, 2.0
 
 
 def connect(ctx=None, backend='rccl', rank=None, world=None, timeout=180.0):
     """The communicator of this process, from the launcher's environment (RANK / WORLD_SIZE, default one process).
 
-    backend 'rccl' needs the rank's DeviceContext; if RCCL cannot be loaded or initialised on ANY rank, every rank
-    falls back to the socket communicator together (`.kind == 'socket'`, `.fallback_reason` says why) -- a
-    gather of a few MB must not be what fails a run.  backend 'socket': host-side only (CPU rehearsals)."""
+    backend 'rccl' needs the rank's DeviceContext.  If RCCL cannot be loaded, rank 0 cannot draw a unique id, or
+    ncclCommInitRank RETURNS an error on any rank, every rank falls back to the socket communicator together
+    (`.kind == 'socket'`, `.fallback_reason` says why) -- a gather of a few MB must not be what fails a run.  If
+    ncclCommInitRank does not return within `timeout` on some rank, every rank raises CommInitTimeout: a process with
+    a thread stuck inside RCCL must end (non-zero), not carry on beside it.  backend 'socket': host-side only."""
     rank = int(os.environ.get('RANK', 0)) if rank is None else int(rank)
     world = int(os.environ.get('WORLD_SIZE', 1)) if world is None else int(world)
     if world == 1 and backend != 'rccl':
         return SoloCommunicator()
-    boot = SocketCommunicator(rank, world, timeout=timeout) if world > 1 else SoloCommunicator()
+    # a receive on the bootstrap channel may have to wait for a peer that sits out its own `timeout` first (the agreement
+    # after ncclCommInitRank): its patience is clearly longer than that, so the slow rank's answer is never cut off
+    boot = SocketCommunicator(rank, world, timeout=timeout, io_timeout=2.0 * timeout + 30.0) if world > 1 else SoloCommunicator()
     if backend == 'socket':
         return boot
     if backend != 'rccl':
         raise ValueError("backend must be 'rccl' or 'socket'")
     if ctx is None:
         raise ValueError("the rccl backend needs this rank's DeviceContext")
-    reason = ''
+
+    def fall_back(reason):
+        boot.fallback_reason = reason
+        return boot
+
+    reason, lib = '', None
     try:
-        load_rccl()
+        lib = load_rccl()
     except CommError as e:
         reason = str(e)
     # agree before anybody enters ncclCommInitRank (which blocks until every rank has arrived)
     if boot.all_reduce(np.array([1.0 if reason else 0.0]), 'max')[0] > 0:
-        boot.fallback_reason = reason or 'librccl.so could not be loaded on another rank'
-        return boot
-    comm = None
-    # ncclCommInitRank blocks until every rank has arrived; should it never return on some box (a fabric or driver
-    # problem is not ours to debug inside a benchmark), give up after `timeout` and gather through the sockets
+        return fall_back(reason or 'librccl.so could not be loaded on another rank')
+    unique_id, reason = exchange_unique_id(boot, lib)             # on the main thread: the channel has one user
+    if unique_id is None:
+        return fall_back(reason)
+    # ncclCommInitRank blocks until every rank has arrived; it runs on a helper thread that touches no socket, so the
+    # main thread can give up on it after `timeout` and still talk to the other ranks
     import threading
     box = {}
 
     def build():
         try:
-            box['comm'] = RcclCommunicator(ctx, boot_for_init)
+            box['comm'] = RcclCommunicator(ctx, rank, world, unique_id)
         except BaseException as e:                         # CommError, OSError from ctypes, ...
             box['error'] = e
 
-    boot_for_init = _BroadcastOnly(boot)                   # the init thread may only use the channel for the unique id
     th = threading.Thread(target=build, name='rccl-init', daemon=True)
     th.start()
     th.join(timeout)
     if th.is_alive():
-        reason = 'ncclCommInitRank did not return within %.0f s' % timeout
+        state, reason = _INIT_STUCK, 'ncclCommInitRank did not return within %.0f s on rank %d' % (timeout, rank)
     elif 'error' in box:
-        reason = str(box['error'])
+        state, reason = _INIT_FAILED, str(box['error'])
     else:
-        comm = box['comm']
-        comm.boot = boot
-    if boot.all_reduce(np.array([1.0 if reason else 0.0]), 'max')[0] > 0:
-        if comm is not None:
-            comm._comm = C.c_void_p()          # a communicator some rank failed to build is not usable: forget it
-        boot.fallback_reason = reason or 'ncclCommInitRank failed on another rank'
-        return boot
+        state = _INIT_OK
+    worst = boot.all_reduce(np.array([state]), 'max')[0]
+    if worst >= _INIT_STUCK:
+        err = CommInitTimeout(reason or 'ncclCommInitRank did not return within %.0f s on another rank' % timeout)
+        err.stuck = th.is_alive()
+        try:
+            boot.close()
+        finally:
+            raise err
+    if worst >= _INIT_FAILED:
+        # a communicator that exists on some ranks only is not usable and not safely destroyable: forget it
+        return fall_back(reason or 'ncclCommInitRank failed on another rank')
+    comm = box['comm']
+    comm.boot = boot
     return comm

@@ -48,6 +48,10 @@ struct bi_plan {
     bool valid = false;           // split dense scan: classes hold the non-empty-bin pass, k_scan_valid checks every bin
     int valid_nslots = 0;         // its waves per group
     DevBuf bad;                   // [items][16] flags it raises
+    bool shared = false;          // a share of a scan dealt over several contexts (plan_points_device, share_world > 1): results
+    int share_world = 1;          // come out in sorted order, out[0 .. share_hi - share_lo); sorted_idx [P] maps sorted positions
+    int64_t share_lo = 0, share_hi = 0, n_valid = 0;   // back to the caller's point indices
+    DevBuf sorted_idx;
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
@@ -149,6 +153,11 @@ struct bi_ctx {
     int64_t scan_split = 1;                      // dense scans over mostly empty data: non-empty-bin pass + matrix-core validity pass
     int64_t sparse_at_upload = 1;                // value of `sparse` when the resident data were uploaded
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
+    int64_t scan_pow = 1;                        // dense-data scans: small integer counts take one logarithm of the product mu^n over a lane's four bins
+    int64_t mail_timeout_ms = 2000;              // in-launch finish: how long a collecting block waits for a partial sum before BI_ST_INTERNAL
+    int64_t debug_skip_post = -1, debug_late_post = -1;   // fault injection for the next mailbox launch (bi_params.h)
+    int64_t n_mail_resets = 0;                   // how often the mailbox had to be emptied after a collector gave up
+    std::vector<void*> user_allocs;              // bi_device_alloc buffers still alive: freed with the context
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
     // scratch
@@ -312,7 +321,7 @@ void free_plan_buffers(bi_plan* p) {
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags); dev_free(k.rowoff_full);
     }
     dev_free(p->bad_idx); dev_free(p->nan_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
-    dev_free(p->slab); dev_free(p->bad);
+    dev_free(p->slab); dev_free(p->bad); dev_free(p->sorted_idx);
 }
 
 }  // namespace

@@ -219,10 +219,10 @@ __device__ __forceinline__ void bb_roots(double a, double p, double U, double d,
 // empty again when the launch ends.  Posting costs a block one store and no wait: round 2 first tried arrival
 // tickets (publish, drain, returning atomics) and measured +27 us on a 300 us launch -- every one of 8192 blocks
 // held its CU slot for ~4 us of round trips -- and round 1's release fence per block was worse still.
-// The collector's wait is bounded (kMailTimeoutTicks of the 100 MHz wall clock): if a value never arrives it gives
+// The collector's wait is bounded (LaunchArgs::mail_timeout ticks of the 100 MHz wall clock, 2 s by default): if a value never arrives it gives
 // up, reports BI_ST_INTERNAL and the result is nan -- no wave can spin forever.
 constexpr unsigned long long kMailEmpty = 0x7FF4B10E1CE00001ull;
-constexpr long long kMailTimeoutTicks = 200000000;                     // 2 s: far beyond any delay a busy, shared GPU causes
+constexpr long long kMailTicksPerMs = 100000;                          // wall_clock64 runs at 100 MHz
 
 __device__ __forceinline__ void mail_post(double* slot, double v) {
     if (v != v) v = __builtin_nan("");                                   // never the "empty" pattern
@@ -287,7 +287,20 @@ struct LaunchArgs {
     int32_t* fin_status;        // or NULL
     int nan_S;              // MODE 2 with non-finite pdf values: number of sources (streams are [corner][source]); the
                             // sum over sources then skips nan terms -- np.nansum, blueice/likelihood.py:686.  0 = off
+    long long mail_timeout = 2000 * kMailTicksPerMs; // in-launch finish: ticks of the 100 MHz wall clock a collector waits (context: mail_timeout_ms;
+                            // default 2 s, far beyond any delay a busy, shared GPU causes)
+    int skip_post = -1, late_post = -1;   // fault injection (tests): this block never posts / posts after the collector gave up; -1 = off
 };
+
+// the post of a block's partial sum with the two injected faults (both -1 in production: two scalar compares per block)
+__device__ __forceinline__ void mail_post_checked(const LaunchArgs& a, double* slot, double v) {
+    if ((int)blockIdx.x == a.skip_post) return;
+    if ((int)blockIdx.x == a.late_post) {
+        const long long until = (long long)wall_clock64() + 2 * a.mail_timeout;
+        while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+    }
+    mail_post(slot, v);
+}
 
 // The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
 // blockIdx.x strides over 512-bin tiles.
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
         const int64_t o = ((int64_t)item * nbx + blockIdx.x) * G + g;
         if (fuse) {
             if (BB) flags_post(a.fin_flags + (int64_t)item * G + g, f);
-            mail_post(a.fin_mail + o, s);
+            mail_post_checked(a, a.fin_mail + o, s);
         } else {
             a.partial[o] = s;
             a.pflags[o] = f;
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
     if (!fuse || (int)blockIdx.x != nbx - 1) return;
 
     // ---- the item's last block does what k_finish would do, in k_finish's summation order ----
-    const long long deadline = (long long)wall_clock64() + kMailTimeoutTicks;
+    const long long deadline = (long long)wall_clock64() + a.mail_timeout;
     double* __restrict__ mail = a.fin_mail + (int64_t)item * nbx * G;
     bool late = false;
     if (nbx <= 64) {
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
         for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w]; f |= s_flg[w]; }
         if constexpr (FUSE) {          // post into the mailbox and leave: the last block collects (see mail_post)
             if (BB) flags_post(d.flags, f);
-            mail_post(a.partial + blockIdx.x, s);
+            mail_post_checked(a, a.partial + blockIdx.x, s);
         } else {                       // a second, tiny launch sums the partials (k_finish_single)
             a.partial[blockIdx.x] = s;
             a.pflags[blockIdx.x] = f;
@@ -623,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleD
     if constexpr (!FUSE) return;
     if (blockIdx.x != gridDim.x - 1) return;
     // the last block in dispatch order: collect the partials of all blocks in block order
-    const long long deadline = (long long)wall_clock64() + kMailTimeoutTicks;
+    const long long deadline = (long long)wall_clock64() + a.mail_timeout;
     bool late = false;
     double s = 0.0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += kThreads) s += mail_take(a.partial + b, deadline, &late);
@@ -716,6 +729,19 @@ __global__ __launch_bounds__(kThreads) void k_finish(const double* __restrict__ 
         out[p] = t - lg;
         if (status) status[p] |= (int32_t)ff;
     }
+}
+
+// OR of the per-point status words of a plan -> one word (bi_plan_status)
+__global__ __launch_bounds__(kThreads) void k_status_or(const int32_t* __restrict__ status, int64_t n, int32_t* __restrict__ out) {
+    unsigned f = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) f |= (unsigned)status[i];
+    f = wave_or(f);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr((unsigned*)out, f);
+}
+
+__global__ void k_fill_value(double* __restrict__ out, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
 }
 
 __global__ void k_fill_const(double* __restrict__ out, const int64_t* __restrict__ idx, int64_t n, double v) {
@@ -1828,8 +1854,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
                     double f[4];                                                                                   \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                         f[r] = n[cb][r] == 2.0 ? acc[cb][r] * acc[cb][r] : acc[cb][r];                             \
-                    const double prod = (f[0] * f[1]) * (f[2] * f[3]);                                             \
-                    if (__ballot(!pos_normal(prod)) == 0ull) { s[cb & 3] += bin_log_fast(prod); break; }           \
+                    /* every intermediate must stay a positive normal number: a subnormal pair product next to a  */ \
+                    /* large one gives a normal total that has already lost mantissa bits                         */ \
+                    const double f01 = f[0] * f[1], f23 = f[2] * f[3];                                             \
+                    const double prod = f01 * f23;                                                                 \
+                    if (__ballot(!(pos_normal(f01) && pos_normal(f23) && pos_normal(prod))) == 0ull) {             \
+                        s[cb & 3] += bin_log_fast(prod);                                                           \
+                        break;                                                                                     \
+                    }                                                                                              \
                 }                                                                                                  \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb][r], bin_log_fast(acc[cb][r]), s[r]); \
             } else {                                                                                               \

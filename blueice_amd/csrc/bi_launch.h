@@ -86,9 +86,18 @@ int ensure_mail(bi_ctx* c) {
     return BI_OK;
 }
 
+// a launch that finishes through the mailbox: the collector's patience, and the injected faults (consumed here)
+void arm_mail(bi_ctx* c, LaunchArgs& a) {
+    a.mail_timeout = c->mail_timeout_ms * kMailTicksPerMs;
+    a.skip_post = (int)c->debug_skip_post;
+    a.late_post = (int)c->debug_late_post;
+    c->debug_skip_post = c->debug_late_post = -1;
+}
+
 // after a collector gave up (BI_ST_INTERNAL) the mailbox may hold values nobody took: empty it again
 void reset_mail(bi_ctx* c) {
     if (!c->mail.p) return;
+    ++c->n_mail_resets;
     (void)hipStreamSynchronize(c->stream);
     hipLaunchKernelGGL(k_mail_init, dim3((unsigned)((kMailSlots + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)c->mail.p, kMailSlots);
     (void)hipMemsetAsync(c->mail_flags.p, 0, (size_t)kMailFlagWords * sizeof(unsigned), c->stream);

@@ -28,12 +28,12 @@ struct PlanItem {
 constexpr int kClassG[5] = {1, 2, 4, 8, 16};
 
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out);
+                       bi_plan** out, int share_rank, int share_world);
 
 // transient: the plan is run once and destroyed inside the calling entry point (bi_eval); small ones then travel in
 // one packed copy and deliver their results to pinned host memory.
 int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bi_plan** out,
-                bool transient = false) {
+                bool transient = false, int share_rank = 0, int share_world = 1) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!out) return fail(c, BI_ERR_INVALID, "out is NULL");
@@ -61,11 +61,17 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     bool inf_scale = false;      // infinite rates are answered point by point on the host (inf_rate_value): host planner
     if (any_neg && rate_scale)
         for (int64_t i = 0; i < P * S && !inf_scale; ++i) inf_scale = std::isinf(rate_scale[i]);
+    if (share_world > 1) {       // a share of a dealt scan: the dealing IS the device planner's sort
+        if (share_rank < 0 || share_rank >= share_world) return fail(c, BI_ERR_INVALID, "share %d outside [0,%d)", share_rank, share_world);
+        if (bb || inf_scale || P > (int64_t)1 << 30)
+            return fail(c, BI_ERR_INVALID, "shares of a scan are planned on the device: not available with Beeston-Barlow or infinite rate scales");
+        return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, share_rank, share_world);
+    }
     if (!bb && !inf_scale && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
         int64_t cells = 1;
         for (int ax : c->eff_axes) cells *= c->n_anchor[(size_t)ax] - 1;
         const int64_t groups = cells * (dataset ? c->T : 1);
-        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out);
+        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, 0, 1);
     }
 
     // ---- phase 1: per point geometry, rates, early exits (parallel) ---------------------------------

@@ -63,6 +63,7 @@ struct PlanMeta {
     const int64_t* c_np;       // sparse: [T] padded non-empty bins
     const double* Tz;          // sparse: [T][n_rows]
     const double* rowsum;      // [n_rows] sum of every template row over all bins
+    int share_order;           // results in sorted order (perm = position in the share) instead of the caller's point order
     int linear_outside;        // the batch goes to k_scan_mfma: sum_b mu_b = sum_k coef_k * rowsum_k joins the per-point constant,
                                // and the kernel adds only the n log mu terms
 };
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
         atomicAdd(tile_sum, (unsigned long long)(row_stride / kTile));
     }
     slot_lg[item * kDevG + g] = m.unbinned ? rsum : m.lgsum[ds] + zsum;
-    perm[item * kDevG + g] = p;
+    perm[item * kDevG + g] = m.share_order ? i : p;
 }
 
 // group bookkeeping for the scan kernel: flag[i] = 1 at the first sorted position of every (cell, dataset) group
@@ -251,8 +252,12 @@ int ensure_plan_tables(bi_ctx* c) {
     return BI_OK;
 }
 
+// share_world > 1: this context evaluates only ITS contiguous share of the (cell, dataset)-sorted list of valid points --
+// the dealing of a scan over several GPUs done where the sort already happens (every rank plans the same P points and
+// gets the same order; rank r takes sorted positions [lo_r, hi_r)).  Its results then come out in sorted order
+// (out[0 .. hi - lo)), and the plan keeps the sorted -> original index map for unsort_share.
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out) {
+                       bi_plan** out, int share_rank = 0, int share_world = 1) {
     int rc = ensure_plan_tables(c);
     if (rc) return rc;
     const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
@@ -317,11 +322,28 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
-    const int64_t n_valid = h_scal[0];
-    plan->n_bad = P - n_valid;
+    const int64_t n_valid_all = h_scal[0];
+    plan->n_bad = P - n_valid_all;
+    // the share of this context: everything, or a contiguous range of the sorted list (the arrays below are windows on it)
+    const bool shared = share_world > 1;
+    int64_t share_lo = 0, share_hi = n_valid_all;
+    if (shared) {
+        const int64_t base = n_valid_all / share_world, extra = n_valid_all % share_world;
+        share_lo = share_rank * base + std::min<int64_t>(share_rank, extra);
+        share_hi = share_lo + base + (share_rank < extra ? 1 : 0);
+        plan->shared = true;
+        plan->share_world = share_world;
+        plan->share_lo = share_lo;
+        plan->share_hi = share_hi;
+        plan->n_valid = n_valid_all;
+    }
+    const int64_t n_valid = share_hi - share_lo;
+    const uint64_t* const keys_s = (const uint64_t*)d_keys2.p + share_lo;
+    const int64_t* const idx_s = (const int64_t*)d_idx2.p + share_lo;
+    m.share_order = shared ? 1 : 0;
     if (n_valid > 0) {
         const unsigned vblk = (unsigned)((n_valid + kThreads - 1) / kThreads);
-        hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const uint64_t*)d_keys2.p, n_valid, (int64_t*)d_a.p);
+        hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, keys_s, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, rocprim::maximum<int64_t>(), c->stream);  // d_b = group start
         hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
@@ -380,8 +402,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if (e == hipSuccess) e = hipMemsetAsync(k.perm.p, 0xFF, ni * kDevG * 8, c->stream);     // -1: padding slots
         if (e == hipSuccess) e = hipMemsetAsync(k.slot_lg.p, 0, ni * kDevG * 8, c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
-        hipLaunchKernelGGL(k_plan_fill, dim3(vblk), dim3(kThreads), 0, c->stream, m, n_valid, (const uint64_t*)d_keys2.p,
-                           (const int64_t*)d_idx2.p, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, (const double*)d_wts.p,
+        hipLaunchKernelGGL(k_plan_fill, dim3(vblk), dim3(kThreads), 0, c->stream, m, n_valid, keys_s,
+                           idx_s, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, (const double*)d_wts.p,
                            (const double*)d_rates.p, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
                            (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
                            split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr);
@@ -469,9 +491,31 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->launches = 1;
         }
     }
+    if (shared) {                 // the sorted -> original index map outlives the planning: unsort_share reads it
+        plan->sorted_idx = d_idx2;
+        d_idx2 = DevBuf{};
+    }
     cleanup();
     *out = plan;
     return BI_OK;
+}
+
+// gathered [share_world][stride]: rank r's results in sorted order -> full [P] in the caller's point order; rejected
+// points (sorted behind the valid ones) get -inf, as bi_run_plan gives them
+__global__ __launch_bounds__(kThreads) void k_unsort_share(const double* __restrict__ gathered, int64_t stride, int world, int64_t n_valid,
+                                                           int64_t P, const int64_t* __restrict__ sorted_idx, double* __restrict__ full) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= P) return;
+    double v = -__builtin_inf();
+    if (i < n_valid) {
+        const int64_t base = n_valid / world, extra = n_valid % world;
+        // ranks [0, extra) hold base + 1 positions, the others base
+        const int64_t cut = extra * (base + 1);
+        const int64_t r = i < cut ? i / (base + 1) : extra + (base ? (i - cut) / base : 0);
+        const int64_t lo = r * base + (r < extra ? r : extra);
+        v = gathered[r * stride + (i - lo)];
+    }
+    full[sorted_idx[i]] = v;
 }
 
 }  // namespace

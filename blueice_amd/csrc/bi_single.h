@@ -277,6 +277,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     a.B = c->B; a.Bp = c->Bp; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.n_tiles = tiles; a.chunks = (int)c->tile_chunks;
     a.outlier = c->outlier;
     a.nan_S = (c->unbinned && !c->ps_finite) ? c->S : 0;
+    if (fuse) arm_mail(c, a);
     const bool nt = !sparse && c->nt_loads != 0;
     // Repeated evaluations in one grid cell (a minimizer's access pattern): let most of the cell's rows keep the default
     // cache policy so that they stay in the 256 MiB Infinity Cache between calls (the rest, and every call into a new

@@ -48,6 +48,7 @@
 #include "bi_single.h"
 #include "bi_planning.h"
 #include "bi_planning_device.h"
+#include "bi_params.h"
 
 namespace {
 
@@ -121,6 +122,8 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
     dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum);
+    for (void* q : c->user_allocs) (void)hipFree(q);   // bi_device_alloc buffers nobody freed
+    c->user_allocs.clear();
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
     c->cache.clear();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -147,84 +150,34 @@ int bi_sync(bi_ctx* c) {
 
 int bi_set_param(bi_ctx* c, const char* name, int64_t v) {
     if (!c || !name) return BI_ERR_INVALID;
-    if (!strcmp(name, "blocks_per_cu")) { if (v < 1 || v > 32) return fail(c, BI_ERR_INVALID, "blocks_per_cu in [1,32]"); c->blocks_per_cu = v; return BI_OK; }
-    if (!strcmp(name, "max_group")) {
-        if (v < 1 || v > kMaxG || (v & (v - 1))) return fail(c, BI_ERR_INVALID, "max_group must be a power of two in [1,%d]", kMaxG);
-        c->max_group = v;
-        return BI_OK;
-    }
-    if (!strcmp(name, "sparse")) {
-        if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "sparse: 0 = off, 1 = auto, 2 = whenever exact");
-        c->sparse = v;
-        return BI_OK;
-    }
-    if (!strcmp(name, "compact_budget")) { c->compact_budget = v; return BI_OK; }
-    if (!strcmp(name, "single_kernel")) { c->single_kernel = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "fuse_finish")) { c->fuse_finish = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "single_timing_reset")) { c->single_ns[0] = c->single_ns[1] = c->single_ns[2] = 0; c->single_calls = 0; return BI_OK; }
-    if (!strcmp(name, "fuse_max_blocks")) { c->fuse_max_blocks = v; return BI_OK; }
-    if (!strcmp(name, "single_blocks_per_cu")) { if (v < 1 || v > 32) return fail(c, BI_ERR_INVALID, "single_blocks_per_cu in [1,32]"); c->single_blocks_per_cu = v; return BI_OK; }
-    if (!strcmp(name, "xcd_affine")) { c->xcd_affine = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "device_plan_min")) { c->device_plan_min = v; return BI_OK; }
-    if (!strcmp(name, "scan_mfma")) { c->scan_mfma = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "scan_split")) { c->scan_split = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "scan_sparse_max_items")) { c->scan_sparse_max_items = v < 0 ? 0 : v; return BI_OK; }
-    if (!strcmp(name, "bb_exact")) { if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "bb_exact: 0 never, 1 always, 2 auto"); c->bb_exact = v; return BI_OK; }
-    if (!strcmp(name, "dot_tiled")) { c->dot_tiled = v != 0; return BI_OK; }
-    if (!strcmp(name, "toy_events")) { c->toy_events = v != 0; return BI_OK; }
-    if (!strcmp(name, "scan_waves_per_cu")) { c->scan_waves_per_cu = v < 0 ? 0 : v; return BI_OK; }
-    if (!strcmp(name, "keep_rows")) { c->keep_rows = v < 0 ? -1 : v; return BI_OK; }
-    if (!strcmp(name, "poll_result")) { c->poll_result = v ? 1 : 0; return BI_OK; }
-    if (!strcmp(name, "tile_chunks")) { c->tile_chunks = v < 1 ? 1 : v; return BI_OK; }
-    if (!strcmp(name, "scan_min_items")) { c->scan_min_items = v < 1 ? 1 : v; return BI_OK; }
-    if (!strcmp(name, "toy_offset")) { if (v < 0) return fail(c, BI_ERR_INVALID, "toy_offset >= 0"); c->toy_offset = v; return BI_OK; }
-    if (!strcmp(name, "scan_cb")) { c->scan_cb = (v == 2 || v == 4) ? v : 0; return BI_OK; }
-    if (!strcmp(name, "nt_loads")) {
-        if (v < 0 || v > 2) return fail(c, BI_ERR_INVALID, "nt_loads: 0 = never, 1 = always, 2 = auto");
-        c->nt_loads = v;
-        return BI_OK;
-    }
-    return fail(c, BI_ERR_INVALID, "unknown parameter %s", name);
+    const ParamDef* p = find_param(name);
+    if (!p) return fail(c, BI_ERR_INVALID, "unknown parameter %s", name);
+    if (!p->set) return fail(c, BI_ERR_INVALID, "parameter %s is read-only", name);
+    return p->set(c, v);
 }
 
 int64_t bi_get_param(bi_ctx* c, const char* name) {
-    if (!c || !name) return -1;
-    if (!strcmp(name, "blocks_per_cu")) return c->blocks_per_cu;
-    if (!strcmp(name, "max_group")) return c->max_group;
-    if (!strcmp(name, "tile_bins")) return kTile;
-    if (!strcmp(name, "padded_bins")) return c->Bp;
-    if (!strcmp(name, "sparse")) return c->sparse;
-    if (!strcmp(name, "single_kernel")) return c->single_kernel;
-    if (!strcmp(name, "fuse_finish")) return c->fuse_finish;
-    if (!strcmp(name, "single_ns_host")) return c->single_ns[0];
-    if (!strcmp(name, "single_ns_launch")) return c->single_ns[1];
-    if (!strcmp(name, "single_ns_wait")) return c->single_ns[2];
-    if (!strcmp(name, "single_calls")) return c->single_calls;
-    if (!strcmp(name, "last_toy_method")) return c->last_toy_method;
-    if (!strcmp(name, "last_scan_nslots")) return c->last_scan_nslots;
-    if (!strcmp(name, "last_scan_resident")) return c->last_scan_resident;
-    if (!strcmp(name, "last_valid_nslots")) return c->last_valid_nslots;
-    if (!strcmp(name, "fuse_max_blocks")) return c->fuse_max_blocks;
-    if (!strcmp(name, "single_blocks_per_cu")) return c->single_blocks_per_cu;
-    if (!strcmp(name, "xcd_affine")) return c->xcd_affine;
-    if (!strcmp(name, "device_plan_min")) return c->device_plan_min;
-    if (!strcmp(name, "scan_mfma")) return c->scan_mfma;
-    if (!strcmp(name, "n_scan_launches")) return c->n_scan_launches;
-    if (!strcmp(name, "nt_loads")) return c->nt_loads;
-    if (!strcmp(name, "toy_offset")) return c->toy_offset;
-    if (!strcmp(name, "compact_budget")) return c->compact_budget;
-    // "ready" = prepared AND in use as an evaluation path (with sparse = 0 at upload they serve split scans only)
-    if (!strcmp(name, "csr_ready")) return (c->csr_ready && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
-    if (!strcmp(name, "compact_ready")) return (c->compact_ready && c->ps_nonneg && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0;
-    if (!strcmp(name, "split_ready")) return (c->compact_ready && c->dense_counts) ? 1 : 0;
-    if (!strcmp(name, "scan_split")) return c->scan_split;
-    if (!strcmp(name, "scan_sparse_max_items")) return c->scan_sparse_max_items;
-    if (!strcmp(name, "bb_exact")) return c->bb_exact;
-    if (!strcmp(name, "n_bb_exact")) return c->n_bb_exact;
-    if (!strcmp(name, "n_valid_launches")) return c->n_valid_launches;
-    if (!strcmp(name, "ps_nonneg")) return c->ps_nonneg ? 1 : 0;
-    if (!strcmp(name, "nnz_total")) return c->csr_ready ? c->h_nz_off.back() : -1;
-    return -1;
+    if (!c || !name) return INT64_MIN;
+    const ParamDef* p = find_param(name);
+    if (!p || !p->get) {
+        fail(c, BI_ERR_INVALID, p ? "parameter %s is write-only" : "unknown parameter %s", name);
+        return INT64_MIN;
+    }
+    return p->get(c);
+}
+
+int bi_list_params(char* buf, int len) {
+    std::string all;
+    for (const ParamDef& p : kParams) {
+        all += p.name;
+        all += p.access == kParamRW ? " rw\n" : (p.access == kParamRead ? " r\n" : " w\n");
+    }
+    if (buf && len > 0) {
+        const size_t n = std::min<size_t>(all.size(), (size_t)len - 1);
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int)all.size() + 1;
 }
 
 // ---- model ---------------------------------------------------------------------------------
@@ -532,6 +485,33 @@ int bi_plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     return plan_points(c, P, z, rate_scale, dataset, out);
 }
 
+int bi_plan_points_share(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, int share_rank,
+                         int share_world, bi_plan** out) {
+    if (share_world < 1) return fail(c, BI_ERR_INVALID, "share_world must be >= 1");
+    return plan_points(c, P, z, rate_scale, dataset, out, /*transient=*/false, share_rank, share_world);
+}
+
+int bi_plan_share_info(const bi_plan* p, int64_t* n_valid, int64_t* lo, int64_t* hi) {
+    if (!p || !p->shared) return BI_ERR_INVALID;
+    if (n_valid) *n_valid = p->n_valid;
+    if (lo) *lo = p->share_lo;
+    if (hi) *hi = p->share_hi;
+    return BI_OK;
+}
+
+int bi_plan_unsort(bi_ctx* c, bi_plan* plan, const double* gathered_dev, int64_t stride, double* full_dev) {
+    if (!c || !plan) return BI_ERR_INVALID;
+    if (!plan->shared) return fail(c, BI_ERR_INVALID, "bi_plan_unsort: not a share of a dealt scan (bi_plan_points_share)");
+    const int64_t per_rank = (plan->n_valid + plan->share_world - 1) / plan->share_world;
+    if (!gathered_dev || !full_dev || stride < per_rank) return fail(c, BI_ERR_INVALID, "bi_plan_unsort: NULL buffer or stride %lld < %lld", (long long)stride, (long long)per_rank);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (plan->P > 0)
+        hipLaunchKernelGGL(k_unsort_share, dim3((unsigned)((plan->P + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, gathered_dev,
+                           stride, plan->share_world, plan->n_valid, plan->P, (const int64_t*)plan->sorted_idx.p, full_dev);
+    HIP_TRY(c, hipGetLastError());
+    return BI_OK;
+}
+
 int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     int rc = check_ready(c, true);
     if (rc) return rc;
@@ -616,6 +596,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
                 b.fin_slot_lg = (const double*)k.slot_lg.p;
                 b.fin_out = out;
                 b.fin_status = (int32_t*)plan->status.p;
+                arm_mail(c, b);
             }
             launch_morph_g(c, k.G, b, dim3((unsigned)k.nbx, (unsigned)ni), bb, nt);
             if (fuse) continue;
@@ -655,7 +636,9 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
         hipLaunchKernelGGL(k_apply_bad, dim3((unsigned)((n_slots + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                            (const unsigned*)plan->bad.p, (const int64_t*)k.perm.p, n_slots, out);
     }
-    if (plan->n_bad > 0 && plan->device_planned)
+    if (plan->shared) {
+        // (rejected points belong to no share: bi_plan_unsort answers them)
+    } else if (plan->n_bad > 0 && plan->device_planned)
         hipLaunchKernelGGL(k_fill_bad_by_status, dim3((unsigned)((plan->P + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                            (const int32_t*)plan->status.p, plan->P, out);
     else if (plan->n_bad > 0)
@@ -670,15 +653,49 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
 
 int bi_plan_read(bi_ctx* c, bi_plan* plan, double* out, int32_t* status) {
     if (!c || !plan) return BI_ERR_INVALID;
+    if (out && plan->shared) return fail(c, BI_ERR_INVALID, "bi_plan_read: a share's results are in sorted order: gather them and call bi_plan_unsort");
     HIP_TRY(c, hipSetDevice(c->device));
     if (out && plan->P)
         HIP_TRY(c, hipMemcpyAsync(out, plan->out.p, (size_t)plan->P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (status && plan->P)
         HIP_TRY(c, hipMemcpyAsync(status, plan->status.p, (size_t)plan->P * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (status)
+    if (status) {
         for (int64_t p = 0; p < plan->P; ++p)
             if (status[p] & BI_ST_INTERNAL) { reset_mail(c); break; }
+        return BI_OK;
+    }
+    int32_t any = 0;
+    return bi_plan_status(c, plan, &any);
+}
+
+int bi_plan_status(bi_ctx* c, bi_plan* plan, int32_t* status_or) {
+    if (!c || !plan) return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int32_t any = 0;
+    if (plan->P) {
+        if (plan->host_results) {              // the status words already sit in pinned host memory
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const int32_t* st = (const int32_t*)plan->status.p;
+            for (int64_t p = 0; p < plan->P; ++p) any |= st[p];
+        } else {
+            DevBuf d_or;
+            int rc = dev_alloc(c, d_or, 64);
+            if (rc) return rc;
+            hipError_t e = hipMemsetAsync(d_or.p, 0, 4, c->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_status_or, dim3((unsigned)std::min<int64_t>(1024, (plan->P + kThreads - 1) / kThreads)), dim3(kThreads),
+                                   0, c->stream, (const int32_t*)plan->status.p, plan->P, (int32_t*)d_or.p);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&any, d_or.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            dev_free(d_or);
+            if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_plan_status: %s", hipGetErrorString(e));
+        }
+    }
+    if (any & BI_ST_INTERNAL) reset_mail(c);
+    if (status_or) *status_or = any;
     return BI_OK;
 }
 
@@ -704,6 +721,9 @@ int bi_eval(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, con
         if (!rc && P) {
             memcpy(out, plan->out.p, (size_t)P * sizeof(double));
             if (status) memcpy(status, plan->status.p, (size_t)P * sizeof(int32_t));
+            const int32_t* st = (const int32_t*)plan->status.p;
+            for (int64_t p = 0; p < P; ++p)
+                if (st[p] & BI_ST_INTERNAL) { reset_mail(c); break; }
         }
     } else if (!rc) {
         rc = bi_plan_read(c, plan, out, status);
@@ -919,8 +939,13 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     auto reject = [&](int32_t bit) -> int {          // the reference returns -inf before it looks at any data
         if (status) *status = bit;
         if (out_dev) {
-            std::vector<double> fill((size_t)n, ninf);
-            if (n) HIP_TRY(c, hipMemcpy(out_dev, fill.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+            // on the context's stream, like every other write to (and the caller's collectives on) that buffer
+            if (n) {
+                hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, out_dev, n, ninf);
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets_device: %s", hipGetErrorString(e));
+            }
         } else {
             std::fill(out, out + n, ninf);
         }
@@ -1147,7 +1172,10 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
         if (M > 0.0 && M == M && M < (double)B / 8.0 && npow2 <= 32768) {
             const size_t lds = (npow2 <= 16384 ? (size_t)2 * npow2 * sizeof(uint32_t) + 16 * kEvThreads * sizeof(uint16_t)
                                                : (size_t)npow2 * sizeof(uint32_t)) + kEvThreads * (sizeof(int) + sizeof(double)) + 64;
-            HIP_TRY(c, hipFuncSetAttribute((const void*)k_toy_events, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if ((e = hipFuncSetAttribute((const void*)k_toy_events, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+                drop(); cleanup();
+                return fail(c, BI_ERR_HIP, "toy generation (LDS size of the event kernel): %s", hipGetErrorString(e));
+            }
             if ((rc = dev_alloc(c, d_nev, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, d_room, (size_t)(T + 1) * sizeof(int64_t))) ||
                 (rc = dev_alloc(c, d_nnz, (size_t)(T + 1) * sizeof(int64_t))) || (rc = dev_alloc(c, c->nz_off, (size_t)(T + 1) * sizeof(int64_t)))) {
                 drop(); cleanup(); return rc;
@@ -1175,9 +1203,9 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
                                        (int64_t*)d_nnz.p + t0, (double*)c->lgsum.p + t0);
                 }
                 // (3) non-empty bins per toy -> final offsets; pack
-                HIP_TRY(c, hipMemsetAsync((int64_t*)d_nnz.p + T, 0, sizeof(int64_t), c->stream));
+                e = hipMemsetAsync((int64_t*)d_nnz.p + T, 0, sizeof(int64_t), c->stream);
                 tb = d_tmp.bytes;
-                e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nnz.p, (int64_t*)c->nz_off.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+                if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nnz.p, (int64_t*)c->nz_off.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
                 c->h_nz_off.assign((size_t)T + 1, 0);
                 if (e == hipSuccess) e = hipGetLastError();
                 if (e == hipSuccess) e = hipMemcpyAsync(c->h_nz_off.data(), c->nz_off.p, (size_t)(T + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
@@ -1471,6 +1499,7 @@ int bi_device_alloc(bi_ctx* c, int64_t bytes, void** out) {
     HIP_TRY(c, hipSetDevice(c->device));
     const hipError_t e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16));
     if (e != hipSuccess) return fail(c, BI_ERR_NOMEM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+    c->user_allocs.push_back(*out);           // whatever is still alive goes with the context (bi_destroy)
     return BI_OK;
 }
 
@@ -1478,7 +1507,10 @@ int bi_device_free(bi_ctx* c, void* p) {
     if (!c) return BI_ERR_INVALID;
     if (!p) return BI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    auto it = std::find(c->user_allocs.begin(), c->user_allocs.end(), p);
+    if (it == c->user_allocs.end()) return fail(c, BI_ERR_INVALID, "bi_device_free: %p was not allocated by bi_device_alloc on this context", p);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->user_allocs.erase(it);
     HIP_TRY(c, hipFree(p));
     return BI_OK;
 }

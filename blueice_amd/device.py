@@ -70,7 +70,17 @@ class DeviceContext:
         self._check(self._lib.bi_set_param(self._h, name.encode(), int(value)))
 
     def get_param(self, name):
-        return int(self._lib.bi_get_param(self._h, name.encode()))
+        v = int(self._lib.bi_get_param(self._h, name.encode()))
+        if v == -2 ** 63:                      # INT64_MIN: no such (readable) parameter -- never a plausible number
+            raise ValueError(self._lib.bi_last_error(self._h).decode())
+        return v
+
+    def list_params(self):
+        """-> {name: 'rw' | 'r' | 'w'} of every tunable, counter and trigger of the library."""
+        n = self._lib.bi_list_params(None, 0)
+        buf = C.create_string_buffer(n)
+        self._lib.bi_list_params(buf, n)
+        return dict(line.split() for line in buf.value.decode().splitlines())
 
     def sync(self):
         self._check(self._lib.bi_sync(self._h))
@@ -332,9 +342,24 @@ class DeviceContext:
         self._check(self._lib.bi_plan_points(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), C.byref(h)))
         return EvalPlan(self, h, P)
 
+    def plan_share(self, z, rate_scale=None, dataset=None, rank=0, world=1):
+        """This context's share of a scan dealt over `world` GPUs: every rank passes the same points, the device
+        planner's (cell, dataset) sort is the dealing.  -> EvalPlan with `.share = (lo, hi)` and `.n_valid`; its run()
+        leaves hi - lo results in sorted order, `unsort()` turns the gathered vectors into the caller's order."""
+        P, z, rate_scale, dataset = self._point_args(z, rate_scale, dataset)
+        h = C.c_void_p()
+        self._check(self._lib.bi_plan_points_share(self._h, P, ptr(z), ptr(rate_scale), ptr(dataset), int(rank), int(world),
+                                                   C.byref(h)))
+        plan = EvalPlan(self, h, P)
+        nv, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.bi_plan_share_info(h, C.byref(nv), C.byref(lo), C.byref(hi)))
+        plan.n_valid, plan.share, plan.world = nv.value, (lo.value, hi.value), int(world)
+        return plan
+
     # -- plain device buffers (gather staging) ------------------------------------------------------
     def device_alloc(self, nbytes):
-        """-> DeviceBuffer of `nbytes` on this context's GPU (freed with .free() or with the context)."""
+        """-> DeviceBuffer of `nbytes` on this context's GPU.  `.free()` releases it; buffers still alive when the
+        context is closed are released with it (the library keeps track of them: `user_allocations`)."""
         h = C.c_void_p()
         self._check(self._lib.bi_device_alloc(self._h, int(nbytes), C.byref(h)))
         return DeviceBuffer(self, h.value, int(nbytes))
@@ -419,6 +444,22 @@ class EvalPlan:
 
     def run(self, out_dev_ptr=None):
         self.ctx._check(self.ctx._lib.bi_run_plan(self.ctx._h, self._h, out_dev_ptr))
+
+    def unsort(self, gathered_ptr, stride, full_ptr):
+        """A share of a dealt scan: gathered [world][stride] (device; rank r's results in sorted order) -> full [P] in
+        the caller's point order (device), on the context stream."""
+        self.ctx._check(self.ctx._lib.bi_plan_unsort(self.ctx._h, self._h, C.c_void_p(gathered_ptr), int(stride),
+                                                     C.c_void_p(full_ptr)))
+
+    def status(self):
+        """Bitwise OR of the per-point status words of the last run() (waits for it) -- for callers that leave the
+        results in HBM.  Raises DeviceError on BI_ST_INTERNAL (a launch gave up collecting a partial sum: the
+        results of that run are not to be used; the library has emptied its mailbox again)."""
+        word = C.c_int32()
+        self.ctx._check(self.ctx._lib.bi_plan_status(self.ctx._h, self._h, C.byref(word)))
+        if word.value & _capi.ST_INTERNAL:
+            raise DeviceError("a launch of this plan gave up waiting for a partial sum (BI_ST_INTERNAL): results discarded")
+        return word.value
 
     def read(self):
         out = np.empty(self.P, dtype=np.float64)

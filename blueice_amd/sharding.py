@@ -11,6 +11,9 @@ The reference has no counterpart: its scans are Python loops over `lf(**kw)`
 """
 import numpy as np
 
+from ._capi import ST_INTERNAL
+from .exceptions import DeviceError
+
 __all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys',
            'sharded_scan_device', 'allreduce_sum', 'bin_sharded_eval']
 
@@ -102,41 +105,72 @@ def sharded_eval_points(eval_fn, anchor_z, z, rate_scale, comm=None):
 
 
 def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
-    """The same with nothing but the final vector leaving HBM: this rank's share of the points is planned once,
-    `bi_run_plan` writes into a device buffer, RCCL gathers the buffers of all ranks on the context's stream and the
-    gathered [world, n_max] block crosses PCIe once.  -> (ll [P] on every rank, run) where run() repeats the
-    evaluation + gather on the resident plan (for timing) and returns ll again.
-    `comm` must offer all_gather_device (blueice_amd.comm.RcclCommunicator); other communicators take the host
-    route of sharded_eval_points."""
+    """A scan of P points over the GPUs of `comm` with nothing but the final vector leaving HBM.  -> (ll [P] on every
+    rank, run) where run() repeats evaluation + gather on the resident plan (for timing) and returns ll again.
+
+    The dealing happens on the device: every rank hands ALL P points to its context, the device planner's
+    (cell, dataset) sort is the same on every rank, and rank r evaluates a contiguous, balanced range of that sorted
+    list (`DeviceContext.plan_share`) -- cells stay together, a cell is split over at most two ranks, and there is no
+    host pass over the points.  The ranks' result vectors (sorted order) are gathered -- RCCL on the context's stream
+    between device buffers when `comm` offers all_gather_device, else through the host communicator -- and one kernel
+    scatters them into the caller's point order (`EvalPlan.unsort`); the [P] vector crosses PCIe once.
+    Beeston-Barlow models are planned on the host: their points are dealt there (deal_points_by_cell)."""
     z = np.atleast_2d(np.asarray(z, dtype=float))
     rate_scale = np.atleast_2d(np.asarray(rate_scale, dtype=float))
     rank, world = _world(comm)
+    P = len(z)
+
+    def agree(word):
+        # every rank takes part in every collective before anybody raises: a rank that bailed out earlier would leave
+        # the others waiting in the gather
+        if world > 1:
+            word = int(comm.all_reduce(np.array([word], dtype=np.int64), 'bor')[0])
+        if word & ST_INTERNAL:
+            raise DeviceError("a rank's launch gave up waiting for a partial sum (BI_ST_INTERNAL): scan discarded")
+
+    def status_of(plan):
+        try:                                 # nobody reads a plan's status array on these routes: look at its OR
+            return plan.status()
+        except DeviceError:
+            return ST_INTERNAL
+
+    if world > 1 and ctx.bb_source < 0 and P > 0:
+        stride = -(-P // world)
+        plan = ctx.plan_share(z, rate_scale, dataset, rank, world)
+        send, recv, full = ctx.device_alloc(8 * stride), ctx.device_alloc(8 * stride * world), ctx.device_alloc(8 * P)
+        send.from_host(np.zeros(stride))
+        on_device = hasattr(comm, 'all_gather_device')
+
+        def run():
+            plan.run(send.ptr)
+            word = status_of(plan)
+            if on_device:
+                comm.all_gather_device(send.ptr, recv.ptr, stride)
+            else:
+                recv.from_host(comm.all_gather(send.to_host(np.float64, stride)))
+            plan.unsort(recv.ptr, stride, full.ptr)
+            out = full.to_host(np.float64, P)
+            agree(word)
+            return out
+
+        return run(), run
+
     deal = deal_points_by_cell(ctx.anchor_z, z, world)
     mine = deal[rank]
-    n_max = max(max(len(d) for d in deal), 1)
-    plan = ctx.plan(z[mine], rate_scale[mine], dataset) if len(mine) else None
-    device_path = world > 1 and hasattr(comm, 'all_gather_device')
-    send = ctx.device_alloc(8 * n_max) if device_path else None
-    recv = ctx.device_alloc(8 * n_max * world) if device_path else None
-    if send is not None:
-        send.from_host(np.zeros(n_max))
+    ds_mine = None if dataset is None else np.broadcast_to(np.asarray(dataset, dtype=np.int64), (P,))[mine]
+    plan = ctx.plan(z[mine], rate_scale[mine], ds_mine) if len(mine) else None
 
     def run():
-        if device_path:
-            if plan is not None:
-                plan.run(send.ptr)
-            comm.all_gather_device(send.ptr, recv.ptr, n_max)
-            parts = recv.to_host(np.float64, n_max * world).reshape(world, n_max)
-            parts = [p[:len(d)] for p, d in zip(parts, deal)]
-        else:
-            local = np.zeros(0)
-            if plan is not None:
-                plan.run()
-                local = plan.read()[0]
-            parts = gather_vector(local, [len(d) for d in deal], comm)
+        local, word = np.zeros(0), 0
+        if plan is not None:
+            plan.run()
+            local, st = plan.read()
+            word = int(np.bitwise_or.reduce(st)) if len(st) else 0
+        parts = gather_vector(local, [len(d) for d in deal], comm)
         out = np.empty(len(z))
         for idx, vals in zip(deal, parts):
             out[idx] = vals
+        agree(word)
         return out
 
     return run(), run

@@ -214,7 +214,24 @@ typedef struct bi_plan bi_plan;
 int bi_plan_points(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
                    bi_plan** out);
 int bi_run_plan(bi_ctx* ctx, bi_plan* plan, double* out_dev /* NULL: internal buffer */);
+/* A scan dealt over several GPUs ("sort/group by grid cell first, then deal cells to ranks"; the
+ * reference's counterpart is the double loop of blueice/inference.py:424-432).  Every rank passes the SAME P points; the
+ * device planner's (cell, dataset) sort IS the dealing: rank `share_rank` of `share_world` takes a contiguous, balanced
+ * range [lo, hi) of the sorted list of valid points, so the points of a grid cell stay together (a cell is split over at
+ * most two neighbouring ranks) and no host pass over the points is needed.  bi_run_plan then writes hi - lo results in
+ * SORTED order to out_dev[0 .. hi - lo); after the ranks' vectors have been gathered into [share_world][stride]
+ * (stride >= ceil(n_valid / share_world)), bi_plan_unsort scatters them into the caller's point order, full_dev [P]
+ * (rejected points: -inf), on the context's stream.  Plain binned / unbinned likelihoods (no Beeston-Barlow). */
+int bi_plan_points_share(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
+                         int share_rank, int share_world, bi_plan** out);
+int bi_plan_share_info(const bi_plan* plan, int64_t* n_valid, int64_t* lo, int64_t* hi);
+int bi_plan_unsort(bi_ctx* ctx, bi_plan* plan, const double* gathered_dev, int64_t stride, double* full_dev);
 int bi_plan_read(bi_ctx* ctx, bi_plan* plan, double* out /*[P]*/, int32_t* status /*[P] or NULL*/);
+/* The bitwise OR of the plan's per-point status words after the last bi_run_plan (waits for the stream): what a caller
+ * that leaves the results in HBM (bi_run_plan(out_dev) -> collective) must look at before it trusts them.
+ * BI_ST_INTERNAL in it means a launch gave up collecting a partial sum (result nan): the context's mailbox is
+ * emptied again here, so the next launch starts clean. */
+int bi_plan_status(bi_ctx* ctx, bi_plan* plan, int32_t* status_or);
 int64_t bi_plan_bytes(const bi_plan* plan);    /* algorithmic HBM bytes one bi_run_plan moves */
 int64_t bi_plan_launches(const bi_plan* plan); /* morph+reduce launches per bi_run_plan */
 void bi_plan_destroy(bi_ctx* ctx, bi_plan* plan);
@@ -282,14 +299,24 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
  *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
+ *   scan_pow          dense-data scans on the matrix cores: blocks whose counts are small integers take ONE logarithm of the
+ *                     product mu^n over a lane's four bins instead of four (1, default)
+ *   mail_timeout_ms   in-launch finish: how long an item's collecting block waits for a sibling's partial sum before it gives
+ *                     up with BI_ST_INTERNAL (2000)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
- * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_bb_exact, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
+ *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
+ *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
  *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
  *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
  *                     bi_eval(P = 1): host half (geometry, rates, descriptors), launch calls, wait for the result */
-int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);
-int64_t bi_get_param(bi_ctx* ctx, const char* name);
+int bi_set_param(bi_ctx* ctx, const char* name, int64_t value);   /* unknown or read-only name: BI_ERR_INVALID */
+int64_t bi_get_param(bi_ctx* ctx, const char* name);               /* unknown or write-only name: INT64_MIN (no parameter
+                                                                      can hold it) and a message in bi_last_error */
+/* every parameter name, one per line as "<name> <rw|r|w>\n", NUL-terminated, into buf (truncated to len); returns
+ * the buffer size the whole list needs */
+int bi_list_params(char* buf, int len);
 
 #ifdef __cplusplus
 }

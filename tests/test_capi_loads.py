@@ -50,6 +50,21 @@ def test_version_and_loud_failure_without_gpu(lib):
         DeviceContext(0)
 
 
+def test_parameter_names_are_enumerable_and_documented(lib):
+    """bi_list_params lists every tunable / counter / trigger, and the header documents each of them."""
+    import ctypes as C
+    n = lib.bi_list_params(None, 0)
+    buf = C.create_string_buffer(n)
+    assert lib.bi_list_params(buf, n) == n
+    params = dict(line.split() for line in buf.value.decode().splitlines())
+    assert len(params) >= 40 and set(params.values()) <= {'rw', 'r', 'w'}
+    header = open(os.path.join(ROOT, 'include', 'blueice_hip.h')).read()
+    for name in params:
+        assert re.search(r'\b%s\b' % re.escape(name), header), '%s is not documented in include/blueice_hip.h' % name
+    small = C.create_string_buffer(8)                    # truncation keeps the terminator and still reports the size
+    assert lib.bi_list_params(small, 8) == n and len(small.value) == 7
+
+
 def _compile_c_demo(tmp_path):
     import subprocess
     exe = str(tmp_path / 'c_abi_demo')

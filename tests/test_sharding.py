@@ -229,3 +229,87 @@ def test_launcher_starts_ranks_and_propagates_failure(tmp_path):
     assert ok.returncode == 0
     bad = subprocess.run([sys.executable, '-m', 'blueice_amd.launch', '--nproc', '2', str(script), 'fail'], env=env, timeout=300)
     assert bad.returncode == 3
+
+
+# ---- the RCCL initialisation's failure modes, with a scripted stand-in for librccl (comm.py) ----------
+class _FakeRccl:
+    """What blueice_amd.comm calls on librccl.so, scripted per rank: `uid_rc` is ncclGetUniqueId's return code,
+    `init` what ncclCommInitRank does ('ok', 'fail', 'hang')."""
+
+    def __init__(self, uid_rc=0, init='ok'):
+        self.uid_rc, self.init = uid_rc, init
+
+    def ncclGetUniqueId(self, ref):
+        return self.uid_rc
+
+    def ncclGetErrorString(self, rc):
+        return b'scripted failure %d' % rc
+
+    def ncclCommInitRank(self, comm_ref, world, uid, rank):
+        import time
+        if self.init == 'hang':
+            time.sleep(3600)
+        return 0 if self.init == 'ok' else 5
+
+    def ncclGetVersion(self, ref):
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        return 0
+
+
+class _FakeCtx:
+    stream = 0
+
+    def device_alloc(self, n):
+        class Buf:
+            def free(self):
+                pass
+        return Buf()
+
+    def sync(self):
+        pass
+
+
+def _rccl_failure_worker(kind, rank, world, port, rdzv, q):
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      BLUEICE_AMD_RDZV=rdzv)
+    from blueice_amd import comm as cm
+    script = {'uid_fails': _FakeRccl(uid_rc=3 if rank == 0 else 0),
+              'init_fails_on_one': _FakeRccl(init='fail' if rank == 1 else 'ok'),
+              'init_hangs_on_one': _FakeRccl(init='hang' if rank == 1 else 'ok'),
+              'all_fine': _FakeRccl()}[kind]
+    cm.load_rccl = lambda: script
+    t = time.monotonic()
+    try:
+        c = cm.connect(_FakeCtx(), backend='rccl', timeout=3.0)
+        # whatever came back must work as a communicator on every rank
+        tot = c.boot.all_reduce(np.array([1.0])) if c.kind == 'rccl' else c.all_reduce(np.array([1.0]))
+        q.put((rank, c.kind, getattr(c, 'fallback_reason', ''), float(tot[0]), time.monotonic() - t))
+        c.boot.close() if c.kind == 'rccl' else c.close()
+    except cm.CommInitTimeout as e:
+        q.put((rank, 'timeout', str(e), float(e.stuck), time.monotonic() - t))
+        q.close()
+        q.join_thread()                              # the message is out before the process ends abruptly
+        os._exit(0)                                  # (a rank with a stuck init thread leaves like this; bench.py: non-zero)
+
+
+@pytest.mark.parametrize('kind', ['uid_fails', 'init_fails_on_one', 'init_hangs_on_one', 'all_fine'])
+def test_rccl_init_failures_are_agreed_on(kind, tmp_path):
+    got = sorted(_run_ranks(_rccl_failure_worker, kind, 2, tmp_path))
+    assert [g[0] for g in got] == [0, 1]
+    if kind == 'all_fine':
+        assert all(g[1] == 'rccl' and g[3] == 2.0 for g in got)
+    elif kind == 'uid_fails':
+        # rank 0 could not draw an id: it says so, nobody waits for an id that never comes, both gather through sockets
+        assert all(g[1] == 'socket' and 'ncclGetUniqueId failed' in g[2] and g[3] == 2.0 and g[4] < 2.5 for g in got), got
+    elif kind == 'init_fails_on_one':
+        assert all(g[1] == 'socket' and g[3] == 2.0 for g in got), got
+        assert 'ncclCommInitRank failed' in got[1][2] and 'another rank' in got[0][2]
+    else:
+        # one rank never comes back from ncclCommInitRank: EVERY rank gives up together, only that one is stuck
+        assert all(g[1] == 'timeout' for g in got), got
+        assert [g[3] for g in got] == [0.0, 1.0]
+        assert all(2.5 < g[4] < 12 for g in got), got
