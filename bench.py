@@ -13,19 +13,24 @@ no anchor model with each other and use 8 different datasets, so no byte is used
 2.1 GB is far beyond the 256 MiB Infinity Cache: algorithmic bytes = compulsory HBM traffic.  Successive steps
 rotate through the 8 parity combinations of cells.
 
-With N > 1 ranks (one process per GPU; launched by torch.distributed.run or `python -m blueice_amd.launch` -- only the
-RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* environment is read, PyTorch is not imported) every rank holds a replica
+With N > 1 ranks (one process per GPU) every rank holds a replica.  `python bench.py --gpus N` with no WORLD_SIZE in the
+environment starts the N rank processes ITSELF: the parent -- before it has touched the GPU or loaded the library --
+spawns N fresh children of this script (blueice_amd.launch: RANK / LOCAL_RANK / WORLD_SIZE / rendezvous file in their
+environment), relays rank 0's JSON line (the children inherit its stdout) and exits with the first non-zero child code.
+Launched by torch.distributed.run or `python -m blueice_amd.launch` only the RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
+environment is read (PyTorch is not imported).  Every rank holds a replica
 of the tensor and evaluates its own K steps (weak scaling, no data-path collective); the per-rank result vectors stay
 in HBM and are gathered once at the end with RCCL (ncclAllGather, bound directly: blueice_amd.comm), inside the timed
-region.  The configurations that really shard -- 10^6 scan points dealt by grid cell (configs[3]), 10^4 toy datasets
-split by range (configs[2]) -- run as STRONG-scaling legs behind the headline on every N and are reported under
+region.  The configurations that really shard -- 10^6 scan points dealt by grid cell (configs[3]; the dealing is the
+device planner's sort, inside the timed step), 10^4 toy datasets split by range (configs[2]), 256 Beeston-Barlow scan
+points on a grid cell of configs[4] -- run as STRONG-scaling legs behind the headline on every N and are reported under
 "legs" (fixed total work, gather inside the timed region, cross-rank consistency asserted on a sample).
 
 The JSON line also carries
   roofline      morph+reduce kernel: algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s, the measured
                 stream ceiling of the same access pattern, PMC traffic from profiles/
   cpu_baseline  the numpy/scipy oracle (the reference's arithmetic) timed on the host, rank 0, N = 1
-  legs          C4 / C4-dense / C3 (every N) and the Beeston-Barlow kernel on one C5 grid cell (N = 1)
+  legs          C4 / C4-dense / C3 / C5-BB (every N; C5-BB carries the Beeston-Barlow kernel's own roofline)
   extras        other call shapes of the same path (N = 1)
 """
 import argparse
@@ -105,13 +110,20 @@ class Ranks:
         self.comm = None
         self.multi = self.world > 1 or bool(os.environ.get('BLUEICE_BENCH_FORCE_DIST'))
         if self.multi:
-            from blueice_amd.comm import connect
+            from blueice_amd.comm import CommInitTimeout, connect
             t = time.perf_counter()
-            self.comm = connect(ctx, backend=backend, rank=self.rank, world=self.world)
+            try:
+                self.comm = connect(ctx, backend=backend, rank=self.rank, world=self.world)
+            except CommInitTimeout as e:
+                # ncclCommInitRank never came back on some rank: this run is over.  A rank whose init thread is still
+                # inside RCCL cannot shut down in an orderly way -- leave at once, non-zero (the launcher ends the others)
+                log('rank %d/%d: %s -- giving up' % (self.rank, self.world, e))
+                sys.stderr.flush()
+                os._exit(3)
             log('rank %d/%d: communicator %s ready in %.1f s %s' % (
                 self.rank, self.world, self.comm.kind, time.perf_counter() - t, getattr(self.comm, 'fallback_reason', '')))
         self.device_gather = self.comm is not None and hasattr(self.comm, 'all_gather_device')
-        self._send = self._recv = None
+        self._send = self._recv = self._full = None
 
     @property
     def kind(self):
@@ -143,6 +155,31 @@ class Ranks:
             return local[None, :]
         return self.comm.all_gather(local)
 
+    def gather_on_device(self, n):
+        """All ranks' send[0:n] -> recv [world, n], left in HBM (RCCL on the context stream; or through the host communicator)."""
+        send, recv = self.buffers(n)
+        if self.device_gather:
+            self.comm.all_gather_device(send.ptr, recv.ptr, n)
+        elif self.comm is not None:
+            recv.from_host(self.comm.all_gather(send.to_host(np.float64, n)))
+        else:
+            recv.from_host(send.to_host(np.float64, n))
+        return recv
+
+    def full_buffer(self, n):
+        if self._full is None or self._full.nbytes < 8 * n:
+            if self._full is not None:
+                self._full.free()
+            self._full = self.ctx.device_alloc(8 * n)
+        return self._full
+
+    def agree_status(self, word, what):
+        """OR of a status word over the ranks; a launch that gave up on a partial sum anywhere fails the leg everywhere."""
+        if self.comm is not None:
+            word = int(self.comm.all_reduce(np.array([word], dtype=np.int64), 'bor')[0])
+        assert not word & 32, '%s: a launch gave up waiting for a partial sum (BI_ST_INTERNAL)' % what
+        return word
+
     def barrier(self):
         self.ctx.sync()
         if self.comm is not None:
@@ -155,9 +192,10 @@ class Ranks:
         return float(self.comm.all_reduce(np.array([float(x)]), 'max')[0])
 
     def close(self):
-        for b in (self._send, self._recv):
+        for b in (self._send, self._recv, self._full):
             if b is not None:
                 b.free()
+        self._send = self._recv = self._full = None
         if self.comm is not None:
             self.comm.close()
 
@@ -166,37 +204,57 @@ class Ranks:
 # strong-scaling legs
 # ---------------------------------------------------------------------------------------------------------
 def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
-    """A profile scan of P parameter points over the resident model (BASELINE.json configs[3]), STRONG scaling: the
-    points are dealt to the ranks by grid cell, every rank plans and evaluates its share (planning is inside the timed
-    step -- it is part of answering a scan), the shares are gathered in HBM and the full vector is assembled on
-    every rank.  Replaces the reference's Python double loop over lf(**kw) (blueice/inference.py:424-432)."""
+    """A profile scan of P parameter points over the resident model (BASELINE.json configs[3]), STRONG scaling.  One step =
+    host buffers of ALL P points in -> full result vector on every rank, everything inside the clock:
+      N > 1  every rank hands all P points to its device planner, whose (cell, dataset) sort IS the dealing: rank r
+             evaluates a contiguous, balanced range of the sorted list (cells stay together, no host pass over the
+             points); the ranks' vectors are gathered in HBM (RCCL) and one kernel scatters them into point order;
+      N = 1  plan, evaluate, one copy back;
+      Beeston-Barlow models (planned on the host): the points are dealt on the host (sharding.deal_points_by_cell),
+             also inside the step.
+    Replaces the reference's Python double loop over lf(**kw) (blueice/inference.py:424-432)."""
     from blueice_amd.sharding import deal_points_by_cell
     world, rank = ranks.world, ranks.rank
-    work = []
-    for s in range(steps + 1):                                   # step 0 is the warm-up
-        z, r = model.random_points(P, seed=900 + s)
-        deal = deal_points_by_cell(model.anchor_z, z, world)     # who evaluates what: agreed before the clock starts,
-        mine = deal[rank]                                        # and this rank's share of the input picked out
-        work.append((z, r, deal, np.ascontiguousarray(z[mine]), np.ascontiguousarray(r[mine])))
-    n_max = max(max(len(d) for d in w[2]) for w in work)
-    send, _ = ranks.buffers(n_max)
-    send.from_host(np.zeros(n_max))
-
-    moved = [0]
+    work = [model.random_points(P, seed=900 + s) for s in range(steps + 1)]      # step 0 is the warm-up
+    device_deal = world > 1 and ctx.bb_source < 0
+    stride = P if world == 1 else -(-P // world)
+    send, _ = ranks.buffers(stride)
+    send.from_host(np.zeros(stride))
+    full = ranks.full_buffer(P) if device_deal else None
+    seen = dict(bytes=0, share=[P, P])
 
     def step(w):
-        # host buffers in -> full result vector on every rank: H2D of the points, device planning, kernels, gather, assembly
-        z, r, deal, z_mine, r_mine = w
-        plan = ctx.plan(z_mine, r_mine) if len(z_mine) else None
-        if plan is not None:
-            moved[0] = plan.bytes                     # bytes the launches of this rank's share stream (work items x rows)
+        z, r = w
+        if device_deal:
+            plan = ctx.plan_share(z, r, None, rank, world)        # H2D of the points, geometry, sort, this rank's items
             plan.run(send.ptr)
-        parts = ranks.gather(n_max)
-        out = np.empty(len(z))
-        for idx, vals in zip(deal, parts):
-            out[idx] = vals[:len(idx)]
+            word = plan.status()
+            recv = ranks.gather_on_device(stride)
+            plan.unsort(recv.ptr, stride, full.ptr)
+            out = full.to_host(np.float64, P)
+            seen['share'] = [plan.n_valid // world, -(-plan.n_valid // world)]
+        elif world == 1:
+            plan = ctx.plan(z, r)
+            plan.run(send.ptr)
+            word = plan.status()
+            out = send.to_host(np.float64, P)
+        else:
+            deal = deal_points_by_cell(model.anchor_z, z, world)
+            mine = deal[rank]
+            plan = ctx.plan(z[mine], r[mine]) if len(mine) else None
+            word = 0
+            if plan is not None:
+                plan.run(send.ptr)
+                word = plan.status()
+            parts = ranks.gather(stride)
+            out = np.empty(P)
+            for idx, vals in zip(deal, parts):
+                out[idx] = vals[:len(idx)]
+            seen['share'] = [min(len(d) for d in deal), max(len(d) for d in deal)]
         if plan is not None:
+            seen['bytes'] = plan.bytes                # bytes the launches of this rank's share stream (work items x rows)
             plan.close()
+        ranks.agree_status(word, label)
         return out
 
     step(work[0])
@@ -206,20 +264,21 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
         out = step(w)
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
-    # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel): points of this rank and
-    # points another rank evaluated (every rank holds the whole tensor, so any rank can check any point)
-    z, r, deal = work[-1][:3]
-    picks = list(deal[rank][:sample]) + list(deal[(rank + 1) % world][-sample:])
+    # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel) on THIS rank: every rank holds
+    # the whole tensor, so any rank can check any point, whoever evaluated it
+    z, r = work[-1]
+    picks = np.random.default_rng(17 + rank).choice(P, size=min(P, 2 * sample), replace=False)
     worst = 0.0
     for i in picks:
         one, _ = ctx.eval(z[i], r[i])
         worst = max(worst, abs(one[0] - out[i]) / max(1.0, abs(out[i])))
     assert worst <= 1e-11, '%s: gathered scan differs from single evaluations by %.2e' % (label, worst)
     assert np.all(np.isfinite(out)), '%s: non-finite values in the gathered scan' % label
-    share = [len(d) for d in work[-1][2]]
     return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
-                ms_per_step=elapsed / steps * 1e3, points_per_rank_min_max=[min(share), max(share)],
-                sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(moved[0]), gather=ranks.kind)
+                ms_per_step=elapsed / steps * 1e3, points_per_rank_min_max=seen['share'],
+                dealing=('device planner sort, inside the step' if device_deal else
+                         ('none (one process)' if world == 1 else 'host (deal_points_by_cell), inside the step')),
+                sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(seen['bytes']), gather=ranks.kind)
 
 
 def toy_leg(ctx, ranks, model, T, steps):
@@ -274,39 +333,82 @@ def toy_leg(ctx, ranks, model, T, steps):
                 nonempty_bins_this_rank=nnz, gather=ranks.kind)
 
 
-def bb_leg(ctx_dev, steps=24):
-    """The Beeston-Barlow kernel (`k_morph_reduce<1,true,true>`) on one grid cell of configs[4]: 2^4 anchors, 6 sources,
-    50^4 bins -- all 113 stream rows of an evaluation, 5.65 GB per pass (blueice/likelihood.py:618-660)."""
-    from blueice_amd.device import DeviceContext
+def c5_leg(ctx, ranks, steps=24):
+    """configs[4] on one grid cell of its anchor grid (2^4 anchors, 6 sources, 50^4 bins, Beeston-Barlow on source 0;
+    blueice/likelihood.py:618-660), uploaded into `ctx` in place of the C2 model:
+      kernel   `k_morph_reduce<1,true,true>`, one evaluation per launch -- all 113 stream rows, 5.65 GB per pass --
+               against the HBM roofline (every rank measures, rank 0 reports);
+      scan     256 scan points in that cell, STRONG scaling over the ranks (the host planner groups 8 points per pass)."""
     from blueice_amd.synthetic import SyntheticModel
     m = SyntheticModel.named('C5-2anchor', bb_source=0)
-    ctx = DeviceContext(ctx_dev)
-    try:
-        m.upload(ctx, threads=8)
-        ctx.set_param('sparse', 0)
-        ctx.upload_counts(m.counts(dense=True))
-        z, r = m.random_points(4, seed=2)
-        plans = [ctx.plan(z[i], r[i]) for i in range(4)]
-        for i in range(8):                     # warm-up: the first passes over a freshly uploaded 4.8 GB tensor run slow
-            plans[i % 4].run()
-        ctx.sync()
-        ctx.profile(True)
-        for i in range(steps):
-            plans[i % 4].run()
-        n, ms = ctx.profile_read()
-        ctx.profile(False)
-        nbytes = plans[0].bytes
-        assert nbytes == 8 * (16 * 6 + 16 + 1) * m.B
-        gbs = nbytes * n / (ms * 1e-3) / 1e9
-        ll, st = plans[0].read()
-        for p in plans:
-            p.close()
-        return dict(workload='C5 grid cell: Beeston-Barlow, 6 sources, 2^4 anchors, 50^4 bins, one evaluation per launch',
-                    kernel='k_morph_reduce<1,true,true> (Beeston-Barlow, nontemporal loads)', bound='hbm',
-                    bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=gbs / HBM_PEAK_GBS, evals_per_s=n / (ms * 1e-3), status_bits=int(st[0]))
-    finally:
-        ctx.close()
+    m.upload(ctx, threads=8)
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(m.counts(dense=True))
+    z, r = m.random_points(4, seed=2)
+    plans = [ctx.plan(z[i], r[i]) for i in range(4)]
+    for i in range(8):                     # warm-up: the first passes over a freshly uploaded 4.8 GB tensor run slow
+        plans[i % 4].run()
+    ctx.sync()
+    ctx.profile(True)
+    for i in range(steps):
+        plans[i % 4].run()
+    n, ms = ctx.profile_read()
+    ctx.profile(False)
+    nbytes = plans[0].bytes
+    assert nbytes == 8 * (16 * 6 + 16 + 1) * m.B
+    gbs = nbytes * n / (ms * 1e-3) / 1e9
+    ll, st = plans[0].read()
+    for p in plans:
+        p.close()
+    kern = dict(workload='C5 grid cell: Beeston-Barlow, 6 sources, 2^4 anchors, 50^4 bins, one evaluation per launch',
+                kernel='k_morph_reduce<1,true,true> (Beeston-Barlow, nontemporal loads)', bound='hbm',
+                bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=gbs / HBM_PEAK_GBS, evals_per_s=n / (ms * 1e-3), status_bits=int(st[0]))
+    scan = scan_leg(ctx, ranks, m, 256, 2, 'C5 grid cell: 256 Beeston-Barlow scan points (6 sources, 2^4 anchors, 50^4 bins), '
+                    'dealt over the ranks, 8 points per 5.65 GB pass', sample=1)
+    return kern, scan
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: this process -- which has not touched the GPU, nor loaded the
+    library -- starts N fresh rank processes of this script (blueice_amd.launch sets RANK / LOCAL_RANK / WORLD_SIZE and
+    the rendezvous file), which inherit its stdout: rank 0's JSON line IS this command's output.  Exit code = the first
+    non-zero rank's."""
+    from blueice_amd import launch
+    argv = ['--nproc', str(args.gpus)]
+    if args.devices:
+        argv += ['--devices', args.devices]
+    return launch.main(argv + [os.path.abspath(__file__)] + sys.argv[1:])
+
+
+def dry_run(args):
+    """--dry: everything of an N-rank run that needs no GPU -- launch, rendezvous, dealing, gather, assembly, the JSON
+    line -- with a stand-in for the evaluation (a checksum of the point).  For the CPU test of the launch path; the
+    line says "dry": true and carries no value."""
+    from blueice_amd.comm import connect
+    from blueice_amd.sharding import deal_points_by_cell, gather_vector
+    from blueice_amd.synthetic import SyntheticModel
+    world, rank = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
+    comm = connect(backend='socket', rank=rank, world=world)
+    model = SyntheticModel.named('C2')
+    z, r = model.random_points(20000, seed=900)
+    deal = deal_points_by_cell(model.anchor_z, z, world)
+    mine = deal[rank]
+    parts = gather_vector(z[mine].sum(axis=1) + r[mine].sum(axis=1), [len(d) for d in deal], comm)
+    out = np.empty(len(z))
+    for idx, vals in zip(deal, parts):
+        out[idx] = vals
+    np.testing.assert_array_equal(out, z.sum(axis=1) + r.sum(axis=1))
+    ranks_seen = comm.all_gather(np.array([float(rank), float(os.environ.get('LOCAL_RANK', -1))]))
+    comm.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': world, 'dry': True,
+                          'steps': args.steps, 'warmup': args.warmup,
+                          'legs': {'C4': {'points': len(z), 'points_per_rank_min_max': [min(len(d) for d in deal), max(len(d) for d in deal)],
+                                          'ranks': ranks_seen[:, 0].tolist(), 'devices': ranks_seen[:, 1].tolist(), 'gather': comm.kind}}}),
+              flush=True)
+    comm.close()
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -322,7 +424,15 @@ def main():
     ap.add_argument('--no-legs', action='store_true')
     ap.add_argument('--backend', default='rccl', help="gather for N > 1: 'rccl' (direct binding) or 'socket' (host; for "
                                                       'rehearsals on a box with fewer GPUs than ranks)')
+    ap.add_argument('--devices', default=None, help='self-launched N > 1 only: comma-separated GPU index per rank '
+                                                    '(default rank r -> GPU r; "0,0" rehearses two ranks on one GPU)')
+    ap.add_argument('--dry', action='store_true', help='no GPU: launch, rendezvous, dealing and gather only (tests)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))          # before anything touches the GPU: the ranks are fresh processes
+    if args.dry:
+        sys.exit(dry_run(args))
 
     # stdout must carry exactly one JSON line: native libraries (RCCL's banner) write to fd 1 too, so fd 1 points at
     # stderr until the line is printed
@@ -333,8 +443,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     if args.gpus != world:
-        log('bench.py: --gpus %d but WORLD_SIZE=%d; N > 1 must be launched with one process per GPU '
-            '(torch.distributed.run or python -m blueice_amd.launch) -- running with %d rank(s)' % (args.gpus, world, world))
+        log('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks -- running with %d rank(s)' % (args.gpus, world, world))
 
     from blueice_amd.device import DeviceContext, default_device
     from blueice_amd.synthetic import SyntheticModel
@@ -535,14 +644,6 @@ def main():
     if rank == 0:
         result['legs'] = legs
 
-    if rank == 0 and world == 1 and not args.no_legs:
-        try:
-            result['legs']['C5-BB'] = bb_leg(ctx.device)
-            result['roofline_bb'] = {k: result['legs']['C5-BB'][k] for k in
-                                     ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'bytes_per_launch', 'avg_launch_us')}
-        except Exception as e:
-            result['legs']['C5-BB'] = {'error': repr(e)}
-
     if rank == 0 and world == 1 and not args.no_extras:
         result['extras'] = extras(ctx, model, counts, z, r, PPS, bytes_per_launch // PPS)
         ex = result['extras']
@@ -583,9 +684,18 @@ def main():
     elif rank == 0:
         result['cpu_baseline'] = None
 
-    emit(result)
+    # ---- configs[4], Beeston-Barlow: kernel roofline + strong-scaling scan on one grid cell, every N.  Last: the C5
+    # cell's tensors replace the C2 model in this rank's context (same stream, same communicator, same gather buffers)
     for p in plans:
         p.close()
+    if not args.no_legs:
+        kern, scan = c5_leg(ctx, ranks)
+        if rank == 0:
+            result['legs']['C5-BB'] = kern
+            result['legs']['C5-BB-scan'] = scan
+            result['roofline_bb'] = {k: kern[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'bytes_per_launch', 'avg_launch_us')}
+
+    emit(result)
     ranks.close()
     ctx.close()
 

@@ -1,0 +1,82 @@
+"""`python bench.py --gpus N` launches its own ranks ("Next round" 1): the parent -- before anything
+touches the GPU -- starts N fresh processes of the script, rank 0's JSON line is the command's output, and a failing
+rank fails the command.  Run here without a GPU in the bench's --dry mode (launch, rendezvous, dealing, gather, assembly,
+JSON; a checksum stands in for the evaluation), and -- marked gpu -- for real with two ranks sharing the box's one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'BLUEICE_AMD_RDZV')}
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bare_invocation_launches_n_ranks():
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry', '--steps', '2', '--warmup', '1'], env=_clean_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_line(res.stdout)
+    assert line['n_gpus'] == 2 and line['dry'] is True and line['value'] is None
+    leg = line['legs']['C4']
+    assert leg['ranks'] == [0.0, 1.0] and leg['devices'] == [0.0, 1.0]          # rank r -> GPU r
+    assert sum(leg['points_per_rank_min_max']) == leg['points']                  # both ranks' shares arrived
+
+
+def test_devices_option_and_launcher_environment():
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '3', '--dry', '--devices', '0,0,0'], env=_clean_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert _json_line(res.stdout)['legs']['C4']['devices'] == [0.0, 0.0, 0.0]
+    # under a launcher (the environment is already there) the script does NOT start ranks of its own
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--dry'], env=_clean_env(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and _json_line(res.stdout)['n_gpus'] == 1
+
+
+def test_a_failing_rank_fails_the_command():
+    """Without a GPU every rank dies in DeviceContext(): the command must end non-zero and say why -- never print a line."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip('a GPU is present')
+    except ImportError:
+        pass
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-legs', '--no-extras',
+                          '--no-cpu-baseline', '--backend', 'socket'], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert 'no CPU fallback' in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_end_to_end():
+    """The real thing on the GPU box: `bench.py --gpus 2` with both ranks on GPU 0 and the host gather (RCCL refuses two
+    ranks on one device) -- headline plus every strong-scaling leg, with the scans dealt on the device."""
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--devices', '0,0', '--backend', 'socket', '--steps', '10',
+                          '--warmup', '2'], env=_clean_env(), capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = _json_line(res.stdout)
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    legs = line['legs']
+    assert set(legs) >= {'C4', 'C4-dense', 'C3', 'C5-BB', 'C5-BB-scan'}
+    assert legs['C4']['dealing'].startswith('device planner') and legs['C4']['points'] == 10 ** 6
+    assert sum(legs['C4']['points_per_rank_min_max']) == 10 ** 6
+    assert legs['C5-BB-scan']['dealing'].startswith('host') and sum(legs['C5-BB-scan']['points_per_rank_min_max']) == 256
+    assert legs['C3']['datasets'] == 10000
+    for leg in ('C4', 'C4-dense', 'C5-BB-scan'):
+        assert legs[leg]['sample_max_rel_diff_vs_single_point_kernel'] <= 1e-11

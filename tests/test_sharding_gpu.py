@@ -181,3 +181,59 @@ def test_bin_sharded_partials_add_up(bb):
         c.close()
     np.testing.assert_allclose(parts[0] + parts[1], want, rtol=1e-12)
     full.close()
+
+
+@pytest.mark.parametrize('sparse', [0, 1])
+def test_scan_dealt_on_the_device_equals_one_plan(sparse):
+    """bi_plan_points_share / bi_plan_unsort in one process: the `world` shares of a scan, evaluated one after the other
+    on one context and 'gathered' by hand, reproduce the plain batched evaluation -- rejected points
+    (outside the anchor box, nan, negative rates) included; shares are contiguous, balanced and cover every valid point."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.set_param('sparse', sparse)
+    ctx.upload_counts(m.counts(dense=not sparse))
+    z, r = m.random_points(2999, seed=12)
+    z[5, 1] = 7.0            # outside the box
+    z[77, 0] = np.nan
+    r[300, 2] = -1.0         # unphysical
+    want, want_st = ctx.eval(z, r)
+    assert np.isneginf(want[[5, 77, 300]]).all() and np.isfinite(np.delete(want, [5, 77, 300])).all()
+    P = len(z)
+    plain = ctx.plan(z, r)
+    with pytest.raises(ValueError):                         # a plain plan is not a share
+        ctx._check(ctx._lib.bi_plan_share_info(plain._h, None, None, None))
+    plain.close()
+    for world in (2, 3, 5, 8):
+        stride = -(-P // world)
+        send = ctx.device_alloc(8 * stride)
+        recv = ctx.device_alloc(8 * stride * world)
+        full = ctx.device_alloc(8 * P)
+        recv.from_host(np.full(stride * world, np.nan))
+        spans, plans = [], []
+        for rank in range(world):
+            plan = ctx.plan_share(z, r, None, rank, world)
+            assert plan.n_valid == P - 3
+            spans.append(plan.share)
+            plan.run(send.ptr)
+            assert plan.status() & ~3 == 0                  # only the rejected points' bits
+            n = plan.share[1] - plan.share[0]
+            recv.from_host(send.to_host(np.float64, n), offset_bytes=8 * stride * rank)
+            plans.append(plan)
+        assert spans[0][0] == 0 and spans[-1][1] == P - 3 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+        plans[-1].unsort(recv.ptr, stride, full.ptr)        # any rank's plan holds the same sorted -> original map
+        got = full.to_host(np.float64, P)
+        # (a share chops a cell's points into other work items than the whole list does: equal to rounding)
+        assert np.isneginf(got[[5, 77, 300]]).all()
+        keep = np.isfinite(want)
+        np.testing.assert_allclose(got[keep], want[keep], rtol=1e-12)
+        with pytest.raises(ValueError):                     # sorted-order results are not readable as a point vector
+            plans[0].read()
+        for p in plans:
+            p.close()
+        for b in (send, recv, full):
+            b.free()
+    ctx.close()
