@@ -739,6 +739,12 @@ __global__ __launch_bounds__(kThreads) void k_status_or(const int32_t* __restric
     if ((threadIdx.x & 63) == 0 && f) atomicOr((unsigned*)out, f);
 }
 
+// a resident plan's status words are OR-ed into by every run: the "gave up" bit of one run must not outlive its report
+__global__ __launch_bounds__(kThreads) void k_status_clear(int32_t* __restrict__ status, int64_t n, int32_t mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        if (status[i] & mask) status[i] &= ~mask;
+}
+
 __global__ void k_fill_value(double* __restrict__ out, int64_t n, double v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = v;

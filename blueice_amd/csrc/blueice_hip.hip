@@ -651,6 +651,20 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     return BI_OK;
 }
 
+// BI_ST_INTERNAL has been reported for this plan: empty the mailbox, and take the bit out of the plan's (sticky) status words
+static void internal_reported(bi_ctx* c, bi_plan* plan) {
+    reset_mail(c);
+    if (!plan->P) return;
+    if (plan->host_results) {
+        int32_t* st = (int32_t*)plan->status.p;
+        for (int64_t p = 0; p < plan->P; ++p) st[p] &= ~BI_ST_INTERNAL;
+    } else {
+        hipLaunchKernelGGL(k_status_clear, dim3((unsigned)std::min<int64_t>(1024, (plan->P + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                           c->stream, (int32_t*)plan->status.p, plan->P, (int32_t)BI_ST_INTERNAL);
+        (void)hipStreamSynchronize(c->stream);
+    }
+}
+
 int bi_plan_read(bi_ctx* c, bi_plan* plan, double* out, int32_t* status) {
     if (!c || !plan) return BI_ERR_INVALID;
     if (out && plan->shared) return fail(c, BI_ERR_INVALID, "bi_plan_read: a share's results are in sorted order: gather them and call bi_plan_unsort");
@@ -662,7 +676,7 @@ int bi_plan_read(bi_ctx* c, bi_plan* plan, double* out, int32_t* status) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (status) {
         for (int64_t p = 0; p < plan->P; ++p)
-            if (status[p] & BI_ST_INTERNAL) { reset_mail(c); break; }
+            if (status[p] & BI_ST_INTERNAL) { internal_reported(c, plan); break; }
         return BI_OK;
     }
     int32_t any = 0;
@@ -694,7 +708,7 @@ int bi_plan_status(bi_ctx* c, bi_plan* plan, int32_t* status_or) {
             if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_plan_status: %s", hipGetErrorString(e));
         }
     }
-    if (any & BI_ST_INTERNAL) reset_mail(c);
+    if (any & BI_ST_INTERNAL) internal_reported(c, plan);
     if (status_or) *status_or = any;
     return BI_OK;
 }

@@ -493,7 +493,9 @@ class DeviceLogLikelihood(LogLikelihoodBase):
             scratch.close()
 
     # -- batched entry points (no counterpart in the reference) --------------------------------
-    def _batch_terms(self, points, livetime_days):
+    def _batch_terms(self, points, livetime_days, want_unit=False):
+        """-> (z [P, d], scale [P, S], prior [P]) of a dict of parameter arrays; want_unit=True adds `unit` [P, S], the
+        scale per unit rate multiplier (live-time and efficiency factors: d scale / d multiplier)."""
         names = list(points.keys())
         cols = [np.atleast_1d(np.asarray(points[n], dtype=float)) for n in names]
         P = max((len(c) for c in cols), default=1)
@@ -508,6 +510,7 @@ class DeviceLogLikelihood(LogLikelihoodBase):
             if log_prior is not None:
                 prior += _prior_of(log_prior, z[:, i])
         scale = np.ones((P, len(self.source_name_list)))
+        unit = np.ones_like(scale) if want_unit else None
         for s, name in enumerate(self.source_name_list):
             key = name + '_rate_multiplier'
             if key in names:
@@ -528,14 +531,17 @@ class DeviceLogLikelihood(LogLikelihoodBase):
                         assert np.all(self.ctx.interpolate('mus', zi) * sc == 0), "Got non-0 mus with 0 livetime?!"
             else:
                 scale = scale * (livetime_days / base)
+                if want_unit:
+                    unit = unit * (livetime_days / base)
         if True in self.source_apply_efficiency:
             for s in np.flatnonzero(self.source_apply_efficiency):
                 en = self.source_efficiency_names[s]
-                if en in names:
-                    scale[:, s] *= cols[names.index(en)]
-                elif en in defaults:
-                    scale[:, s] *= defaults[en]
-        return z, scale, prior
+                eff = cols[names.index(en)] if en in names else defaults.get(en)
+                if eff is not None:
+                    scale[:, s] *= eff
+                    if want_unit:
+                        unit[:, s] *= eff
+        return (z, scale, prior, unit) if want_unit else (z, scale, prior)
 
     @_needs_data
     def eval_points(self, points, livetime_days=None, dataset=None):
@@ -698,6 +704,49 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
                     g += gs[s] * scale[s] / settings[name]
             grads[name] = g
         return prior + ll, grads
+
+    @_needs_data
+    def values_and_gradients(self, points, livetime_days=None, dataset=None):
+        """The batched form of `value_and_gradient`: points = dict parameter name -> array [P] (as `eval_points`) ->
+        (ll [P], OrderedDict parameter name -> d ll / d parameter [P]) for every registered rate and shape parameter,
+        from ONE device call (`bi_eval_grad` over all P points).  Points outside the anchor box or with unphysical
+        rates give -inf and nan slopes.  What the batched profile-fit engine (blueice_amd.profile) advances P
+        minimisations with."""
+        z, scale, prior, unit = self._batch_terms(points, livetime_days, want_unit=True)
+        P = len(z)
+        ll, gz, gs, st = self.ctx.eval_grad(z if z.shape[1] else None, scale, dataset)
+        if np.any(st & _capi.ST_INTERNAL):
+            raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
+        if np.any(st & _BB_FLAGS):
+            raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
+        bad = (st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0
+        if np.any(st & _capi.ST_UNPHYSICAL) and self.config.get('unphysical_behaviour') == 'error':
+            raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(st & _capi.ST_UNPHYSICAL)), P))
+        out = ll + prior
+        out[bad] = -np.inf
+
+        def slope(log_prior, x):               # priors are Python callables: central differences, vectorised
+            if log_prior is None:
+                return 0.0
+            h = 1e-6 * np.maximum(1.0, np.abs(x))
+            return (_prior_of(log_prior, x + h) - _prior_of(log_prior, x - h)) / (2 * h)
+
+        grads = OrderedDict()
+        for s, name in enumerate(self.source_name_list):
+            if name in self.rate_parameters:
+                mult = np.broadcast_to(np.asarray(points.get(name + '_rate_multiplier', 1.0), dtype=float), (P,))
+                grads['%s_rate_multiplier' % name] = gs[:, s] * unit[:, s] + slope(self.rate_parameters[name], mult)
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            g = gz[:, i] + slope(log_prior, z[:, i])
+            # a shape parameter that doubles as the efficiency of some sources also scales their rates
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                if self.source_efficiency_names[s] == name:
+                    with np.errstate(all='ignore'):
+                        g = g + np.where(z[:, i] != 0, gs[:, s] * scale[:, s] / np.where(z[:, i] != 0, z[:, i], 1.0), 0.0)
+            grads[name] = g
+        for g in grads.values():
+            g[bad] = np.nan
+        return out, grads
 
     # -- toy-MC ---------------------------------------------------------------------------------
     @_needs_data

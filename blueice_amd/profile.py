@@ -1,0 +1,217 @@
+"""Batched profile fits: P independent maximisations of one likelihood advanced in lock-step on the device.
+
+The reference profiles a likelihood by running `bestfit_routine(lf, **fixed)` once per hypothesis, one scalar `lf()` call
+after the other -- the loops of `plot_likelihood_ratio` (blueice/inference.py:424-432) and the brentq search of
+`one_parameter_interval` (:332-389, 3 387 calls per limit in SURVEY.md's probe).  Here the P hypotheses are P
+problems that differ only in their fixed parameters; every iteration of the optimiser is ONE device call that returns
+value and analytic gradient for all problems still running (`lf.values_and_gradients` -> `bi_eval_grad`), and the
+optimiser's own arithmetic is a few numpy operations on [P, F] arrays (F = floating parameters, a handful).
+
+Optimiser: BFGS per problem (dense [F, F] inverse-Hessian estimates, updated together with einsum), Armijo
+backtracking -- one more device call per halving, over the problems that still need it --, box constraints by
+projection (rate multipliers >= 0 unless the source may go negative, shape parameters inside their anchor range;
+variables pinned at a bound leave the search direction).  Likelihoods without an analytic gradient (unbinned; sums)
+get central differences from batched `eval_points` calls instead.
+
+    best, ll = bestfit_batched(lf, points={'shift': grid}, s2_rate_multiplier=1.)     # arrays [len(grid)]
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .exceptions import NoOpimizationNecessary
+from .utils import is_numeric
+
+__all__ = ['bestfit_batched', 'batched_minimize', 'BatchObjective', 'supports_batched_fits']
+
+
+def supports_batched_fits(lf):
+    return hasattr(lf, 'eval_points') and hasattr(lf, 'get_bounds')
+
+
+class BatchObjective:
+    """f(x [n, F], rows [n]) -> (-ll [n], d(-ll)/dx [n, F]) for problems `rows` of P, whose fixed parameters are
+    `points` (name -> array [P]) and `fixed` (name -> scalar)."""
+
+    def __init__(self, lf, float_names, points, fixed, livetime_days=None):
+        self.lf, self.names = lf, list(float_names)
+        self.points = {k: np.asarray(v, dtype=float) for k, v in points.items()}
+        self.fixed = dict(fixed)
+        self.livetime_days = livetime_days
+        self.analytic = bool(getattr(lf, 'supports_gradient', False)) and hasattr(lf, 'values_and_gradients')
+        self.calls = self.evaluations = 0
+
+    def _points_of(self, x, rows):
+        pts = {k: v[rows] for k, v in self.points.items()}
+        pts.update(self.fixed)
+        for j, n in enumerate(self.names):
+            pts[n] = x[:, j]
+        return pts
+
+    def __call__(self, x, rows):
+        self.calls += 1
+        if self.analytic:
+            self.evaluations += len(x)
+            ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days)
+            g = np.stack([np.broadcast_to(grads[n], ll.shape) for n in self.names], axis=1)
+            return -ll, -g
+        # central differences, all 2F + 1 stencil points of all problems in one batched call
+        n, F = x.shape
+        h = 1e-6 * np.maximum(1.0, np.abs(x))
+        stencil = np.repeat(x[None], 2 * F + 1, axis=0)               # [2F+1, n, F]
+        for j in range(F):
+            stencil[1 + 2 * j, :, j] += h[:, j]
+            stencil[2 + 2 * j, :, j] -= h[:, j]
+        pts = self._points_of(stencil.reshape(-1, F), np.tile(rows, 2 * F + 1))
+        self.evaluations += len(stencil) * n
+        ll = np.asarray(self.lf.eval_points(pts, livetime_days=self.livetime_days)).reshape(2 * F + 1, n)
+        g = np.empty((n, F))
+        for j in range(F):
+            up, dn = ll[1 + 2 * j], ll[2 + 2 * j]
+            both = np.isfinite(up) & np.isfinite(dn)
+            with np.errstate(all='ignore'):                            # at a bound: the one-sided difference
+                g[:, j] = np.where(both, (up - dn) / (2 * h[:, j]),
+                                   np.where(np.isfinite(up), (up - ll[0]) / h[:, j], (ll[0] - dn) / h[:, j]))
+        return -ll[0], -g
+
+
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=40):
+    """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
+    lo / hi [F]: box (+-inf = none).  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
+    gtol), info['stalled'] [P] (no descent step found: a kink of the morph or rounding), info['iterations'],
+    info['calls'] (device launches)."""
+    x = np.clip(np.array(x0, dtype=float), lo, hi)
+    P, F = x.shape
+    rows_all = np.arange(P)
+    f, g = fun(x, rows_all)
+    calls = 1
+    eye = np.eye(F)
+    H = np.broadcast_to(eye, (P, F, F)).copy()          # inverse-Hessian estimates
+    fresh = np.ones(P, dtype=bool)                       # H is still the (unscaled) identity
+    done = ~np.isfinite(f)                               # nothing to descend from
+    failed = done.copy()
+    stalled = np.zeros(P, dtype=bool)
+    converged = np.zeros(P, dtype=bool)
+    at_lo = lambda xx: xx <= lo
+    at_hi = lambda xx: xx >= hi
+    it = 0
+    for it in range(1, max_iter + 1):
+        blocked = (at_lo(x) & (g > 0)) | (at_hi(x) & (g < 0))       # moving against the gradient would leave the box
+        pg = np.where(blocked, 0.0, g)
+        converged |= ~done & (np.max(np.abs(pg), axis=1, initial=0.0) <= gtol)
+        done |= converged
+        act = np.flatnonzero(~done)
+        if not len(act):
+            break
+        ga, free = g[act], ~blocked[act]
+        d = -np.einsum('pij,pj->pi', H[act], ga * free) * free
+        slope = np.sum(d * ga, axis=1)
+        reset = ~(slope < 0) | fresh[act]
+        if np.any(reset):                                            # steepest descent, first step of length ~1 in x
+            pga = pg[act][reset]
+            d[reset] = -pga / np.maximum(1.0, np.sum(np.abs(pga), axis=1, keepdims=True))
+            H[act[reset]] = eye
+            fresh[act[reset]] = True
+            slope = np.sum(d * ga, axis=1)
+        alpha = np.ones(len(act))
+        xa, fa = x[act], f[act]
+        todo = np.arange(len(act))
+        acc_x, acc_f, acc_g = xa.copy(), fa.copy(), ga.copy()
+        accepted = np.zeros(len(act), dtype=bool)
+        for _ in range(max_halvings):
+            xt = np.clip(xa[todo] + alpha[todo, None] * d[todo], lo, hi)
+            ft, gt = fun(xt, act[todo])
+            calls += 1
+            with np.errstate(invalid='ignore'):
+                ok = np.isfinite(ft) & (ft <= fa[todo] + c1 * np.sum(ga[todo] * (xt - xa[todo]), axis=1)) & \
+                     np.all(np.isfinite(gt), axis=1)
+            hit = todo[ok]
+            acc_x[hit], acc_f[hit], acc_g[hit] = xt[ok], ft[ok], gt[ok]
+            accepted[hit] = True
+            # quadratic interpolation of the step where the trial was finite, halving otherwise; kept in [0.1, 0.5] alpha
+            miss = todo[~ok]
+            if not len(miss):
+                break
+            a_m, f_t = alpha[miss], ft[~ok]
+            with np.errstate(all='ignore'):
+                quad = -slope[miss] * a_m ** 2 / (2.0 * (f_t - fa[miss] - slope[miss] * a_m))
+            alpha[miss] = np.where(np.isfinite(quad), np.clip(quad, 0.1 * a_m, 0.5 * a_m), 0.5 * a_m)
+            todo = miss
+            if np.all(alpha[todo] * np.max(np.abs(d[todo]), axis=1) < 1e-15 * np.maximum(1.0, np.max(np.abs(xa[todo]), axis=1))):
+                break
+        # problems without an acceptable step: once more from a fresh H; if that was a fresh H already, they are where
+        # they can get (a kink between two grid cells of the morph, or the rounding floor of the likelihood)
+        lost = ~accepted
+        again = lost & ~fresh[act]
+        H[act[again]] = eye
+        fresh[act[again]] = True
+        gone = lost & ~again
+        stalled[act[gone]] = True
+        done[act[gone]] = True
+        # BFGS update of the others
+        w = np.flatnonzero(accepted)
+        if len(w):
+            s = acc_x[w] - xa[w]
+            y = acc_g[w] - ga[w]
+            sy = np.sum(s * y, axis=1)
+            good = sy > 1e-10 * np.sqrt(np.sum(s * s, axis=1) * np.sum(y * y, axis=1))
+            rows = act[w]
+            first = fresh[rows] & good
+            if np.any(first):                                        # scale the first estimate (Nocedal & Wright 6.20)
+                yy = np.sum(y[first] * y[first], axis=1)
+                H[rows[first]] = eye * (sy[first] / yy)[:, None, None]
+            fresh[rows[good]] = False
+            if np.any(good):
+                sg, yg, rho = s[good], y[good], 1.0 / sy[good]
+                Hg = H[rows[good]]
+                Hy = np.einsum('pij,pj->pi', Hg, yg)
+                yHy = np.sum(yg * Hy, axis=1)
+                Hg = Hg - rho[:, None, None] * (sg[:, :, None] * Hy[:, None, :] + Hy[:, :, None] * sg[:, None, :]) + \
+                     ((rho * rho * yHy + rho)[:, None, None]) * (sg[:, :, None] * sg[:, None, :])
+                H[rows[good]] = Hg
+            x[rows], f[rows], g[rows] = acc_x[w], acc_f[w], acc_g[w]
+    return x, f, dict(converged=converged, stalled=stalled, failed=failed, iterations=it, calls=calls)
+
+
+def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, max_iter=200, return_info=False, **fixed):
+    """Maximise `lf` over its floating parameters for P hypotheses at once.
+
+    points: dict parameter name -> array [P] of values held fixed per problem (the scan grid / the hypotheses);
+    fixed (kwargs): parameters held at one value in every problem; everything else floats, as in `bestfit_scipy`
+    (rate multipliers first, guess 1; then shape parameters, guess = base value; blueice/inference.py:79-102).
+    guess: dict name -> scalar or array [P] (e.g. the neighbouring hypothesis' solution).
+    -> (OrderedDict name -> fitted values [P], max log likelihood [P]) [, info]."""
+    points = {} if points is None else {k: np.atleast_1d(np.asarray(v, dtype=float)) for k, v in points.items()}
+    P = max([len(v) for v in points.values()] + [1])
+    points = {k: np.broadcast_to(v, (P,)) for k, v in points.items()}
+    guess = guess or {}
+    names, x0, lo, hi = [], [], [], []
+    for src in lf.rate_parameters:
+        key = '%s_rate_multiplier' % src
+        if key in fixed or key in points:
+            continue
+        names.append(key)
+        x0.append(np.broadcast_to(np.asarray(guess.get(key, 1.0), dtype=float), (P,)))
+        b = lf.get_bounds(key)
+        lo.append(b[0]); hi.append(b[1])
+    for key, (_, _, base_value) in lf.shape_parameters.items():
+        if key in fixed or key in points:
+            continue
+        gval = guess.get(key)
+        if gval is None:
+            gval = lf.pdf_base_config.get(key)
+            if not is_numeric(gval):
+                gval = base_value
+        names.append(key)
+        x0.append(np.broadcast_to(np.asarray(gval, dtype=float), (P,)))
+        b = lf.get_bounds(key)
+        lo.append(b[0]); hi.append(b[1])
+    if not names:
+        raise NoOpimizationNecessary("There are no parameters to fit, no optimization is necessary")
+    obj = BatchObjective(lf, names, points, fixed, livetime_days)
+    x, f, info = batched_minimize(obj, np.stack(x0, axis=1), np.array(lo, dtype=float), np.array(hi, dtype=float),
+                                  gtol=gtol, max_iter=max_iter)
+    info['evaluations'] = obj.evaluations
+    info['analytic_gradient'] = obj.analytic
+    best = OrderedDict((n, x[:, j].copy()) for j, n in enumerate(names))
+    return (best, -f, info) if return_info else (best, -f)

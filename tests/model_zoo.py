@@ -355,6 +355,23 @@ def fit_c1_like(ns):
     return morph_lf(ns, rng, 2, space, OrderedDict(shift=(-1., 0., 1.)), 4000, 300)
 
 
+def profile_d2(ns):
+    """Three sources, two shape parameters (non-uniform anchors), 2-d space: profiled scans with FOUR floating nuisances
+    (two rates, two shapes) that cross grid-cell boundaries of the morph."""
+    rng = np.random.default_rng(31)
+    space = [['x', np.linspace(-3, 3, 13)], ['y', np.linspace(0, 5, 9)]]
+    return morph_lf(ns, rng, 3, space, OrderedDict(shift=(-1., -0.25, 0.5, 2.), stretch=(0., 1., 4.)), 6000, 700)
+
+
+# the profiled scans whose per-point maxima tests/golden/make_golden_profile.py records from the reference's own
+# bestfit_scipy (blueice/inference.py:131-178 under the loops of :392-443): name -> (builder, scan space, fixed kwargs)
+PROFILE_SCANS = OrderedDict([
+    ('c1_shift_1001', (fit_c1_like, [('shift', np.linspace(-1., 1., 1001))], {})),
+    ('c1_rate_x_shift_24x24', (fit_c1_like, [('s0_rate_multiplier', np.linspace(0.2, 3., 24)), ('shift', np.linspace(-0.95, 0.95, 24))], {})),
+    ('d2_rate_160', (profile_d2, [('s0_rate_multiplier', np.linspace(0.05, 4., 160))], {'s2_rate_multiplier': 1.})),
+])
+
+
 # ---------------------------------------------------------------------------------------------
 # unbinned cases (SURVEY.md section 8f-4): analytic Gaussian sources scored at fixed events
 # ---------------------------------------------------------------------------------------------
