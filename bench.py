@@ -816,10 +816,35 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
     t = time.perf_counter()
     lf.bestfit_scipy(use_gradient=True, **fixed)
     ex['api_bestfit_scipy_with_gradient_s'] = time.perf_counter() - t
+    lf.bestfit_scipy(batch_stencil=False, **fixed)
+    t = time.perf_counter()
+    lf.bestfit_scipy(batch_stencil=False, **fixed)          # the reference's stream of scalar calls (round 2's number)
+    ex['api_bestfit_scipy_scalar_stream_s'] = time.perf_counter() - t
     t = time.perf_counter()
     for i in range(300):
         lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
     ex['api_call_us'] = (time.perf_counter() - t) / 300 * 1e6
+    # profiled scan (blueice/inference.py:392-443 with floating nuisances): 1024 hypotheses of shape0, at each of them the
+    # first rate and the two other shape parameters fitted -- all 1024 fits advance together on the batched engine
+    grid = np.linspace(-1.9, 1.9, 1024)
+    lf.bestfit_batched(points={'shape0': grid[:64]}, **fixed)
+    t = time.perf_counter()
+    _, prof_ll, info = lf.bestfit_batched(points={'shape0': grid}, return_info=True, **fixed)
+    dt = time.perf_counter() - t
+    ex['api_profiled_scan_1024_points_s'] = dt
+    ex['api_profiled_points_per_s'] = len(grid) / dt
+    ex['api_profiled_scan_device_calls'] = int(info['calls'])
+    ex['api_profiled_scan_evaluations'] = int(info['evaluations'])
+    ex['api_profiled_scan_converged_fraction'] = float(np.mean(info['converged'] | info['stalled']))
+    k = int(np.argmax(prof_ll))
+    t = time.perf_counter()
+    _, one = lf.bestfit_scipy(use_gradient=True, shape0=float(grid[k]), **fixed)
+    ex['api_profiled_point_sequential_fit_s'] = time.perf_counter() - t       # what ONE of those fits costs on its own
+    assert abs(one - prof_ll[k]) <= 1e-6 * abs(one), (one, prof_ll[k])
+    t = time.perf_counter()
+    up = lf.one_parameter_interval('s0_rate_multiplier', bound=3.0, kind='upper', confidence_level=0.9, **fixed)
+    ex['api_upper_limit_s'] = time.perf_counter() - t
+    ex['api_upper_limit_value'] = up
     ex['api_bestfit_max_loglikelihood'] = ll
     # template building: the binning of one source's Monte Carlo sample (10^6 events, 3 dimensions, 100^3 bins) -- what
     # prepare() does once per source and anchor model (blueice/source.py:287-299)

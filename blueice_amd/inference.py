@@ -2,8 +2,13 @@
 (blueice/inference.py:57-178) plus a batched `best_anchor` (:34-54).
 
 These only need `lf(**kwargs) -> float`, `lf.rate_parameters`, `lf.shape_parameters`,
-`lf.get_bounds`, `lf.pdf_base_config`; scipy.optimize is used as is.  iminuit / emcee drivers,
-intervals and plotting are out of scope.
+`lf.get_bounds`, `lf.pdf_base_config`; scipy.optimize is used as is.  iminuit / emcee drivers and
+plotting are out of scope.
+
+Profiled quantities -- `likelihood_ratio_scan` with floating nuisances, `one_parameter_interval` -- run on the batched
+profile-fit engine (blueice_amd.profile: all hypotheses advance together, one device call per optimiser iteration)
+whenever the likelihood offers batched evaluation; a user-supplied `bestfit_routine` keeps the reference's sequential
+loops (blueice/inference.py:332-443).
 """
 from collections import OrderedDict
 from copy import deepcopy
@@ -13,9 +18,11 @@ from scipy import stats
 from scipy.optimize import brentq, minimize
 
 from .exceptions import NoOpimizationNecessary, OptimizationFailed
+from .profile import bestfit_batched, supports_batched_fits
 from .utils import is_numeric
 
-__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'one_parameter_interval', 'likelihood_ratio_scan']
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'one_parameter_interval',
+           'likelihood_ratio_scan']
 
 
 def best_anchor(lf):
@@ -32,11 +39,17 @@ def best_anchor(lf):
     return dict(zip(names, anchors[int(np.argmax(results))]))
 
 
-def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, with_gradient=False, **kwargs):
+_FD_STEP = float(np.finfo(np.float64).eps) ** 0.5          # scipy.optimize._numdiff: relative step of '2-point' differences
+
+
+def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, with_gradient=False,
+                   stencil_respects_bounds=False, **kwargs):
     """-> (f(x), names, guesses, bounds) over the parameters not fixed through kwargs.
     Rate multipliers come first (guess 1, bounds (0, None)), then shape parameters (bounds from the
-    anchors, guess = base setting).  with_gradient=True (extension): f returns (value, gradient) from one
-    device pass (`lf.value_and_gradient`), for `scipy.optimize.minimize(..., jac=True)`."""
+    anchors, guess = base setting).  with_gradient (extensions, both for `scipy.optimize.minimize(..., jac=True)`):
+    True -> f returns (value, analytic gradient) from one device pass (`lf.value_and_gradient`);
+    'stencil' -> f returns (value, scipy's forward-difference gradient), the F + 1 stencil points evaluated in ONE
+    batched device call (`lf.eval_points`)."""
     guess = guess or {}
     names, guesses, bounds = [], [], []
     for src in lf.rate_parameters:
@@ -77,28 +90,65 @@ def make_objective(lf, guess=None, minus=True, rates_in_log_space=False, with_gr
             g = np.zeros(len(names))
         return value * sign, g * sign
 
+    def objective_with_stencil(args):
+        """Value AND scipy's own forward-difference gradient from ONE batched device call: scipy's default minimiser
+        differences the objective numerically, F + 1 scalar calls per gradient (blueice/inference.py:111-124,153-155 via
+        scipy.optimize._numdiff); the F + 1 stencil points are independent, so they go to `lf.eval_points` together --
+        same points (scipy's step sqrt(eps) * sign(x) * max(1, |x|), turned around at an upper bound), same
+        differences, one launch in which the points of a grid cell share one pass over its templates."""
+        args = np.asarray(args, dtype=float)
+        F = len(args)
+        h = _FD_STEP * np.where(args >= 0, 1.0, -1.0) * np.maximum(1.0, np.abs(args))
+        for j, (lo_j, hi_j) in enumerate(stencil_bounds):
+            if hi_j is not None and args[j] + h[j] > hi_j:
+                h[j] = -abs(h[j])
+            elif lo_j is not None and args[j] + h[j] < lo_j:
+                h[j] = abs(h[j])
+        pts = np.repeat(args[None, :], F + 1, axis=0)
+        pts[np.arange(1, F + 1), np.arange(F)] += h
+        call = {n: (10 ** pts[:, j] if lg else pts[:, j]) for j, (n, lg) in enumerate(zip(names, log_rate))}
+        call.update(kwargs)
+        vals = np.asarray(lf.eval_points(call), dtype=float) * sign
+        with np.errstate(invalid='ignore'):
+            grad = (vals[1:] - vals[0]) / ((args + h) - args)
+        return vals[0], grad
+
+    # bounds the stencil must respect: only those the minimiser is told about (pass_bounds_to_minimizer); without them
+    # scipy steps blindly, and so does this
+    stencil_bounds = [(None, None)] * len(names) if not stencil_respects_bounds else \
+        [(None if b[0] in (None, -np.inf) else b[0], None if b[1] in (None, np.inf) else b[1]) for b in bounds]
+    if with_gradient == 'stencil':
+        return objective_with_stencil, names, np.array(guesses), bounds
     return (objective_with_gradient if with_gradient else objective), names, np.array(guesses), bounds
 
 
 def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bounds_to_minimizer=False,
-                  use_gradient=False, **kwargs):
+                  use_gradient=False, batch_stencil=True, **kwargs):
     """Maximise lf over its floating parameters -> (OrderedDict name -> value, max log likelihood).
     scipy's default minimizer first, Nelder-Mead as the fallback, OptimizationFailed after that.
     use_gradient=True (extension): hand scipy the analytic gradient computed in the same device pass as
-    the value instead of letting it difference the objective numerically (n_parameters + 1 calls per step)."""
+    the value instead of letting it difference the objective numerically (n_parameters + 1 calls per step).
+    batch_stencil (default on, when the likelihood evaluates batches): scipy still gets its own forward differences,
+    but the n_parameters + 1 points behind each of them are evaluated in one device call (`make_objective`,
+    with_gradient='stencil'); batch_stencil=False is the reference's stream of scalar calls."""
     minimize_kwargs = minimize_kwargs or {}
     use_gradient = use_gradient and bool(getattr(lf, 'supports_gradient', False))
+    # scipy's gradient-based default methods difference the objective numerically: hand them the same differences, with
+    # the stencil evaluated as one batch (not for methods that take no gradient, nor when the caller brings a jac)
+    stencil = batch_stencil and not use_gradient and hasattr(lf, 'eval_points') and 'jac' not in minimize_kwargs and \
+        str(minimize_kwargs.get('method', 'BFGS')).lower() in ('bfgs', 'l-bfgs-b', 'cg', 'slsqp', 'tnc')
+    mode = dict(with_gradient=True) if use_gradient else \
+        (dict(with_gradient='stencil', stencil_respects_bounds=pass_bounds_to_minimizer) if stencil else {})
     try:
-        f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space,
-                                                    **(dict(kwargs, with_gradient=True) if use_gradient else kwargs))
+        f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space, **dict(kwargs, **mode))
     except NoOpimizationNecessary:
         return {}, lf(**kwargs)
     use_bounds = bounds if pass_bounds_to_minimizer else None
-    res = minimize(f, guess, bounds=use_bounds, **(dict(minimize_kwargs, jac=True) if use_gradient else minimize_kwargs))
+    res = minimize(f, guess, bounds=use_bounds, **(dict(minimize_kwargs, jac=True) if mode else minimize_kwargs))
     if not res.success:
         retry = deepcopy(minimize_kwargs)
         retry.pop('method', None)
-        if use_gradient:
+        if mode:
             f, names, guess, bounds = lf.make_objective(minus=True, rates_in_log_space=rates_in_log_space, **kwargs)
         res = minimize(f, guess, bounds=use_bounds, method='Nelder-Mead', **retry)
         if not res.success:
@@ -110,34 +160,110 @@ def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bound
     return out, -res.fun
 
 
+def _first_crossing(tfun, a, b, xtol=1e-11, points_per_round=16, max_rounds=12):
+    """The root of t between a and b that lies nearest to a, by rounds of batched evaluations: every round evaluates a
+    fan of hypotheses inside the current bracket in ONE call of tfun(h [n]) -> t [n] -- uniformly spaced at first, then
+    half of them clustered around the secant estimate (t is smooth) -- and keeps the first sign change seen from a.
+    Like brentq, raises ValueError when t(a) and t(b) have the same sign."""
+    ta, tb = tfun(np.array([a, b], dtype=float))
+    if ta == 0:
+        return float(a)
+    if tb == 0:
+        return float(b)
+    if not np.isfinite(ta) or not np.isfinite(tb) or np.sign(ta) == np.sign(tb):
+        raise ValueError("f(a) and f(b) must have different signs")
+    xs, ts = np.array([a, b], dtype=float), np.array([ta, tb], dtype=float)
+    K = points_per_round
+    for rnd in range(max_rounds):
+        (lo, hi), (tl, th) = xs, ts
+        if abs(hi - lo) <= xtol * max(1.0, abs(lo), abs(hi)):
+            break
+        fan = np.linspace(lo, hi, K + 2)[1:-1]
+        if rnd >= 1:
+            secant = lo - tl * (hi - lo) / (th - tl)
+            steps = abs(hi - lo) * 0.5 ** np.arange(3, 3 + 3 * (K // 4), 3)
+            near = secant + np.concatenate([-steps, [0.0], steps])
+            near = near[(near > min(lo, hi)) & (near < max(lo, hi))]
+            fan = np.unique(np.concatenate([np.linspace(lo, hi, K // 2 + 2)[1:-1], near]))
+            if hi < lo:
+                fan = fan[::-1]
+        allx = np.concatenate([[lo], fan, [hi]])
+        allt = np.concatenate([[tl], tfun(fan), [th]])
+        k = np.flatnonzero(np.sign(allt[1:]) != np.sign(allt[0]))[0]          # first sign change seen from a
+        xs, ts = allx[k:k + 2], allt[k:k + 2]
+        if ts[1] == 0:
+            return float(xs[1])
+    (lo, hi), (tl, th) = xs, ts
+    return float(lo - tl * (hi - lo) / (th - tl))
+
+
 def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper', bestfit_routine=None,
                            t_ppf=None, **kwargs):
     """Profile-likelihood interval on parameter `target` (reference: blueice/inference.py:332-389).
     kind 'upper' / 'lower': `bound` is the far end of the line search; 'central': a 2-tuple.
     The test statistic 2 (max logL - logL profiled at the hypothesis) is compared with
-    norm.ppf(quantile)**2 (Wilks) or with t_ppf(hypothesis, quantile); the crossing is found with brentq.
-    Every profile point is one nested fit, i.e. a stream of single-point device calls."""
-    fit = bestfit_routine or bestfit_scipy
+    norm.ppf(quantile)**2 (Wilks) or with t_ppf(hypothesis, quantile); the crossing is the one the reference's brentq
+    search finds.  With a likelihood that evaluates batches (and no bestfit_routine of the caller's) the search runs on
+    the batched profile-fit engine: every round profiles a fan of hypotheses in lock-step on the device (a handful of
+    rounds of ~16 fits, each a few dozen device calls) instead of brentq's chain of nested sequential fits (3 387 scalar
+    likelihood calls per limit in SURVEY.md's probe); otherwise the reference's loop."""
     if target is None:
         target = lf.source_list[-1] + '_rate_multiplier'
-    best, max_ll = fit(lf, **kwargs)
+    batched = bestfit_routine is None and supports_batched_fits(lf)
+    fit = bestfit_routine or bestfit_scipy
+    if batched:
+        try:
+            best, ll = bestfit_batched(lf, **kwargs)
+            best, max_ll = {k: float(v[0]) for k, v in best.items()}, float(ll[0])
+        except NoOpimizationNecessary:
+            batched = False
+    if not batched:
+        best, max_ll = fit(lf, **kwargs)
     global_best = best[target]
 
+    def critical_of(hypothesis, quantile):
+        return stats.norm.ppf(quantile) ** 2 if t_ppf is None else t_ppf(hypothesis, quantile)
+
+    def one_sided_ok(hypothesis):
+        return (kind == 'upper' and hypothesis <= global_best) or (kind == 'lower' and hypothesis >= global_best)
+
     def t(hypothesis, quantile):
-        critical = stats.norm.ppf(quantile) ** 2 if t_ppf is None else t_ppf(hypothesis, quantile)
-        one_sided_ok = (kind == 'upper' and hypothesis <= global_best) or (kind == 'lower' and hypothesis >= global_best)
-        if one_sided_ok:
+        critical = critical_of(hypothesis, quantile)
+        if one_sided_ok(hypothesis):
             return 0 - critical
         _, ll = fit(lf, **dict(kwargs, **{target: hypothesis}))
         return 2 * (max_ll - ll) - critical
 
+    def t_batched(quantile):
+        nuisances = [k for k in best if k != target]
+
+        def tfun(hs):
+            hs = np.asarray(hs, dtype=float)
+            crit = np.array([critical_of(h, quantile) for h in hs])
+            out = 0.0 - crit
+            need = np.array([not one_sided_ok(h) for h in hs])
+            if np.any(need):
+                if nuisances:                       # start every hypothesis from the global best fit's nuisances
+                    guess = {k: np.full(int(need.sum()), best[k]) for k in nuisances}
+                    _, ll = bestfit_batched(lf, points={target: hs[need]}, guess=guess, **kwargs)
+                else:                               # nothing left to profile: plain evaluations
+                    ll = np.asarray(lf.eval_points(dict(kwargs, **{target: hs[need]})))
+                out[need] = 2 * (max_ll - ll) - crit[need]
+            return out
+        return tfun
+
+    def search(a, b, quantile):
+        if batched:
+            return _first_crossing(t_batched(quantile), a, b)
+        return brentq(t, a, b, args=(quantile,))
+
     if kind == 'central':
-        return (brentq(t, bound[0], global_best, args=((1 - confidence_level) / 2,)),
-                brentq(t, global_best, bound[1], args=(1 - (1 - confidence_level) / 2,)))
+        return (search(bound[0], global_best, (1 - confidence_level) / 2),
+                search(global_best, bound[1], 1 - (1 - confidence_level) / 2))
     if kind == 'lower':
-        return brentq(t, bound, global_best, args=(1 - confidence_level,))
+        return search(bound, global_best, 1 - confidence_level)
     if kind == 'upper':
-        return brentq(t, global_best, bound, args=(confidence_level,))
+        return search(global_best, bound, confidence_level)
     raise ValueError("kind must be 'upper', 'lower' or 'central'")
 
 
@@ -145,21 +271,25 @@ def likelihood_ratio_scan(lf, *space, bestfit_routine=None, **kwargs):
     """-log likelihood ratio over a 1-d or 2-d grid of parameter values: the numbers behind the reference's
     `plot_likelihood_ratio` (blueice/inference.py:392-443) without the plotting.
     space: (name, values) tuples.  Parameters given in kwargs are fixed, all others are fitted at every grid
-    point; when nothing is left to fit the whole grid is ONE batched device call (`lf.eval_points`).
-    Returns an array of shape [len(values_0)(, len(values_1))], best point = 0."""
+    point.  When nothing is left to fit the whole grid is ONE batched device call (`lf.eval_points`); with floating
+    nuisances the grid points are profiled together on the batched fit engine (blueice_amd.profile: one device call per
+    optimiser iteration over the whole grid) -- unless the caller brings a `bestfit_routine`, which is then run point by
+    point as the reference does.  Returns an array of shape [len(values_0)(, len(values_1))], best point = 0."""
     if not 1 <= len(space) <= 2:
         raise ValueError("Can't handle %d dimensions" % len(space))
-    fit = bestfit_routine or bestfit_scipy
     names = [n for n, _ in space]
     grids = np.meshgrid(*[np.asarray(v, dtype=float) for _, v in space], indexing='ij')
     floating = [p + '_rate_multiplier' for p in lf.rate_parameters if p + '_rate_multiplier' not in kwargs] + \
                [p for p in lf.shape_parameters if p not in kwargs]
     floating = [p for p in floating if p not in names]
+    pts = {n: g.ravel() for n, g in zip(names, grids)}
     if not floating and hasattr(lf, 'eval_points'):
-        pts = {n: g.ravel() for n, g in zip(names, grids)}
         pts.update({k: v for k, v in kwargs.items()})
         ll = np.asarray(lf.eval_points(pts)).reshape(grids[0].shape)
+    elif floating and bestfit_routine is None and supports_batched_fits(lf):
+        ll = bestfit_batched(lf, points=pts, **kwargs)[1].reshape(grids[0].shape)
     else:
+        fit = bestfit_routine or bestfit_scipy
         ll = np.empty(grids[0].shape)
         for idx in np.ndindex(*grids[0].shape):
             ll[idx] = fit(lf, **dict(kwargs, **{n: float(g[idx]) for n, g in zip(names, grids)}))[1]

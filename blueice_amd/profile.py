@@ -7,7 +7,7 @@ problems that differ only in their fixed parameters; every iteration of the opti
 value and analytic gradient for all problems still running (`lf.values_and_gradients` -> `bi_eval_grad`), and the
 optimiser's own arithmetic is a few numpy operations on [P, F] arrays (F = floating parameters, a handful).
 
-Optimiser: BFGS per problem (dense [F, F] inverse-Hessian estimates, updated together with einsum), Armijo
+Optimiser: BFGS per problem (dense [F, F] Hessian estimates, updated together with einsum, solved together), Armijo
 backtracking -- one more device call per halving, over the problems that still need it --, box constraints by
 projection (rate multipliers >= 0 unless the source may go negative, shape parameters inside their anchor range;
 variables pinned at a bound leave the search direction).  Likelihoods without an analytic gradient (unbinned; sums)
@@ -75,23 +75,24 @@ class BatchObjective:
         return -ll[0], -g
 
 
-def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=40):
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=40, ftol=1e-15):
     """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
     lo / hi [F]: box (+-inf = none).  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
-    gtol), info['stalled'] [P] (no descent step found: a kink of the morph or rounding), info['iterations'],
-    info['calls'] (device launches)."""
+    gtol, or two successive steps that lowered f by less than ftol * max(1, |f|): the rounding floor),
+    info['stalled'] [P] (no descent step found: a kink of the morph), info['iterations'], info['calls'] (device launches)."""
     x = np.clip(np.array(x0, dtype=float), lo, hi)
     P, F = x.shape
     rows_all = np.arange(P)
     f, g = fun(x, rows_all)
     calls = 1
     eye = np.eye(F)
-    H = np.broadcast_to(eye, (P, F, F)).copy()          # inverse-Hessian estimates
-    fresh = np.ones(P, dtype=bool)                       # H is still the (unscaled) identity
+    B = np.broadcast_to(eye, (P, F, F)).copy()          # Hessian estimates (direct BFGS form: a pinned variable can be cut out exactly)
+    fresh = np.ones(P, dtype=bool)                       # B is still the (unscaled) identity
     done = ~np.isfinite(f)                               # nothing to descend from
     failed = done.copy()
     stalled = np.zeros(P, dtype=bool)
     converged = np.zeros(P, dtype=bool)
+    flat = np.zeros(P, dtype=np.int32)                   # successive steps without a measurable decrease
     at_lo = lambda xx: xx <= lo
     at_hi = lambda xx: xx >= hi
     it = 0
@@ -104,13 +105,20 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
         if not len(act):
             break
         ga, free = g[act], ~blocked[act]
-        d = -np.einsum('pij,pj->pi', H[act], ga * free) * free
+        # quasi-Newton step in the subspace of the free variables: rows / columns of the pinned ones replaced by identity
+        # (the sub-block of the Hessian estimate is inverted -- the sub-block of an inverse estimate would not be the same)
+        pair = free[:, :, None] & free[:, None, :]
+        Bm = np.where(pair, B[act], eye)
+        try:
+            d = -np.linalg.solve(Bm, (ga * free)[:, :, None])[:, :, 0] * free
+        except np.linalg.LinAlgError:
+            d = np.zeros_like(ga)
         slope = np.sum(d * ga, axis=1)
-        reset = ~(slope < 0) | fresh[act]
+        reset = ~(slope < 0) | fresh[act] | ~np.all(np.isfinite(d), axis=1)
         if np.any(reset):                                            # steepest descent, first step of length ~1 in x
             pga = pg[act][reset]
             d[reset] = -pga / np.maximum(1.0, np.sum(np.abs(pga), axis=1, keepdims=True))
-            H[act[reset]] = eye
+            B[act[reset]] = eye
             fresh[act[reset]] = True
             slope = np.sum(d * ga, axis=1)
         alpha = np.ones(len(act))
@@ -139,11 +147,11 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             todo = miss
             if np.all(alpha[todo] * np.max(np.abs(d[todo]), axis=1) < 1e-15 * np.maximum(1.0, np.max(np.abs(xa[todo]), axis=1))):
                 break
-        # problems without an acceptable step: once more from a fresh H; if that was a fresh H already, they are where
+        # problems without an acceptable step: once more from a fresh B; if that was a fresh B already, they are where
         # they can get (a kink between two grid cells of the morph, or the rounding floor of the likelihood)
         lost = ~accepted
         again = lost & ~fresh[act]
-        H[act[again]] = eye
+        B[act[again]] = eye
         fresh[act[again]] = True
         gone = lost & ~again
         stalled[act[gone]] = True
@@ -159,17 +167,21 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             first = fresh[rows] & good
             if np.any(first):                                        # scale the first estimate (Nocedal & Wright 6.20)
                 yy = np.sum(y[first] * y[first], axis=1)
-                H[rows[first]] = eye * (sy[first] / yy)[:, None, None]
+                B[rows[first]] = eye * (yy / sy[first])[:, None, None]
             fresh[rows[good]] = False
             if np.any(good):
-                sg, yg, rho = s[good], y[good], 1.0 / sy[good]
-                Hg = H[rows[good]]
-                Hy = np.einsum('pij,pj->pi', Hg, yg)
-                yHy = np.sum(yg * Hy, axis=1)
-                Hg = Hg - rho[:, None, None] * (sg[:, :, None] * Hy[:, None, :] + Hy[:, :, None] * sg[:, None, :]) + \
-                     ((rho * rho * yHy + rho)[:, None, None]) * (sg[:, :, None] * sg[:, None, :])
-                H[rows[good]] = Hg
+                sg, yg = s[good], y[good]
+                Bg = B[rows[good]]
+                Bs = np.einsum('pij,pj->pi', Bg, sg)
+                sBs = np.sum(sg * Bs, axis=1)
+                Bg = Bg - (Bs[:, :, None] * Bs[:, None, :]) / sBs[:, None, None] + (yg[:, :, None] * yg[:, None, :]) / sy[good][:, None, None]
+                B[rows[good]] = Bg
+            gain = f[rows] - acc_f[w]
+            flat[rows] = np.where(gain <= ftol * np.maximum(1.0, np.abs(acc_f[w])), flat[rows] + 1, 0)
             x[rows], f[rows], g[rows] = acc_x[w], acc_f[w], acc_g[w]
+            at_floor = rows[flat[rows] >= 2]
+            converged[at_floor] = True
+            done[at_floor] = True
     return x, f, dict(converged=converged, stalled=stalled, failed=failed, iterations=it, calls=calls)
 
 

@@ -12,7 +12,8 @@ tests/golden/profile_<name>.npz:
     axis_<i>_name / axis_<i>_values     the scan space
     fixed_names / fixed_values           parameters held fixed through kwargs
     float_names                          the fitted parameters, in the reference's order
-    ll [grid]                            max log likelihood per grid point (bestfit_scipy with minimize_kwargs = {'tol': 1e-10})
+    ll [grid]                            max log likelihood per grid point (bestfit_scipy with minimize_kwargs = TIGHT below; nan where
+                                         the reference then raises OptimizationFailed)
     ll_default [grid]                    the same with the reference's default minimiser settings
     best [grid, F]                       fitted values per grid point
     global_names / global_values / global_ll     the unconstrained best fit (denominator of the ratio)
@@ -29,6 +30,7 @@ import blueice
 import model_zoo
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+TIGHT = {'tol': 1e-10, 'options': {'maxiter': 40000}}
 
 
 def main():
@@ -55,13 +57,17 @@ def main():
         for idx in np.ndindex(*grids[0].shape):
             kw = dict(fixed, **{n: float(g[idx]) for n, g in zip(names, grids)})
             ll_default[idx] = lf.bestfit_scipy(**kw)[1]
-            res, val = lf.bestfit_scipy(minimize_kwargs={'tol': 1e-10}, **kw)
+            try:
+                res, val = lf.bestfit_scipy(minimize_kwargs=TIGHT, **kw)
+            except blueice.exceptions.OptimizationFailed:          # (a maximum on the edge of the allowed region, where the
+                res, val = lf.bestfit_scipy(**kw)                   # objective is +inf next door: Nelder-Mead gives up)
+                val = np.nan
             if best is None:
                 float_names = list(res.keys())
                 best = np.empty(grids[0].shape + (len(float_names),))
             ll[idx] = val
             best[idx] = [res[k] for k in float_names]
-        gres, gll = lf.bestfit_scipy(minimize_kwargs={'tol': 1e-10}, **fixed)
+        gres, gll = lf.bestfit_scipy(minimize_kwargs=TIGHT, **fixed)
         t = dict(ll=ll, ll_default=ll_default, best=best, float_names=np.array(float_names), fixed_names=np.array(list(fixed.keys())),
                  fixed_values=np.array(list(fixed.values()), dtype=float), global_names=np.array(list(gres.keys())),
                  global_values=np.array(list(gres.values()), dtype=float), global_ll=gll,
@@ -70,7 +76,7 @@ def main():
             t['axis_%d_name' % i] = np.array(n)
             t['axis_%d_values' % i] = np.asarray(v, dtype=float)
         if name == 'd2_rate_160':
-            tight = dict(minimize_kwargs={'tol': 1e-10})
+            tight = dict(minimize_kwargs=TIGHT)
             fit = lambda lf_, **kw: lf_.bestfit_scipy(**dict(tight, **kw))
             t['upper_s0_90'] = lf.one_parameter_interval('s0_rate_multiplier', bound=40., kind='upper', confidence_level=0.9,
                                                          bestfit_routine=fit, **fixed)
@@ -78,7 +84,7 @@ def main():
                                                          bestfit_routine=fit, **fixed)
         np.savez_compressed(os.path.join(OUT, 'profile_%s.npz' % name), **t)
         print('%-24s %d fits in %.0f s; ll in [%.6f, %.6f], global %.9f; default settings differ by up to %.2e' % (
-            name, ll.size, time.time() - t0, ll.min(), ll.max(), gll, np.abs(ll - ll_default).max()), flush=True)
+            name, ll.size, time.time() - t0, np.nanmin(ll), np.nanmax(ll), gll, np.nanmax(np.abs(ll - ll_default))), flush=True)
 
 
 if __name__ == '__main__':

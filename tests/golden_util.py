@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 def _all_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
-                  if not os.path.basename(p).startswith(('fit_', 'api_')))
+                  if not os.path.basename(p).startswith(('fit_', 'api_', 'profile_')))
 
 
 def case_names():
