@@ -51,6 +51,23 @@ void launch_morph_grad(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool nt
 #undef BI_GRAD_CASE
 }
 
+// value + gradient with Beeston-Barlow: G columns in all (padded 1 + d + S), DZ of them (padded 1 + d) for the P / a streams
+int launch_morph_bbgrad(bi_ctx* c, int G, int DZ, const LaunchArgs& a, dim3 grid, bool nt) {
+    EventScope ev(c);
+#define BI_BBG(GG, ZZ)                                                                                             \
+    do {                                                                                                            \
+        if (nt) hipLaunchKernelGGL((k_morph_bbgrad<GG, ZZ, true>), grid, dim3(kThreads), 0, c->stream, a);          \
+        else hipLaunchKernelGGL((k_morph_bbgrad<GG, ZZ, false>), grid, dim3(kThreads), 0, c->stream, a);            \
+    } while (0)
+    if (G == 8 && DZ == 4) BI_BBG(8, 4);
+    else if (G == 8 && DZ == 8) BI_BBG(8, 8);
+    else if (G == 16 && DZ == 4) BI_BBG(16, 4);
+    else if (G == 16 && DZ == 8) BI_BBG(16, 8);
+    else return BI_ERR_INVALID;
+#undef BI_BBG
+    return BI_OK;
+}
+
 // nt: the launch streams its template rows exactly once (no two items touch the same anchor), so the loads
 // carry the nontemporal hint: +8 % HBM rate on gfx950; with shared rows the default policy (L2 / MALL) wins.
 void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {

@@ -48,6 +48,7 @@
 #include "bi_single.h"
 #include "bi_planning.h"
 #include "bi_planning_device.h"
+#include "bi_grad_bb.h"
 #include "bi_params.h"
 
 namespace {
@@ -782,10 +783,13 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
                  double* grad, int32_t* status) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "bi_eval_grad is not available with Beeston-Barlow");
     if (c->unbinned) return fail(c, BI_ERR_INVALID, "bi_eval_grad is implemented for binned likelihoods only");
     if (P < 0 || (P > 0 && (!ll || !grad))) return fail(c, BI_ERR_INVALID, "bad P / output pointers");
     if (c->d > 0 && P > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
+    if (c->bb_source >= 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        return eval_grad_bb(c, P, z, rate_scale, dataset, ll, grad, status);
+    }
     const int S = c->S, d = c->d;
     const int W = 1 + d + S;
     if (W > kMaxG) return fail(c, BI_ERR_INVALID, "1 + d + S = %d exceeds %d gradient columns", W, kMaxG);

@@ -243,9 +243,8 @@ def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper'
             out = 0.0 - crit
             need = np.array([not one_sided_ok(h) for h in hs])
             if np.any(need):
-                if nuisances:                       # start every hypothesis from the global best fit's nuisances
-                    guess = {k: np.full(int(need.sum()), best[k]) for k in nuisances}
-                    _, ll = bestfit_batched(lf, points={target: hs[need]}, guess=guess, **kwargs)
+                if nuisances:                       # every hypothesis starts where the reference starts AND at the global best fit's nuisances
+                    _, ll = bestfit_batched(lf, points={target: hs[need]}, also_from=[{k: best[k] for k in nuisances}], **kwargs)
                 else:                               # nothing left to profile: plain evaluations
                     ll = np.asarray(lf.eval_points(dict(kwargs, **{target: hs[need]})))
                 out[need] = 2 * (max_ll - ll) - crit[need]

@@ -667,8 +667,12 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
 
     @property
     def supports_gradient(self):
-        """bi_eval_grad exists for plain binned likelihoods (not with Beeston-Barlow: mu then depends on the data)."""
-        return self.model_statistical_uncertainty_handling is None
+        """bi_eval_grad covers binned likelihoods, with and without Beeston-Barlow (there the chain rule runs through the
+        per-bin root of likelihood.py:693-712), up to 1 + d + S = 16 gradient columns (d <= 7 with Beeston-Barlow)."""
+        n = 1 + len(self.shape_parameters) + len(self.source_name_list)
+        if self.model_statistical_uncertainty_handling is not None and len(self.shape_parameters) > 7:
+            return False
+        return n <= 16
 
     @_needs_data
     def value_and_gradient(self, livetime_days=None, **kwargs):
@@ -706,19 +710,23 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         return prior + ll, grads
 
     @_needs_data
-    def values_and_gradients(self, points, livetime_days=None, dataset=None):
+    def values_and_gradients(self, points, livetime_days=None, dataset=None, bb_assert='raise'):
         """The batched form of `value_and_gradient`: points = dict parameter name -> array [P] (as `eval_points`) ->
         (ll [P], OrderedDict parameter name -> d ll / d parameter [P]) for every registered rate and shape parameter,
         from ONE device call (`bi_eval_grad` over all P points).  Points outside the anchor box or with unphysical
         rates give -inf and nan slopes.  What the batched profile-fit engine (blueice_amd.profile) advances P
-        minimisations with."""
+        minimisations with.  bb_assert: points at which one of the reference's Beeston-Barlow assertions would fire
+        (likelihood.py:649,655) raise AssertionError, as the scalar call does -- or, with 'nan', come back as nan so that a
+        line search can step around them."""
         z, scale, prior, unit = self._batch_terms(points, livetime_days, want_unit=True)
         P = len(z)
         ll, gz, gs, st = self.ctx.eval_grad(z if z.shape[1] else None, scale, dataset)
         if np.any(st & _capi.ST_INTERNAL):
             raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
         if np.any(st & _BB_FLAGS):
-            raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
+            if bb_assert != 'nan':
+                raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
+            ll = np.where(st & _BB_FLAGS, np.nan, ll)
         bad = (st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0
         if np.any(st & _capi.ST_UNPHYSICAL) and self.config.get('unphysical_behaviour') == 'error':
             raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(st & _capi.ST_UNPHYSICAL)), P))

@@ -52,7 +52,10 @@ class BatchObjective:
         self.calls += 1
         if self.analytic:
             self.evaluations += len(x)
-            ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days)
+            try:       # (a trial point at which a Beeston-Barlow assertion of the reference would fire is a point to avoid)
+                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, bb_assert='nan')
+            except TypeError:
+                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days)
             g = np.stack([np.broadcast_to(grads[n], ll.shape) for n in self.names], axis=1)
             return -ll, -g
         # central differences, all 2F + 1 stencil points of all problems in one batched call
@@ -75,7 +78,7 @@ class BatchObjective:
         return -ll[0], -g
 
 
-def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=40, ftol=1e-15):
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=30, ftol=1e-15):
     """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
     lo / hi [F]: box (+-inf = none).  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
     gtol, or two successive steps that lowered f by less than ftol * max(1, |f|): the rounding floor),
@@ -95,6 +98,9 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
     flat = np.zeros(P, dtype=np.int32)                   # successive steps without a measurable decrease
     at_lo = lambda xx: xx <= lo
     at_hi = lambda xx: xx >= hi
+    # no step carries a boxed variable (a shape parameter) further than a quarter of its range -- a tenth on a plain
+    # gradient step --: the morph is only piecewise smooth, and a long first stride lands in another grid cell's basin
+    span = np.where(np.isfinite(hi - lo), hi - lo, np.inf)
     it = 0
     for it in range(1, max_iter + 1):
         blocked = (at_lo(x) & (g > 0)) | (at_hi(x) & (g < 0))       # moving against the gradient would leave the box
@@ -121,7 +127,9 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             B[act[reset]] = eye
             fresh[act[reset]] = True
             slope = np.sum(d * ga, axis=1)
-        alpha = np.ones(len(act))
+        with np.errstate(all='ignore'):
+            cap = np.where(fresh[act], 0.1, 0.25)[:, None] * span[None, :] / np.maximum(np.abs(d), 1e-300)
+        alpha = np.minimum(1.0, np.min(cap, axis=1))
         xa, fa = x[act], f[act]
         todo = np.arange(len(act))
         acc_x, acc_f, acc_g = xa.copy(), fa.copy(), ga.copy()
@@ -145,7 +153,7 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
                 quad = -slope[miss] * a_m ** 2 / (2.0 * (f_t - fa[miss] - slope[miss] * a_m))
             alpha[miss] = np.where(np.isfinite(quad), np.clip(quad, 0.1 * a_m, 0.5 * a_m), 0.5 * a_m)
             todo = miss
-            if np.all(alpha[todo] * np.max(np.abs(d[todo]), axis=1) < 1e-15 * np.maximum(1.0, np.max(np.abs(xa[todo]), axis=1))):
+            if np.all(alpha[todo] * np.max(np.abs(d[todo]), axis=1) < 1e-13 * np.maximum(1.0, np.max(np.abs(xa[todo]), axis=1))):
                 break
         # problems without an acceptable step: once more from a fresh B; if that was a fresh B already, they are where
         # they can get (a kink between two grid cells of the morph, or the rounding floor of the likelihood)
@@ -161,6 +169,12 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
         if len(w):
             s = acc_x[w] - xa[w]
             y = acc_g[w] - ga[w]
+            # the update lives in the subspace of the variables that moved freely: one that was pinned, or that the step
+            # ran into a bound with (a clipped, arbitrarily short move against a finite change of slope), would plant a
+            # huge curvature in B and shrink every later step to nothing
+            pinned = ~free[w] | (acc_x[w] <= lo) | (acc_x[w] >= hi)
+            s = np.where(pinned, 0.0, s)
+            y = np.where(pinned, 0.0, y)
             sy = np.sum(s * y, axis=1)
             good = sy > 1e-10 * np.sqrt(np.sum(s * s, axis=1) * np.sum(y * y, axis=1))
             rows = act[w]
@@ -179,19 +193,30 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             gain = f[rows] - acc_f[w]
             flat[rows] = np.where(gain <= ftol * np.maximum(1.0, np.abs(acc_f[w])), flat[rows] + 1, 0)
             x[rows], f[rows], g[rows] = acc_x[w], acc_f[w], acc_g[w]
-            at_floor = rows[flat[rows] >= 2]
+            # two steps in a row without a measurable decrease: if B was fresh (plain gradient steps) this is the rounding
+            # floor of the function; otherwise distrust B first and take gradient steps from here
+            floor = flat[rows] >= 2
+            at_floor = rows[floor & fresh[rows]]
             converged[at_floor] = True
             done[at_floor] = True
+            retry = rows[floor & ~fresh[rows]]
+            B[retry] = eye
+            fresh[retry] = True
+            flat[retry] = 0
     return x, f, dict(converged=converged, stalled=stalled, failed=failed, iterations=it, calls=calls)
 
 
-def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, max_iter=200, return_info=False, **fixed):
+def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, max_iter=200, return_info=False,
+                    multi_start=True, keep_starts=2, scout_iterations=6, also_from=(), **fixed):
     """Maximise `lf` over its floating parameters for P hypotheses at once.
 
     points: dict parameter name -> array [P] of values held fixed per problem (the scan grid / the hypotheses);
     fixed (kwargs): parameters held at one value in every problem; everything else floats, as in `bestfit_scipy`
     (rate multipliers first, guess 1; then shape parameters, guess = base value; blueice/inference.py:79-102).
     guess: dict name -> scalar or array [P] (e.g. the neighbouring hypothesis' solution).
+    multi_start: also start from the other grid cells of every floating shape parameter (see below); the reference's
+    single start is multi_start=False.  also_from: more starting points, each a dict name -> scalar or array [P] (floating
+    parameters it does not name start at their guess) -- e.g. the global best fit's nuisances for a profile fit.
     -> (OrderedDict name -> fitted values [P], max log likelihood [P]) [, info]."""
     points = {} if points is None else {k: np.atleast_1d(np.asarray(v, dtype=float)) for k, v in points.items()}
     P = max([len(v) for v in points.values()] + [1])
@@ -220,10 +245,56 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         lo.append(b[0]); hi.append(b[1])
     if not names:
         raise NoOpimizationNecessary("There are no parameters to fit, no optimization is necessary")
+    x0 = np.stack(x0, axis=1)
+    lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)
     obj = BatchObjective(lf, names, points, fixed, livetime_days)
-    x, f, info = batched_minimize(obj, np.stack(x0, axis=1), np.array(lo, dtype=float), np.array(hi, dtype=float),
-                                  gtol=gtol, max_iter=max_iter)
+    # Other starting points: the morph is smooth only inside a grid cell of the anchors, and with noisy templates the
+    # likelihood can have one local maximum per cell along a shape parameter.  Besides the reference's starting point
+    # (the base value) every problem is therefore also started from the centre of each OTHER cell along each floating
+    # shape parameter (one axis at a time, not their product); all starts take `scout_iterations` steps together, then
+    # the best `keep_starts` per problem run to convergence.  The price is a few more rows per device call.
+    starts = [x0]
+    if multi_start:
+        for j, key in enumerate(names):
+            anchors = lf.shape_parameters.get(key, (None,))[0] if key in lf.shape_parameters else None
+            if not anchors:
+                continue
+            zs = np.sort(np.array([float(a) for a in anchors if is_numeric(a)]))
+            for a, b in zip(zs[:-1], zs[1:]):
+                inside = (x0[:, j] >= a) & (x0[:, j] <= b)
+                if np.all(inside):
+                    continue
+                alt = x0.copy()
+                alt[:, j] = np.where(inside, x0[:, j], 0.5 * (a + b))
+                starts.append(alt)
+    for extra in also_from:
+        alt = x0.copy()
+        for j, key in enumerate(names):
+            if key in extra:
+                alt[:, j] = np.broadcast_to(np.asarray(extra[key], dtype=float), (P,))
+        starts.append(alt)
+    n_st = len(starts)
+    if n_st == 1:
+        x, f, info = batched_minimize(obj, x0, lo, hi, gtol=gtol, max_iter=max_iter)
+    else:
+        rows_of = lambda k: np.tile(np.arange(P), k)
+        scout = lambda xx, rr: obj(xx, rr % P)                       # row r of the stacked problem set is problem r % P
+        xs, fs, _ = batched_minimize(scout, np.concatenate(starts), lo, hi, gtol=gtol, max_iter=scout_iterations)
+        fs = np.where(np.isfinite(fs), fs, np.inf).reshape(n_st, P)
+        keep = min(keep_starts + len(also_from), n_st)
+        order = np.argsort(fs, axis=0, kind='stable')[:keep]          # [keep, P] start indices, best first
+        xk = xs.reshape(n_st, P, -1)[order, np.arange(P)[None, :]].reshape(keep * P, -1)
+        x, f, info = batched_minimize(scout, xk, lo, hi, gtol=gtol, max_iter=max_iter)
+        f2 = np.where(np.isfinite(f), f, np.inf).reshape(keep, P)
+        win = np.argmin(f2, axis=0)
+        pick = win * P + np.arange(P)
+        x, f = x[pick], f[pick]
+        info = dict(info, **{k: info[k][pick] for k in ('converged', 'stalled', 'failed')})
+        info['starts'] = n_st
+        info['winning_start'] = order[win, np.arange(P)]
+        del rows_of
     info['evaluations'] = obj.evaluations
+    info['calls'] = obj.calls
     info['analytic_gradient'] = obj.analytic
     best = OrderedDict((n, x[:, j].copy()) for j, n in enumerate(names))
     return (best, -f, info) if return_info else (best, -f)

@@ -181,7 +181,12 @@ int bi_eval_end(bi_ctx* ctx, double* out, int32_t* status);
  *   grad [P][d + S]   d ll / d z_i (i < d; through the morph weights AND through mus(z)), then
  *                     d ll / d rate_scale_s.  Inside a grid cell ll is smooth; on an anchor the
  *                     derivative is the one of the cell the point is assigned to.  NaN where ll = -inf.
- * Needs 1 + d + S <= 16; not available with Beeston-Barlow. */
+ * Needs 1 + d + S <= 16.
+ * With Beeston-Barlow (bb_source >= 0; blueice/likelihood.py:618-660,693-712) the chain rule runs through the per-bin root:
+ * mu_b = U_b + A_b p_b with p_b = r_i P_b / a_b, d mu = dU + p dA + A dp, dA from the root formula's partial derivatives;
+ * in bins with U_b == 0 exactly the derivative of the reference's special case A = (n + a) / (1 + p_cal) is taken (on that
+ * measure-zero set the two branches of the reference differ, so ll itself is not differentiable across it).  d <= 7 there.
+ * status carries the Beeston-Barlow assertion bits of the value, as bi_eval does. */
 int bi_eval_grad(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
                  double* grad, int32_t* status);
 

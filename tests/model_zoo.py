@@ -369,6 +369,10 @@ PROFILE_SCANS = OrderedDict([
     ('c1_shift_1001', (fit_c1_like, [('shift', np.linspace(-1., 1., 1001))], {})),
     ('c1_rate_x_shift_24x24', (fit_c1_like, [('s0_rate_multiplier', np.linspace(0.2, 3., 24)), ('shift', np.linspace(-0.95, 0.95, 24))], {})),
     ('d2_rate_160', (profile_d2, [('s0_rate_multiplier', np.linspace(0.05, 4., 160))], {'s2_rate_multiplier': 1.})),
+    # the same with the second shape parameter held inside its range: in the scan above its best value sits ON the
+    # lower anchor, where the reference's minimisers meet an infinite wall and mostly stop short of the maximum
+    ('d2_rate_120_interior', (profile_d2, [('s0_rate_multiplier', np.linspace(0.05, 4., 120))],
+                              {'s2_rate_multiplier': 1., 'stretch': 1.5})),
 ])
 
 

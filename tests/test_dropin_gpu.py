@@ -155,20 +155,27 @@ def test_reparam_as_the_reference_tests_it(ns):
 
 
 def test_gradient_fit_falls_back_without_gradient_support(ns):
-    """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (Beeston-Barlow terms, a sum
-    containing one) must take the numerical route instead of failing mid-fit."""
+    """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (unbinned terms, a sum containing
+    one) must take the numerical route instead of failing mid-fit.  (Beeston-Barlow likelihoods have one since round 3.)"""
     from blueice_amd import LogLikelihoodSum
     bb, _, _ = model_zoo.bb_two_shape(ns)
     plain, _, _ = model_zoo.c1_like(ns)
-    assert plain.supports_gradient and not bb.supports_gradient
-    total = LogLikelihoodSum([plain, bb])
-    assert not total.supports_gradient and LogLikelihoodSum([plain, plain]).supports_gradient
+    unb, _, _ = model_zoo.unb_shape_2src(ns)
+    assert plain.supports_gradient and bb.supports_gradient and not unb.supports_gradient
+    total = LogLikelihoodSum([plain, unb])
+    assert not total.supports_gradient and LogLikelihoodSum([plain, bb]).supports_gradient
     with pytest.raises(NotImplementedError):
         total.value_and_gradient()
-    fixed = dict(strlen_multiplier=2, dummy=0.5)
+    fixed = dict(sigma=1.2, some_multiplier=0.8, shift=0.2)
     a = total.bestfit_scipy(use_gradient=True, **fixed)
     b = total.bestfit_scipy(**fixed)
     assert same(a[1], b[1], 1e-9)
+    # a sum with a Beeston-Barlow term: the analytic route and the differencing route reach the same maximum
+    both = LogLikelihoodSum([plain, bb])
+    fixed = dict(strlen_multiplier=2, dummy=0.5, shift=0.1)
+    a = both.bestfit_scipy(use_gradient=True, **fixed)
+    b = both.bestfit_scipy(**fixed)
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(b[1])
 
 
 def test_reference_binned_tests_verbatim(ns):

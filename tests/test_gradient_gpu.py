@@ -109,3 +109,123 @@ def test_gradient_with_efficiency_parameter():
         dn[name] -= h
         fd = (lf(**up) - lf(**dn)) / (2 * h)
         assert abs(g - fd) <= 2e-5 * max(1.0, abs(fd)), (name, g, fd)
+
+
+# ---- Beeston-Barlow: the chain rule through the per-bin root (blueice/likelihood.py:618-660,693-712)
+def fd_oracle_bb(model, counts, z, r, bb, h=1e-6):
+    from oracle import blueice_oracle as orc
+    f = lambda zz, rr: orc.loglikelihood(model, counts, zz, rr, bb_source=bb, forgive_zero_u=True)
+    gz = np.zeros(len(z))
+    for i in range(len(z)):
+        zp, zm = np.array(z, float), np.array(z, float)
+        zp[i] += h
+        zm[i] -= h
+        gz[i] = (f(zp, r) - f(zm, r)) / (2 * h)
+    gr = np.zeros(len(r))
+    for s in range(len(r)):
+        hs = h * max(1.0, abs(r[s]))
+        rp, rm = np.array(r, float), np.array(r, float)
+        rp[s] += hs
+        rm[s] -= hs
+        gr[s] = (f(z, rp) - f(z, rm)) / (2 * hs)
+    return gz, gr
+
+
+@pytest.mark.parametrize('name', ['ref_bb_second_source', 'bb_two_shape', 'bb_d2'])
+def test_beeston_barlow_gradient_matches_finite_differences(name):
+    from blueice_amd.device import DeviceContext
+    c = load_case(name)
+    bb = c['bb_source']
+    ctx = DeviceContext(0)
+    ctx.upload_model(c['model']['anchor_z'], c['model']['ps'], c['model']['mus'], n_model=c['model']['n_model'], bb_source=bb)
+    ctx.upload_counts(c['counts'])
+    rng = np.random.default_rng(5)
+    n = 6
+    zs = np.array([[rng.uniform(g[0] + 0.02 * (g[-1] - g[0]), g[-1] - 0.02 * (g[-1] - g[0])) for g in c['model']['anchor_z']]
+                   for _ in range(n)]).reshape(n, c['d'])
+    rs = rng.uniform(0.5, 1.6, size=(n, c['S']))
+    ll, gz, gs, st = ctx.eval_grad(zs if c['d'] else None, rs)
+    ref, rst = ctx.eval(zs if c['d'] else None, rs)
+    np.testing.assert_array_equal(st, rst)                    # the assertion bits of the value ride along
+    ok = st == 0
+    assert ok.sum() >= 3
+    np.testing.assert_allclose(ll[ok], ref[ok], rtol=1e-13)
+    for i in np.flatnonzero(ok):
+        fz, fr = fd_oracle_bb(c['model'], c['counts'], zs[i], rs[i], bb)
+        scale = max(1.0, np.abs(np.concatenate([fz, fr])).max())
+        np.testing.assert_allclose(gz[i], fz, atol=1e-6 * scale, rtol=2e-6)
+        np.testing.assert_allclose(gs[i], fr, atol=1e-6 * scale, rtol=2e-6)
+    ctx.close()
+
+
+def test_beeston_barlow_gradient_synthetic_mini_and_zero_u_bins():
+    """mini4bb (4 shape axes, one of them a single anchor; 3 sources -> 8 columns, DZ = 8) and a model in which the other
+    sources expect exactly nothing in some bins (U_b == 0: the reference's special case, differentiated as such)."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini4bb', bb_source=0)
+    dense = m.dense_model()
+    counts = m.counts(dense=True)
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.upload_counts(counts)
+    z, r = m.random_points(5, seed=3)
+    ll, gz, gs, st = ctx.eval_grad(z, r)
+    assert not st.any()
+    np.testing.assert_allclose(ll, ctx.eval(z, r)[0], rtol=1e-13)
+    for i in range(5):
+        fz, fr = fd_oracle_bb(dense, counts, z[i], r[i], 0)
+        scale = max(1.0, np.abs(np.concatenate([fz, fr])).max())
+        np.testing.assert_allclose(gz[i], fz, atol=1e-6 * scale, rtol=2e-6)
+        np.testing.assert_allclose(gs[i], fr, atol=1e-6 * scale, rtol=2e-6)
+    # exact zeros of the other sources' templates in a block of bins
+    shape = dense['ps'].shape
+    ps = dense['ps'].reshape(shape[:m.d + 1] + (m.B,)).copy()
+    ps[..., 1:, 100:160] = 0.0
+    ps = ps.reshape(shape)
+    model = dict(dense, ps=ps)
+    ctx.upload_model(model['anchor_z'], ps, model['mus'], n_model=model['n_model'], bb_source=0)
+    ctx.upload_counts(counts)
+    ll, gz, gs, st = ctx.eval_grad(z, r)
+    ref, rst = ctx.eval(z, r)
+    np.testing.assert_array_equal(st & ~4, rst & ~4)
+    for i in range(5):
+        fz, fr = fd_oracle_bb(model, counts, z[i], r[i], 0)
+        scale = max(1.0, np.abs(np.concatenate([fz, fr])).max())
+        np.testing.assert_allclose(gz[i], fz, atol=2e-6 * scale, rtol=5e-6)
+        np.testing.assert_allclose(gs[i], fr, atol=2e-6 * scale, rtol=5e-6)
+    ctx.close()
+
+
+def test_beeston_barlow_fit_with_analytic_gradient():
+    """bestfit_scipy(use_gradient=True) on a Beeston-Barlow likelihood reaches the optimum of the differencing fit in a
+    fraction of the device calls; the batched engine profiles it too."""
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf, _, _ = model_zoo.bb_d2(ns)
+    assert lf.supports_gradient
+    kw = {k: v for k, v in zip(lf.shape_parameters, [0.3, 0.4])}
+    ll, grads = lf.value_and_gradient(**kw)
+    assert abs(ll - lf(**kw)) <= 1e-12 * abs(ll)
+    for name, g in grads.items():
+        h = 1e-6
+        up, dn = dict(kw), dict(kw)
+        up[name] = up.get(name, 1.0) + h
+        dn[name] = dn.get(name, 1.0) - h
+        fd = (lf(**up) - lf(**dn)) / (2 * h)
+        assert abs(g - fd) <= 2e-5 * max(1.0, abs(fd)), (name, g, fd)
+    lf.ctx.set_param('single_timing_reset', 1)
+    res_fd, ll_fd = lf.bestfit_scipy(batch_stencil=False)
+    scalar_calls = lf.ctx.get_param('single_calls')
+    calls = {'n': 0}
+    orig = lf.ctx.eval_grad
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    lf.ctx.eval_grad = counting
+    res_g, ll_g = lf.bestfit_scipy(use_gradient=True)
+    assert ll_g >= ll_fd - 1e-6 * abs(ll_fd)
+    assert abs(ll_g - ll_fd) <= 1e-4 * abs(ll_fd)
+    assert 0 < calls['n'] < scalar_calls / 2
+    best, ll_b, info = lf.bestfit_batched(return_info=True)
+    assert info['analytic_gradient'] and ll_b[0] >= ll_fd - 1e-6 * abs(ll_fd)
