@@ -55,6 +55,7 @@ struct bi_plan {
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
+    bool sorted = false;       // rows / counts refer to the count-sorted copy of all bins (dense-data scans, ensure_sorted_rows)
     int64_t bytes = 0;         // algorithmic HBM bytes per run
     int64_t launches = 0;
 };
@@ -153,7 +154,12 @@ struct bi_ctx {
     int64_t scan_split = 1;                      // dense scans over mostly empty data: non-empty-bin pass + matrix-core validity pass
     int64_t sparse_at_upload = 1;                // value of `sparse` when the resident data were uploaded
     int64_t scan_mfma = 1;                       // scans: fp64 matrix-core kernel when many points share a cell
-    int64_t scan_pow = 1;                        // dense-data scans: small integer counts take one logarithm of the product mu^n over a lane's four bins
+    int64_t scan_pow = 1;                        // dense-data scans run on a copy of the rows with the bins ordered by their count, where n log mu
+                                                 // over a lane's bins becomes n log of their product (ensure_sorted_rows, k_scan_mfma PROD = 2)
+    DevBuf ps_sorted, cnt_sorted;                // that copy: [A*S][Bp] rows and [Bp] counts of dataset 0
+    int64_t sorted_epoch = -1;                   // data epoch it was (or could not be) built for
+    bool sorted_ok = false;
+    int64_t n_sorted_scans = 0;                  // how often a scan ran on it (observability)
     int64_t mail_timeout_ms = 2000;              // in-launch finish: how long a collecting block waits for a partial sum before BI_ST_INTERNAL
     int64_t debug_skip_post = -1, debug_late_post = -1;   // fault injection for the next mailbox launch (bi_params.h)
     int64_t n_mail_resets = 0;                   // how often the mailbox had to be emptied after a collector gave up

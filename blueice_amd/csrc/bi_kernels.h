@@ -41,6 +41,12 @@ __device__ __forceinline__ void log_table_load() {
 
 __device__ __forceinline__ bool pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
 
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // the core: x must be a positive normal number (anything else gives a meaningless but harmless value);
 // k_adjust is added to the binary exponent
 __device__ __forceinline__ double log_core(double x, int k_adjust) {
@@ -60,10 +66,12 @@ __device__ __forceinline__ double log_core(double x, int k_adjust) {
     const double w = fma(kd, kLn2Hi, e.y);         // exact
     const double tail = fma(kd, kLn2Lo, e.z);
     double p = fma(r, -1.0 / 8.0, e.w);            // e.w = 1/7: arrives in a vector register with the table entry
-    p = fma(r, p, -1.0 / 6.0);
-    p = fma(r, p, 1.0 / 5.0);
-    p = fma(r, p, -1.0 / 4.0);
-    p = fma(r, p, 1.0 / 3.0);
+    // (Horner steps as explicit three-address FMAs with the constants in registers: the compiler otherwise forms v_fmac,
+    // whose accumulator IS the addend, and copies every constant into it first -- four more instructions per logarithm)
+    p = fma3(r, p, -1.0 / 6.0);
+    p = fma3(r, p, 1.0 / 5.0);
+    p = fma3(r, p, -1.0 / 4.0);
+    p = fma3(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
     const double q = fma(r * r, p, tail);
     // w + r with its rounding error kept (|w| >= |r| wherever w != 0: k != 0, or a subinterval away from the two that touch
@@ -1927,9 +1935,15 @@ __device__ __forceinline__ double rows4_sum(double v) {
 // in-lane additions and two cross-row exchanges per item (rows4_sum: ~10 vector instructions) -- with the operands the
 // other way round (bins along the lanes of a row) it took four 16-lane rotations per accumulator element, ~60
 // instructions per item, a fifth of the kernel's vector work when every bin has data.
-// PROD: the rows are the compacted non-empty bins of sparse data -- blocks whose counts are all 1 or 2 take one logarithm of
+// PROD = 1: the rows are the compacted non-empty bins of sparse data -- blocks whose counts are all 1 or 2 take one logarithm of
 // the product mu^n over a lane's four bins (a separate instantiation, so that the dense-data kernel keeps its code).
-template <int CB, int KG, bool MASK, bool PROD = false>
+// PROD = 2: the rows are a copy of ALL bins ordered by their count (ensure_sorted_rows: dense data, ~10 events per bin).
+// A sum over bins does not care about their order, and in that order the four bins of a lane -- almost always the
+// whole 32-bin strip -- carry the SAME count n, so  sum_b n log mu_b = n log prod_b mu_b : seven multiplications and ONE
+// logarithm per lane, item and strip instead of eight logarithms (24 instructions each, on a chip where no vector
+// instruction executes beside an fp64 MFMA).  Factors and intermediate products are checked to be positive normal
+// numbers; anything else takes the bin-wise form, which has scipy's values for every argument.
+template <int CB, int KG, bool MASK, int PROD = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
     constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
@@ -1957,7 +1971,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
         // (the four kinds of a lane's bins packed into one register, 2 bits each: registers decide the occupancy here)
         int kinds[CB];
-        bool special[CB], alldata[CB], ones_twos[CB];
+        bool special[CB], alldata[CB], ones_twos[CB], uniform[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             kinds[cb] = 0;
@@ -1975,8 +1989,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             bool small = true;
 #pragma unroll
             for (int r = 0; r < 4; ++r) small &= n[cb][r] == 1.0 || n[cb][r] == 2.0;
-            ones_twos[cb] = PROD && __ballot(small) == ~0ull;
+            ones_twos[cb] = PROD == 1 && __ballot(small) == ~0ull;
+            // count-sorted rows: the four bins of every lane of this block carry one count
+            uniform[cb] = PROD == 2 && alldata[cb] &&
+                          __ballot(n[cb][0] == n[cb][1] && n[cb][1] == n[cb][2] && n[cb][2] == n[cb][3]) == ~0ull;
         }
+        // ... and both blocks of the strip the same one, lane by lane: one logarithm per lane and item for the whole strip
+        bool strip_uniform = false;
+        if constexpr (PROD == 2 && CB == 2) strip_uniform = uniform[0] && uniform[1] && __ballot(n[0][0] == n[1][0]) == ~0ull;
 #define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
 
         // coefficient operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
@@ -2015,7 +2035,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
             if (__ballot(checked) == 0ull) {                                                                       \
-                if (PROD && ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
+                if (PROD == 2 && uniform[cb]) { /* one count per lane: n log of the product over the lane's four bins */ \
+                    const double f01 = acc[cb][0] * acc[cb][1], f23 = acc[cb][2] * acc[cb][3];                     \
+                    const double prod = f01 * f23;                                                                 \
+                    if (__ballot(!(pos_normal(f01) && pos_normal(f23) && pos_normal(prod))) == 0ull) {             \
+                        s[cb & 3] = fma(n[cb][0], bin_log_fast(prod), s[cb & 3]);                                  \
+                        break;                                                                                     \
+                    }                                                                                              \
+                }                                                                                                  \
+                if (PROD == 1 && ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
                     double f[4];                                                                                   \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                         f[r] = n[cb][r] == 2.0 ? acc[cb][r] * acc[cb][r] : acc[cb][r];                             \
@@ -2059,13 +2087,37 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
                 av[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
                 if (MASK && k >= a.NS) av[kg] = 0.0;
             }
+            bool strip_done = false;
+            double tot = 0.0;
+            if constexpr (PROD == 2 && CB == 2) {
+                if (strip_uniform) {          // (wave-uniform) the whole strip: eight factors, seven products, one logarithm
+                    const double a01 = acc[0][0] * acc[0][1], a23 = acc[0][2] * acc[0][3];
+                    const double b01 = acc[1][0] * acc[1][1], b23 = acc[1][2] * acc[1][3];
+                    const double pa = a01 * a23, pb = b01 * b23;
+                    const double pp = pa * pb;
+                    // (bitwise on purpose: fifteen class tests and scalar ANDs, no branches)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
+                    const bool ok = pos_normal(acc[0][0]) & pos_normal(acc[0][1]) & pos_normal(acc[0][2]) & pos_normal(acc[0][3]) &
+                                    pos_normal(acc[1][0]) & pos_normal(acc[1][1]) & pos_normal(acc[1][2]) & pos_normal(acc[1][3]) &
+                                    pos_normal(a01) & pos_normal(a23) & pos_normal(b01) & pos_normal(b23) & pos_normal(pa) &
+                                    pos_normal(pb) & pos_normal(pp);
+#pragma clang diagnostic pop
+                    if (__ballot(!ok) == 0ull) {
+                        tot = n[0][0] * bin_log_fast(pp);
+                        strip_done = true;
+                    }
+                }
+            }
+            if (!strip_done) {
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
+                for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
+                tot = (s[0] + s[1]) + (s[2] + s[3]);
+                if (mn < 0.0) tot = __builtin_nan("");
+            }
 #undef BI_CHAIN
 #undef BI_EPILOGUE
 #undef BI_KIND
-            double tot = (s[0] + s[1]) + (s[2] + s[3]);
-            if (mn < 0.0) tot = __builtin_nan("");
             tot = rows4_sum(tot);                     // over the four DPP rows: the 16 bins of the block are spread 4 r + kq
             if (kq == 0) unsafeAtomicAdd(dst, tot);
             dst += dst_step;

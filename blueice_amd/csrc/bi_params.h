@@ -52,7 +52,7 @@ const ParamDef kParams[] = {
     {"scan_waves_per_cu", kParamRW, BI_P_GET(c->scan_waves_per_cu), BI_P_SET(c->scan_waves_per_cu = v < 0 ? 0 : v)},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},
     {"scan_split", kParamRW, BI_P_GET(c->scan_split), BI_P_FLAG(scan_split)},
-    {"scan_pow", kParamRW, BI_P_GET(c->scan_pow), BI_P_FLAG(scan_pow)},
+    {"scan_pow", kParamRW, BI_P_GET(c->scan_pow), BI_P_SET(c->scan_pow = v ? 1 : 0; c->sorted_epoch = -1)},
     {"bb_exact", kParamRW, BI_P_GET(c->bb_exact), BI_P_RANGE(0, 2, bb_exact, "bb_exact: 0 never, 1 always, 2 auto")},
     {"toy_events", kParamRW, BI_P_GET(c->toy_events), BI_P_FLAG(toy_events)},
     {"dot_tiled", kParamRW, BI_P_GET(c->dot_tiled), BI_P_FLAG(dot_tiled)},
@@ -73,6 +73,7 @@ const ParamDef kParams[] = {
     BI_P_RO("padded_bins", c->Bp),
     BI_P_RO("n_scan_launches", c->n_scan_launches),
     BI_P_RO("n_valid_launches", c->n_valid_launches),
+    BI_P_RO("n_sorted_scans", c->n_sorted_scans),
     BI_P_RO("n_bb_exact", c->n_bb_exact),
     BI_P_RO("n_mail_resets", c->n_mail_resets),
     // "ready" = prepared AND in use as an evaluation path (with sparse = 0 at upload they serve split scans only)

@@ -43,6 +43,53 @@ int scan_resident_blocks(bool valid, int cb, int NS) {
     return blocks;
 }
 
+__global__ void k_iota32(int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+
+// The rows of the model with the bins of dataset 0 ordered BY THEIR COUNT (ties: by bin), for scans over dense data on the
+// matrix cores: in that order a lane's bins carry one count, and sum n log mu turns into n log prod mu (k_scan_mfma,
+// PROD = 2).  A sum over bins does not depend on their order; only the matrix-core scan kernel reads this copy.  Built on
+// first use per data upload (a radix sort of the counts and one gather pass over the tensor: 4 GB at C2, ~3 ms), within
+// the budget the compacted templates have (`compact_budget`); one dataset only.  -> true when the copy is resident.
+bool ensure_sorted_rows(bi_ctx* c) {
+    if (c->sorted_epoch == c->epoch) return c->sorted_ok;
+    c->sorted_epoch = c->epoch;
+    c->sorted_ok = false;
+    const int64_t B = c->B, Bp = c->Bp, rows = c->A * c->S;
+    if (!c->scan_pow || c->T != 1 || !c->dense_counts || c->unbinned || c->bb_source >= 0 || B < 4096 || B > INT32_MAX || rows > 65535) return false;
+    if ((rows + 1) * Bp * (int64_t)sizeof(double) > c->compact_budget) return false;
+    DevBuf d_iota, d_perm, d_tmp;
+    auto drop = [&]() { dev_free(d_iota); dev_free(d_perm); dev_free(d_tmp); };
+    size_t tmp_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                    (size_t)B, 0u, 64u, c->stream);
+    if (dev_alloc(c, c->ps_sorted, (size_t)rows * Bp * sizeof(double)) || dev_alloc(c, c->cnt_sorted, (size_t)Bp * sizeof(double)) ||
+        dev_alloc(c, d_iota, (size_t)B * sizeof(int32_t)) || dev_alloc(c, d_perm, (size_t)B * sizeof(int32_t)) ||
+        dev_alloc(c, d_tmp, std::max<size_t>(tmp_bytes, 256))) {
+        drop();
+        dev_free(c->ps_sorted); dev_free(c->cnt_sorted);
+        return false;
+    }
+    hipLaunchKernelGGL(k_iota32, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, (int32_t*)d_iota.p, B);
+    hipError_t e = hipMemsetAsync(c->cnt_sorted.p, 0, (size_t)Bp * sizeof(double), c->stream);
+    size_t tb = d_tmp.bytes;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const double*)c->counts.p, (double*)c->cnt_sorted.p, (const int32_t*)d_iota.p,
+                                                       (int32_t*)d_perm.p, (size_t)B, 0u, 64u, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((Bp + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0, c->stream,
+                           (const double*)c->ps.p, Bp, (const int32_t*)d_perm.p, B, Bp, (double*)c->ps_sorted.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) { dev_free(c->ps_sorted); dev_free(c->cnt_sorted); return false; }
+    c->sorted_ok = true;
+    return true;
+}
+
 constexpr int kDevG = 16;   // every device-planned work item has 16 slots (the last of a group is padded)
 
 struct PlanMeta {
@@ -477,6 +524,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             const int cb = c->scan_cb ? (int)c->scan_cb : ((mostly_empty && !sparse) ? 4 : 2);
             plan->use_scan = true;
             plan->scan_cb = cb;
+            // dense data, rows in full: the count-sorted copy, if it can be had (every bin still visited, in another order)
+            plan->sorted = !compacted && cb == 2 && ensure_sorted_rows(c);
             plan->n_groups = n_groups;
             // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
             const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));

@@ -116,6 +116,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     dev_free(c->mail); dev_free(c->mail_flags);
+    dev_free(c->ps_sorted); dev_free(c->cnt_sorted);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     if (c->bounce_host) (void)hipHostFree(c->bounce_host);
@@ -538,6 +539,11 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
         bi_plan::Class& k = plan->classes[0];
         ScanArgs sa{};
         sa.ps = a.ps; sa.counts = a.counts;
+        if (plan->sorted) {
+            if (c->sorted_epoch != c->epoch || !c->sorted_ok) return fail(c, BI_ERR_STATE, "plan is stale: the count-sorted rows are gone");
+            sa.ps = (const double*)c->ps_sorted.p; sa.counts = (const double*)c->cnt_sorted.p;
+            ++c->n_sorted_scans;
+        }
         sa.rowoff = (const int64_t*)k.rowoff.p; sa.coef = (const double*)k.coef.p;
         sa.item_cnt = (const int64_t*)k.item_cnt.p; sa.item_tiles = (const int32_t*)k.item_tiles.p;
         sa.grp_first = (const int64_t*)plan->grp_first.p; sa.grp_items = (const int32_t*)plan->grp_items.p;
@@ -551,8 +557,11 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
 #define BI_SCAN(CB, KG)                                                                                           \
     do {                                                                                                          \
         if (CB == 2 && plan->sparse) { /* compacted rows: the instantiation with the product form of the logarithms */ \
-            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, true>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, true>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
+            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 1>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 1>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
+        } else if (CB == 2 && plan->sorted) { /* count-sorted rows: n log of the product over a lane's bins */    \
+            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 2>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 2>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
         } else if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
         else hipLaunchKernelGGL((k_scan_mfma<CB, KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
     } while (0)

@@ -304,14 +304,17 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   compact_budget    bytes of device memory the compacted templates of the non-empty-bin form may take
  *   toy_offset        bi_generate_toys: toy t of a call is dataset toy_offset + t of the seed's random stream, so ranks
  *                     that each generate a range of one toy-MC ensemble draw the same toys as one process would (0)
- *   scan_pow          dense-data scans on the matrix cores: blocks whose counts are small integers take ONE logarithm of the
- *                     product mu^n over a lane's four bins instead of four (1, default)
+ *   scan_pow          scans over dense data on the matrix cores run on a copy of the template rows whose bins are ordered by
+ *                     their count (one dataset, within compact_budget; built on first use per data upload): a lane's bins then
+ *                     carry one count n, and sum n log mu over them is n log of their product -- one logarithm per lane, work
+ *                     item and 32-bin strip instead of eight (1, default; 0 = rows in bin order, a logarithm per bin).
+ *                     Read-only n_sorted_scans counts the scans that ran on the copy
  *   mail_timeout_ms   in-launch finish: how long an item's collecting block waits for a sibling's partial sum before it gives
  *                     up with BI_ST_INTERNAL (2000)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
  *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
  *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
- * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
  *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
  *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
