@@ -56,6 +56,7 @@ struct bi_plan {
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
     bool sorted = false;       // rows / counts refer to the count-sorted copy of all bins (dense-data scans, ensure_sorted_rows)
+    bool by_count = false;     // the rows the scan kernel reads are ordered by count (sorted, or a count-sorted compacted copy)
     int64_t bytes = 0;         // algorithmic HBM bytes per run
     int64_t launches = 0;
 };
@@ -103,6 +104,7 @@ struct bi_ctx {
 
     // sparse forms of the data: CSR lists of the non-empty bins, and per-dataset compacted templates
     bool csr_ready = false, compact_ready = false;
+    bool compact_sorted = false;               // the compacted copy holds the non-empty bins ordered by their count (build_compact_templates)
     DevBuf nz_idx, nz_n, nz_off, ps_c, cnt_c;
     DevBuf tm_entries, tm_off;                // tile-major copy of the non-empty-bin lists (k_dataset_dot_tiled): 4-byte entries, [n_tiles * T + 1] offsets
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for

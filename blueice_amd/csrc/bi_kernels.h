@@ -41,12 +41,6 @@ __device__ __forceinline__ void log_table_load() {
 
 __device__ __forceinline__ bool pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
 
-__device__ __forceinline__ double fma3(double a, double b, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
 // the core: x must be a positive normal number (anything else gives a meaningless but harmless value);
 // k_adjust is added to the binary exponent
 __device__ __forceinline__ double log_core(double x, int k_adjust) {
@@ -66,12 +60,10 @@ __device__ __forceinline__ double log_core(double x, int k_adjust) {
     const double w = fma(kd, kLn2Hi, e.y);         // exact
     const double tail = fma(kd, kLn2Lo, e.z);
     double p = fma(r, -1.0 / 8.0, e.w);            // e.w = 1/7: arrives in a vector register with the table entry
-    // (Horner steps as explicit three-address FMAs with the constants in registers: the compiler otherwise forms v_fmac,
-    // whose accumulator IS the addend, and copies every constant into it first -- four more instructions per logarithm)
-    p = fma3(r, p, -1.0 / 6.0);
-    p = fma3(r, p, 1.0 / 5.0);
-    p = fma3(r, p, -1.0 / 4.0);
-    p = fma3(r, p, 1.0 / 3.0);
+    p = fma(r, p, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
     p = fma(r, p, -0.5);
     const double q = fma(r * r, p, tail);
     // w + r with its rounding error kept (|w| >= |r| wherever w != 0: k != 0, or a subinterval away from the two that touch

@@ -81,6 +81,7 @@ const ParamDef kParams[] = {
     BI_P_RO("compact_ready", (c->compact_ready && c->ps_nonneg && (c->sparse_at_upload != 0 || !c->dense_counts)) ? 1 : 0),
     BI_P_RO("split_ready", (c->compact_ready && c->dense_counts) ? 1 : 0),
     BI_P_RO("ps_nonneg", c->ps_nonneg ? 1 : 0),
+    BI_P_RO("compact_sorted", (c->compact_ready && c->compact_sorted) ? 1 : 0),
     BI_P_RO("nnz_total", c->csr_ready ? c->h_nz_off.back() : -1),
     BI_P_RO("last_scan_nslots", c->last_scan_nslots),
     BI_P_RO("last_valid_nslots", c->last_valid_nslots),

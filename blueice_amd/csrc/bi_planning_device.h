@@ -526,6 +526,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->scan_cb = cb;
             // dense data, rows in full: the count-sorted copy, if it can be had (every bin still visited, in another order)
             plan->sorted = !compacted && cb == 2 && ensure_sorted_rows(c);
+            plan->by_count = plan->sorted || (compacted && cb == 2 && c->compact_sorted);
             plan->n_groups = n_groups;
             // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
             const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));

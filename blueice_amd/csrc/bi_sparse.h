@@ -1,6 +1,8 @@
 // bi_sparse.h -- non-empty-bin forms of the data: CSR lists and per-dataset compacted templates.
 #pragma once
 
+#include <rocprim/rocprim.hpp>
+
 namespace {
 
 // per-dataset compacted copies of all template rows over the non-empty bins (needs the CSR lists)
@@ -30,21 +32,44 @@ int build_compact_templates(bi_ctx* c) {
         return rc;
     c->h_Tz.assign((size_t)T * rows, 0.0);
     std::vector<double> tnz((size_t)rows);
+    // Few datasets (a scan's one): the compacted copy holds the non-empty bins ORDERED BY THEIR COUNT (ties by bin) -- every
+    // consumer of the copy sums over its bins, so the order is free, and the matrix-core scan kernel turns runs of equal
+    // counts into one logarithm per lane and strip (k_scan_mfma PROD = 2).  The CSR lists themselves stay in bin order.
+    c->compact_sorted = false;
+    const bool sort_by_count = c->scan_pow && T <= 64;
+    DevBuf d_sidx, d_sn, d_tmp;
+    auto drop = [&]() { dev_free(d_sidx); dev_free(d_sn); dev_free(d_tmp); };
     for (int64_t t = 0; t < T; ++t) {
         const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo, np = c->h_c_np[(size_t)t];
         double* dst = (double*)c->ps_c.p + c->h_c_off[(size_t)t];
+        const int32_t* idx = (const int32_t*)c->nz_idx.p + lo;
+        const double* cnt = (const double*)c->nz_n.p + lo;
+        if (sort_by_count && nnz > 1) {
+            size_t tmp_bytes = 0;
+            (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
+                                            (int32_t*)nullptr, (size_t)nnz, 0u, 64u, c->stream);
+            if ((rc = dev_alloc(c, d_sidx, (size_t)nnz * sizeof(int32_t))) || (rc = dev_alloc(c, d_sn, (size_t)nnz * sizeof(double))) ||
+                (rc = dev_alloc(c, d_tmp, std::max<size_t>(tmp_bytes, 256)))) { drop(); return rc; }
+            size_t tb = d_tmp.bytes;
+            e = rocprim::radix_sort_pairs(d_tmp.p, tb, cnt, (double*)d_sn.p, idx, (int32_t*)d_sidx.p, (size_t)nnz, 0u, 64u, c->stream);
+            if (e != hipSuccess) { drop(); return fail(c, BI_ERR_HIP, "template compaction (sort by count): %s", hipGetErrorString(e)); }
+            idx = (const int32_t*)d_sidx.p;
+            cnt = (const double*)d_sn.p;
+        }
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((np + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0,
-                           c->stream, (const double*)c->ps.p, Bp, (const int32_t*)c->nz_idx.p + lo, nnz, np, dst);
+                           c->stream, (const double*)c->ps.p, Bp, idx, nnz, np, dst);
         hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->nz_n.p + lo, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
+                           cnt, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
         hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
                            (double*)c->scratch.p);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { drop(); return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e)); }
         for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
     }
+    drop();
+    c->compact_sorted = sort_by_count;
     c->compact_ready = true;
     return BI_OK;
 }

@@ -556,12 +556,12 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
 #define BI_SCAN(CB, KG)                                                                                           \
     do {                                                                                                          \
-        if (CB == 2 && plan->sparse) { /* compacted rows: the instantiation with the product form of the logarithms */ \
-            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 1>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 1>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
-        } else if (CB == 2 && plan->sorted) { /* count-sorted rows: n log of the product over a lane's bins */    \
+        if (CB == 2 && plan->by_count) { /* rows ordered by count (all bins of dense data, or the compacted non-empty bins): n log of the product over a lane's bins */ \
             if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 2>), sgrid, dim3(kThreads), 0, c->stream, sa); \
             else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 2>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
+        } else if (CB == 2 && plan->sparse) { /* compacted rows in bin order: blocks of counts 1 and 2 take the logarithm of the product mu^n */ \
+            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 1>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 1>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
         } else if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
         else hipLaunchKernelGGL((k_scan_mfma<CB, KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
     } while (0)

@@ -314,7 +314,7 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
  *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
  *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
- * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, split_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
  *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
  *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of
