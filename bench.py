@@ -30,7 +30,7 @@ The JSON line also carries
   roofline      morph+reduce kernel: algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s, the measured
                 stream ceiling of the same access pattern, PMC traffic from profiles/
   cpu_baseline  the numpy/scipy oracle (the reference's arithmetic) timed on the host, rank 0, N = 1
-  legs          C4 / C4-dense / C3 / C5-BB (every N; C5-BB carries the Beeston-Barlow kernel's own roofline)
+  legs          C4 / C4-dense / C3 / C5-BB (every N; C5-BB carries the Beeston-Barlow kernel's own roofline); unbinned (N = 1)
   extras        other call shapes of the same path (N = 1)
 """
 import argparse
@@ -369,6 +369,57 @@ def c5_leg(ctx, ranks, steps=24):
     return kern, scan
 
 
+def unbinned_leg(ctx, model, n_events=1000000, steps=24):
+    """The extended unbinned likelihood on the same machinery (UnbinnedLogLikelihood, blueice/likelihood.py:528-573,
+    :678-690), C2-shaped: 4 sources, 5^3 anchors, 10^6 events.
+      set_data   the events are scored at every anchor model ON THE DEVICE (bi_score_events: the resident C2 rows serve
+                 as the sources' density histograms, 'piecewise' lookup; only the 3 x N coordinates cross PCIe) --
+                 the reference loops `m.score_events(d)` over the 125 anchor models on the host (:557-560);
+      evaluate   `k_morph_reduce<1,false,true,2>`: 8 evaluations per launch in grid cells that share no anchor, each
+                 streams the 2^3 * 4 rows of pdf values at the events: 8 * 2^d * S * N bytes per evaluation, HBM-bound."""
+    from blueice_amd.device import DeviceContext
+    rng = np.random.default_rng(77)
+    edges = [np.linspace(0.0, 1.0, b + 1) for b in model.bins]
+    coords = [rng.uniform(0.0, 1.0, n_events) for _ in model.bins]
+    uctx = DeviceContext(ctx.device)
+    try:
+        ctx.score_events(uctx, 'piecewise', edges, coords)                 # warm (allocations)
+        t = time.perf_counter()
+        ctx.score_events(uctx, 'piecewise', edges, coords)
+        score_s = time.perf_counter() - t
+        # per-event rates: the rows are probabilities per bin (~1e-6), the "densities" of this synthetic exercise
+        sets = [model.disjoint_cell_points(parity=i, seed=50 + i) for i in range(4)]
+        plans = [uctx.plan(zz, rr) for zz, rr in sets]
+        PPS = len(sets[0][0])
+        NS = 2 ** model.d * model.S
+        nbytes = plans[0].bytes
+        assert plans[0].launches == 1 and nbytes == PPS * 8 * (NS + 1) * n_events, (nbytes, PPS)
+        nbytes = PPS * 8 * NS * n_events                                   # (the plan's figure counts a counts row; this mode reads none)
+        for i in range(8):
+            plans[i % 4].run()
+        uctx.sync()
+        uctx.profile(True)
+        for i in range(steps):
+            plans[i % 4].run()
+        n, ms = uctx.profile_read()
+        uctx.profile(False)
+        ll, st = plans[0].read()
+        assert not st.any() and np.all(np.isfinite(ll))
+        for p in plans:
+            p.close()
+        gbs = nbytes * n / (ms * 1e-3) / 1e9
+        return dict(workload='unbinned C2 shape: 4 sources, 5^3 anchors, %d events; %d evaluations per launch in disjoint grid cells' % (n_events, PPS),
+                    kernel='k_morph_reduce<1,false,true,2> (extended unbinned likelihood, nontemporal loads, in-launch finish)',
+                    bound='hbm', events=n_events, bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs,
+                    peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, evals_per_s=PPS * n / (ms * 1e-3),
+                    set_data_on_device_s=score_s,
+                    set_data_note='k_score_events fills the [125 anchors][4 sources][%d events] tensor (%.1f GB) from the 3 x N '
+                                  'coordinates: %.1f M pdf values per second' % (n_events, 8e-9 * model.A * model.S * n_events,
+                                                                               model.A * model.S * n_events / score_s / 1e6))
+    finally:
+        uctx.close()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: this process -- which has not touched the GPU, nor loaded the
     library -- starts N fresh rank processes of this script (blueice_amd.launch sets RANK / LOCAL_RANK / WORLD_SIZE and
@@ -683,6 +734,14 @@ def main():
             result['cpu_baseline']['all_cores'] = {'error': repr(e)}
     elif rank == 0:
         result['cpu_baseline'] = None
+
+    if rank == 0 and world == 1 and not args.no_legs:
+        try:
+            result['legs']['unbinned'] = unbinned_leg(ctx, model)
+            result['roofline_unbinned'] = {k: result['legs']['unbinned'][k] for k in
+                                           ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'bytes_per_launch', 'avg_launch_us')}
+        except Exception as e:                                  # a side leg: never lose the line over it
+            result['legs']['unbinned'] = {'error': repr(e)}
 
     # ---- configs[4], Beeston-Barlow: kernel roofline + strong-scaling scan on one grid cell, every N.  Last: the C5
     # cell's tensors replace the C2 model in this rank's context (same stream, same communicator, same gather buffers)

@@ -42,6 +42,9 @@ SIGNATURES = {
     'bi_histogram_events': (C.c_int, [_p, C.c_int, _p, _p, _i64, _p, _p]),
     'bi_score_events': (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _i64, _p, C.c_double]),
     'bi_set_unbinned': (C.c_int, [_p, _f64]),
+    'bi_simulate_events': (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_uint64, C.c_double, _p]),
+    'bi_download_events': (C.c_int, [_p, _p, _p]),
+    'bi_simulated_event_count': (_i64, [_p]),
     'bi_generate_toys': (C.c_int, [_p, _p, _p, _i64, C.c_uint64]),
     'bi_download_counts': (C.c_int, [_p, _i64, _p]),
     'bi_eval': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p]),

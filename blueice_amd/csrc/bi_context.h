@@ -168,6 +168,11 @@ struct bi_ctx {
     std::vector<void*> user_allocs;              // bi_device_alloc buffers still alive: freed with the context
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
+    // the events of the last bi_simulate_events into this context: coordinates [k][N], source index [N]
+    DevBuf sim_coords, sim_source;
+    int sim_k = 0;
+    int64_t sim_n = -1;
+
     // scratch
     DevBuf scratch, scratch2, logmu;
 

@@ -117,6 +117,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     dev_free(c->mail); dev_free(c->mail_flags);
     dev_free(c->ps_sorted); dev_free(c->cnt_sorted);
+    dev_free(c->sim_coords); dev_free(c->sim_source);
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     if (c->bounce_host) (void)hipHostFree(c->bounce_host);
@@ -1355,8 +1356,13 @@ int bi_set_unbinned(bi_ctx* c, double outlier_likelihood) {
     return BI_OK;
 }
 
-int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_grid, const double* grid, int64_t N,
-                    const double* coords, double outlier_likelihood) {
+}  // extern "C"
+
+namespace {
+
+// coords: host [k][N], or coords_dev: the same block already in HBM (bi_simulate_events)
+int score_events_impl(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_grid, const double* grid, int64_t N,
+                      const double* coords, const double* coords_dev, double outlier_likelihood) {
     if (!c) return BI_ERR_INVALID;
     if (!tp || tp == c) return fail(c, BI_ERR_INVALID, "need a templates context different from the target");
     if (c->pending || tp->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding: call bi_eval_end first");
@@ -1365,7 +1371,7 @@ int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_g
     if (tp->bb_source >= 0) return fail(c, BI_ERR_INVALID, "Beeston-Barlow applies to binned likelihoods only");
     if (method != 0 && method != 1) return fail(c, BI_ERR_INVALID, "method must be 0 (piecewise) or 1 (linear)");
     if (k < 1 || k > kMaxDim || !n_grid || !grid) return fail(c, BI_ERR_INVALID, "need 1..%d axes with grid values", kMaxDim);
-    if (N < 0 || (N > 0 && !coords)) return fail(c, BI_ERR_INVALID, "bad N / coords");
+    if (N < 0 || (N > 0 && !coords && !coords_dev)) return fail(c, BI_ERR_INVALID, "bad N / coords");
     ScoreArgs a{};
     a.k = k;
     a.method = method;
@@ -1391,18 +1397,18 @@ int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_g
     if (rc) return rc;
     if (N > 0) {
         DevBuf d_ev, d_grid;
-        if ((rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double)))) {
+        if ((!coords_dev && (rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double)))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double)))) {
             dev_free(d_ev); dev_free(d_grid);
             return rc;
         }
-        hipError_t e = hipMemcpyAsync(d_ev.p, coords, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        hipError_t e = coords_dev ? hipSuccess : hipMemcpyAsync(d_ev.p, coords, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_grid.p, grid, (size_t)off * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(tp->stream);            // whatever filled the templates is complete
         if (e == hipSuccess) {
             const int n_rows = (int)(tp->A * tp->S);
             const unsigned bx = (unsigned)((N + kThreads - 1) / kThreads);
             const unsigned by = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)c->prop.multiProcessorCount * 8 / bx));
-            hipLaunchKernelGGL(k_score_events, dim3(bx, by), dim3(kThreads), 0, c->stream, (const double*)d_ev.p, N, a,
+            hipLaunchKernelGGL(k_score_events, dim3(bx, by), dim3(kThreads), 0, c->stream, coords_dev ? coords_dev : (const double*)d_ev.p, N, a,
                                (const double*)d_grid.p, (const double*)tp->ps.p, tp->Bp, n_rows, (double*)c->ps.p, c->Bp);
             e = hipGetLastError();
         }
@@ -1417,6 +1423,139 @@ int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_g
     c->allow_neg = tp->allow_neg;
     return bi_set_unbinned(c, outlier_likelihood);
 }
+
+}  // namespace
+
+extern "C" {
+
+int bi_score_events(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n_grid, const double* grid, int64_t N,
+                    const double* coords, double outlier_likelihood) {
+    return score_events_impl(tp, c, method, k, n_grid, grid, N, coords, nullptr, outlier_likelihood);
+}
+
+int bi_simulate_events(bi_ctx* tp, bi_ctx* c, const double* z, const double* rate_scale, int method, int k, const int32_t* n_edges,
+                       const double* edges, uint64_t seed, double outlier_likelihood, int64_t* n_per_source) {
+    if (!c) return BI_ERR_INVALID;
+    if (!tp || tp == c) return fail(c, BI_ERR_INVALID, "need a templates context different from the target");
+    if (c->pending || tp->pending) return fail(c, BI_ERR_STATE, "a bi_eval_begin is outstanding: call bi_eval_end first");
+    if (!tp->model_ready) return fail(c, BI_ERR_STATE, "the templates context holds no model");
+    if (tp->device != c->device) return fail(c, BI_ERR_INVALID, "templates and target live on different devices");
+    if (method != 0 && method != 1) return fail(c, BI_ERR_INVALID, "method must be 0 (piecewise) or 1 (linear)");
+    if (k < 1 || k > kMaxDim || !n_edges || !edges) return fail(c, BI_ERR_INVALID, "need 1..%d axes with bin edges", kMaxDim);
+    if (tp->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
+    SimArgs a{};
+    a.k = k; a.S = tp->S; a.clip_to_centres = method == 1 ? 1 : 0;
+    int64_t bins = 1;
+    int off = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n_edges[i] < (method == 1 ? 3 : 2)) return fail(c, BI_ERR_INVALID, "axis %d has too few bin edges", i);
+        for (int j = 1; j < n_edges[i]; ++j)
+            if (!(edges[off + j] > edges[off + j - 1])) return fail(c, BI_ERR_INVALID, "bin edges of axis %d are not strictly ascending", i);
+        a.n_edges[i] = n_edges[i];
+        a.edge_off[i] = off;
+        off += n_edges[i];
+        bins *= n_edges[i] - 1;
+    }
+    if (bins != tp->B) return fail(c, BI_ERR_INVALID, "the edges describe %lld bins, the templates have %lld", (long long)bins, (long long)tp->B);
+    int64_t step = 1;
+    for (int i = k - 1; i >= 0; --i) { a.stride[i] = step; step *= n_edges[i] - 1; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    // expected events per source at z (the scalar half of likelihood.py:355-393), then N_s ~ Poisson
+    PointGeom g;
+    if (!point_geometry(tp, z, g)) return fail(c, BI_ERR_INVALID, "simulation point is outside the anchor box");
+    const int S = tp->S;
+    std::vector<double> r((size_t)S);
+    interp_mus(tp, g, r.data());
+    if (rate_scale) for (int s = 0; s < S; ++s) r[(size_t)s] *= rate_scale[s];
+    for (int s = 0; s < S; ++s)
+        if (!(r[(size_t)s] >= 0.0 && r[(size_t)s] < std::numeric_limits<double>::infinity()))
+            return fail(c, BI_ERR_INVALID, "event simulation needs rates in [0, inf)");
+    const int nc = (int)g.w.size();
+    const int64_t B = tp->B;
+    std::vector<int64_t> rowoff((size_t)S * nc);
+    for (int s = 0; s < S; ++s)
+        for (int corner = 0; corner < nc; ++corner)
+            rowoff[(size_t)s * nc + corner] = ((g.cell_anchor + corner_offset(tp, corner)) * S + s) * tp->Bp;
+    DevBuf d_row, d_w, d_dens, d_cdf, d_edges, d_rates, d_n, d_first, d_tmp;
+    auto cleanup = [&]() { dev_free(d_row); dev_free(d_w); dev_free(d_dens); dev_free(d_cdf); dev_free(d_edges); dev_free(d_rates);
+                           dev_free(d_n); dev_free(d_first); dev_free(d_tmp); };
+    int rc;
+    size_t scan_bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const double*)nullptr, (double*)nullptr, (size_t)B, rocprim::plus<double>(), c->stream);
+    std::vector<double> h_edges(edges, edges + off);
+    if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_w, g.w)) || (rc = dev_upload(c, d_edges, h_edges)) ||
+        (rc = dev_upload(c, d_rates, r)) || (rc = dev_alloc(c, d_dens, (size_t)S * B * sizeof(double))) ||
+        (rc = dev_alloc(c, d_cdf, (size_t)S * B * sizeof(double))) || (rc = dev_alloc(c, d_n, (size_t)S * sizeof(int64_t))) ||
+        (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256)))) { cleanup(); return rc; }
+    hipError_t e = hipStreamSynchronize(tp->stream);                      // whatever filled the templates is complete
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_morph_store, dim3((unsigned)((B + kThreads - 1) / kThreads), (unsigned)S), dim3(kThreads), 0, c->stream,
+                           (const double*)tp->ps.p, (const int64_t*)d_row.p, (const double*)d_w.p, nc, B, (double*)d_dens.p);
+        hipLaunchKernelGGL(k_sim_pmf, dim3((unsigned)((B + kThreads - 1) / kThreads), (unsigned)S), dim3(kThreads), 0, c->stream,
+                           (const double*)d_dens.p, a, (const double*)d_edges.p, B, (double*)d_dens.p);
+        e = hipGetLastError();
+    }
+    for (int s = 0; e == hipSuccess && s < S; ++s) {
+        size_t tb = d_tmp.bytes;
+        e = rocprim::inclusive_scan(d_tmp.p, tb, (const double*)d_dens.p + (size_t)s * B, (double*)d_cdf.p + (size_t)s * B, (size_t)B,
+                                    rocprim::plus<double>(), c->stream);
+    }
+    std::vector<int64_t> n_s((size_t)S, 0);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sim_counts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, c->stream, (const double*)d_rates.p, S, seed, (int64_t*)d_n.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(n_s.data(), d_n.p, (size_t)S * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, BI_ERR_HIP, "bi_simulate_events: %s", hipGetErrorString(e)); }
+    std::vector<int64_t> first((size_t)S + 1, 0);
+    for (int s = 0; s < S; ++s) first[(size_t)s + 1] = first[(size_t)s] + n_s[(size_t)s];
+    const int64_t N = first[(size_t)S];
+    if (n_per_source) std::copy(n_s.begin(), n_s.end(), n_per_source);
+    // the events themselves: coordinates [k][N] and the source of every event, kept with the target for bi_download_events
+    if ((rc = dev_alloc(c, c->sim_coords, (size_t)std::max<int64_t>(N, 1) * k * sizeof(double))) ||
+        (rc = dev_alloc(c, c->sim_source, (size_t)std::max<int64_t>(N, 1) * sizeof(int32_t))) || (rc = dev_upload(c, d_first, first))) { cleanup(); return rc; }
+    c->sim_k = k;
+    c->sim_n = N;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_sim_events, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, (const double*)d_cdf.p, B, a,
+                           (const double*)d_edges.p, (const int64_t*)d_first.p, seed, N, (double*)c->sim_coords.p, (int32_t*)c->sim_source.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_simulate_events: %s", hipGetErrorString(e));
+    // score them at every anchor model: the grid of the lookup is the edges ('piecewise') or the bin centres ('linear')
+    std::vector<int32_t> n_grid((size_t)k);
+    std::vector<double> grid;
+    int eo = 0;
+    for (int i = 0; i < k; ++i) {
+        if (method == 0) {
+            n_grid[(size_t)i] = n_edges[i];
+            grid.insert(grid.end(), edges + eo, edges + eo + n_edges[i]);
+        } else {
+            n_grid[(size_t)i] = n_edges[i] - 1;
+            for (int j = 0; j + 1 < n_edges[i]; ++j) grid.push_back(0.5 * (edges[eo + j] + edges[eo + j + 1]));
+        }
+        eo += n_edges[i];
+    }
+    // (bi_model_begin inside re-allocates the target's model, not the sim_* buffers)
+    return score_events_impl(tp, c, method, k, n_grid.data(), grid.data(), N, nullptr, (const double*)c->sim_coords.p, outlier_likelihood);
+}
+
+int bi_download_events(bi_ctx* c, double* coords, int32_t* source) {
+    if (!c) return BI_ERR_INVALID;
+    if (c->sim_n < 0) return fail(c, BI_ERR_STATE, "no simulated events are resident (bi_simulate_events first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->sim_n > 0 && coords)
+        HIP_TRY(c, hipMemcpyAsync(coords, c->sim_coords.p, (size_t)c->sim_n * c->sim_k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (c->sim_n > 0 && source)
+        HIP_TRY(c, hipMemcpyAsync(source, c->sim_source.p, (size_t)c->sim_n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BI_OK;
+}
+
+int64_t bi_simulated_event_count(const bi_ctx* c) { return c ? c->sim_n : -1; }
 
 // ---- compatibility mode --------------------------------------------------------------------
 

@@ -138,6 +138,26 @@ int bi_set_unbinned(bi_ctx* ctx, double outlier_likelihood);
 int bi_score_events(bi_ctx* templates, bi_ctx* target, int method, int k, const int32_t* n_grid, const double* grid,
                     int64_t N, const double* coords, double outlier_likelihood);
 
+/* Event-level toy Monte Carlo on the device, for the unbinned likelihood with histogram-pdf sources: what
+ * `Model.simulate` (blueice/model.py:69-91) does source by source on the host -- N_s ~ Poisson(mu_s) events, each drawn
+ * from the source's pdf, for a histogram pdf a bin with probability density x volume and a uniform position inside it
+ * (`HistogramPdfSource.simulate`, blueice/source.py:248-264) -- followed by `set_data` (likelihood.py:531-563), without
+ * the events ever leaving HBM.  `templates` holds the density histograms of every source at every anchor (as for
+ * bi_score_events); the events are drawn at parameter point (z, rate_scale) from the MORPHED densities, scored at every
+ * anchor model, and become the (unbinned) data of `target`.  Philox4x32-10 keyed by the seed; counters are (event within
+ * its source, source), so a toy does not depend on launch geometry.
+ *   method 0 / 1   the sources' pdf_interpolation_method 'piecewise' / 'linear' (as bi_score_events; with 'linear' the
+ *                  coordinates are clipped to the outer bin centres before scoring, source.py:232-241)
+ *   n_edges [k], edges concatenated: the BIN EDGES of the analysis space
+ *   n_per_source [S] or NULL: receives the number of events drawn per source
+ * bi_download_events copies the simulated coordinates [k][N] (and the source index of every event) to the host,
+ * N = bi_simulated_event_count. */
+int bi_simulate_events(bi_ctx* templates, bi_ctx* target, const double* z, const double* rate_scale, int method, int k,
+                       const int32_t* n_edges, const double* edges, uint64_t seed, double outlier_likelihood,
+                       int64_t* n_per_source);
+int bi_download_events(bi_ctx* target, double* coords /*[k][N] or NULL*/, int32_t* source /*[N] or NULL*/);
+int64_t bi_simulated_event_count(const bi_ctx* target);
+
 /* Toy-MC datasets generated on the device: n_{t,b} ~ Poisson(mu_b), mu_b = sum_s r_s p_{s,b}(z) -- the binned
  * equivalent of Model.simulate (blueice/model.py:69-91: Poisson number of events per source, each drawn from
  * the source's pdf) followed by set_data's binning (blueice/likelihood.py:603-609).  Philox4x32-10 keyed by
