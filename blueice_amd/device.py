@@ -210,6 +210,36 @@ class DeviceContext:
         target.d, target.S, target.B, target.bb_source, target.T = self.d, self.S, int(cols.shape[1]), -1, 1
         target.anchor_z = self.anchor_z
 
+    def simulate_events(self, target, method, edges, z, rate_scale=None, seed=0, outlier_likelihood=1e-12):
+        """This context holds density histograms as its model rows: draw an event-level toy dataset from them at (z,
+        rate_scale) on the device -- `Model.simulate` for histogram-pdf sources -- and make it the (unbinned) data of
+        `target`, scored at every anchor model, without a host hop.  edges: the bin edges of every analysis dimension.
+        -> events per source [S]."""
+        code = {'piecewise': 0, 'linear': 1}[method]
+        edges = [np.ascontiguousarray(e, dtype=np.float64) for e in edges]
+        n_edges = np.array([len(e) for e in edges], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(edges))
+        z = as_f64(z).reshape(self.d) if self.d else None
+        if rate_scale is not None:
+            rate_scale = as_f64(rate_scale, (self.S,))
+        per_source = np.zeros(self.S, dtype=np.int64)
+        target._check(self._lib.bi_simulate_events(self._h, target._h, ptr(z), ptr(rate_scale), code, len(edges), ptr(n_edges),
+                                                   ptr(flat), int(seed) & (2**64 - 1), float(outlier_likelihood), ptr(per_source)))
+        target.d, target.S, target.B, target.bb_source, target.T = self.d, self.S, int(per_source.sum()), -1, 1
+        target.anchor_z = self.anchor_z
+        target._sim_dims = len(edges)
+        return per_source
+
+    def download_events(self):
+        """The events of the last simulate_events into this context -> (coords [k, N], source index [N])."""
+        n = int(self._lib.bi_simulated_event_count(self._h))
+        if n < 0:
+            raise NotPreparedException("no simulated events are resident")
+        coords = np.empty((self._sim_dims, n), dtype=np.float64)
+        source = np.empty(n, dtype=np.int32)
+        self._check(self._lib.bi_download_events(self._h, ptr(coords), ptr(source)))
+        return coords, source
+
     def set_unbinned(self, outlier_likelihood=1e-12):
         """Treat the uploaded rows as pdf values at the events: extended unbinned likelihood."""
         self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))

@@ -864,6 +864,42 @@ class UnbinnedLogLikelihood(DeviceLogLikelihood):
         self.ctx.set_unbinned(self.outlier_likelihood)
 
 
+    @_needs_preparation
+    def simulate_toy(self, seed=0, livetime_days=None, **kwargs):
+        """Draw an event-level toy dataset ON THE DEVICE at the given parameter values and make it the likelihood's data:
+        what `d = lf.base_model.simulate(...)` + `lf.set_data(d)` do on the host (model.py:69-91, source.py:248-264,
+        likelihood.py:531-563) -- per source N_s ~ Poisson(mu_s) events, each a bin drawn with probability density x
+        volume of the (morphed) histogram pdf and a uniform position inside it, then scored at every anchor model --
+        with nothing but the call crossing PCIe.  Needs sources whose pdf is a histogram (see `set_data`); raises
+        NotImplementedError otherwise.  -> events per source; `simulated_events()` fetches the events themselves."""
+        tpl = self._histogram_templates()
+        if not tpl:
+            raise NotImplementedError("device-side event simulation needs sources whose pdf is a histogram over the analysis space")
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        if prior is None:
+            raise ValueError("cannot simulate outside the anchor box")
+        tp, method, _ = tpl
+        if self.ctx is None:
+            self.ctx = DeviceContext(self.config.get('device'))
+        edges = [np.asarray(e, dtype=float) for _, e in self.base_model.config['analysis_space']]
+        per_source = tp.simulate_events(self.ctx, method, edges, zs, scale, seed, self.outlier_likelihood)
+        self._data = None
+        self.bin_shape = (int(per_source.sum()),)
+        self.is_data_set = True
+        return per_source
+
+    def simulated_events(self):
+        """The events of the last `simulate_toy` as a record array with the analysis dimensions and a 'source' field, as
+        `Model.simulate` returns them."""
+        coords, source = self.ctx.download_events()
+        names = [n for n, _ in self.base_model.config['analysis_space']]
+        d = np.zeros(coords.shape[1], dtype=[(n, float) for n in names] + [('source', int)])
+        for n, c in zip(names, coords):
+            d[n] = c
+        d['source'] = source
+        return d
+
+
 class LogLikelihoodSum:
     """Weighted sum of likelihoods sharing (some) parameters, with the likelihood interface the inference
     helpers need (reference: blueice/likelihood.py:867-955).  A host-side combinator: every term is its own

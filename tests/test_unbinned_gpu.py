@@ -220,3 +220,75 @@ def test_fit_and_sum(ns):
     assert tot.get_bounds('shift') == (-1.0, 1.0)
     res, ll = tot.bestfit_scipy(s1_rate_multiplier=1.)
     assert set(res) == {'s0_rate_multiplier', 'shift'} and ll >= tot(s1_rate_multiplier=1.) - 1e-9
+
+
+@pytest.mark.parametrize('dims,method', [(1, 'linear'), (2, 'piecewise'), (3, 'linear')])
+def test_event_level_toys_drawn_on_the_device(ns, dims, method):
+    """`lf.simulate_toy(**params)` = base_model.simulate() + set_data on the device (bi_simulate_events; reference:
+    blueice/model.py:69-91, source.py:248-264, likelihood.py:531-563).  An RNG stream cannot be compared with numpy's bit
+    for bit, so the LAW is pinned -- events per source ~ Poisson(mu_s), bins ~ the morphed pmf, positions uniform inside
+    the bin -- together with reproducibility from the seed, and the likelihood of the toy: downloaded and handed to
+    set_data() like any dataset, the same events give the same number."""
+    from collections import OrderedDict
+    space = [['x', np.linspace(-4, 4, 17)], ['y', np.array([0., 0.4, 1., 2.2, 3.5, 5.])], ['w', np.linspace(-1, 1, 6)]][:dims]
+    rng = np.random.default_rng(300 + dims)
+    lf = model_zoo.morph_lf(ns, rng, 3, space, OrderedDict(shift=(-1., 0., 1.)), 6000, 50, unbinned=True,
+                            extra_config=dict(pdf_interpolation_method=method))
+    kw = dict(shift=0.35, s1_rate_multiplier=1.5)
+    per_source = lf.simulate_toy(seed=11, **kw)
+    ll = lf(**kw)
+    assert np.isfinite(ll) and lf.ctx.B == per_source.sum()
+    ev = lf.simulated_events()
+    assert len(ev) == per_source.sum() and list(np.bincount(ev['source'], minlength=3)) == list(per_source)
+    # the same toy again from the same seed; another seed, another toy
+    again = lf.simulate_toy(seed=11, **kw)
+    np.testing.assert_array_equal(again, per_source)
+    assert lf(**kw) == ll
+    for nm in ev.dtype.names:
+        np.testing.assert_array_equal(lf.simulated_events()[nm], ev[nm])
+    assert not np.array_equal(lf.simulate_toy(seed=12, **kw), per_source) or lf(**kw) != ll
+    # handed back through set_data like any dataset: the same likelihood (to rounding: the host path clips and scores
+    # the same coordinates)
+    lf.set_data(ev)
+    assert same(lf(**kw), ll, 1e-13)
+    # the law: many toys.  Events per source against mu_s, the bin occupancy of source 0 against its morphed pmf
+    mus = lf.mus_interpolator(np.array([0.35])) * np.array([1.0, 1.5, 1.0])
+    counts = np.zeros(3)
+    edges = [np.asarray(e, dtype=float) for _, e in space]
+    occ = np.zeros([len(e) - 1 for e in edges])
+    frac = []
+    n_toys = 400
+    for seed in range(n_toys):
+        counts += lf.simulate_toy(seed=1000 + seed, **kw)
+        ev = lf.simulated_events()
+        sel = ev[ev['source'] == 0]
+        occ += np.histogramdd(np.stack([sel[nm] for nm, _ in space], axis=1), bins=edges)[0]
+        x, e0 = sel[space[0][0]], edges[0]
+        i = np.clip(np.searchsorted(e0, x, side='right') - 1, 0, len(e0) - 2)
+        frac.append((x - e0[i]) / (e0[i + 1] - e0[i]))
+    assert np.all(np.abs(counts - n_toys * mus) < 5 * np.sqrt(n_toys * mus))
+    tp, _, _ = lf._templates
+    dens = tp.interpolate('ps', np.array([0.35]))[0].reshape(occ.shape)          # source 0's density at shift = 0.35
+    vol = np.ones(occ.shape)
+    for ax, e in enumerate(edges):
+        shape = [1] * len(edges)
+        shape[ax] = len(e) - 1
+        vol = vol * np.diff(e).reshape(shape)
+    pmf = np.maximum(dens * vol, 0)
+    pmf /= pmf.sum()
+    expected = pmf * occ.sum()
+    big = expected > 20
+    pulls = (occ[big] - expected[big]) / np.sqrt(expected[big])
+    assert abs(pulls.mean()) < 0.25 and 0.7 < pulls.std() < 1.3, (pulls.mean(), pulls.std())
+    assert occ[pmf == 0].sum() == 0                                               # no event where the pdf is zero
+    if method == 'piecewise':                                                     # uniform inside the bin (unclipped coordinates)
+        f = np.concatenate(frac)
+        assert abs(f.mean() - 0.5) < 0.01 and abs(f.var() - 1 / 12) < 0.005
+    # outside the anchor box there is nothing to draw from; analytic pdfs have no device route
+    with pytest.raises(ValueError):
+        lf.simulate_toy(shift=3.0)
+    plain = ns.UnbinnedLogLikelihood(ns.conf_for_test(events_per_day=3.))
+    plain.add_shape_parameter('some_multiplier', (0.5, 1, 2))
+    plain.prepare()
+    with pytest.raises(NotImplementedError):
+        plain.simulate_toy()
