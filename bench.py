@@ -619,11 +619,11 @@ def main():
     # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from the
     # committed summary of the same command (profiles/), corrected as MI355X_MICROARCH.md prescribes
     traffic = traffic_src = None
-    for name in ('r02_pmc_traffic.json',):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 pm = json.load(f)
-            if pm.get('algorithmic_bytes_per_launch') == bytes_per_launch:
+            if traffic is None and pm.get('algorithmic_bytes_per_launch') == bytes_per_launch:
                 traffic = pm['traffic_bytes_per_launch']
                 traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' % name
         except Exception:

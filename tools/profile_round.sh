@@ -5,6 +5,7 @@
 #   fetch/ write/ PMC FETCH_SIZE / WRITE_SIZE of the headline kernel (own passes)
 #   extras/       kernel trace + stats of the bench with its legs and extras
 #   bb*/          Beeston-Barlow pass (tools/profile/bb_only.py): kernel trace, FETCH_SIZE
+#   unb*/         unbinned pass (tools/profile/unbinned_only.py): kernel trace, FETCH_SIZE
 set -e -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -18,6 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/extras" -o extras 
 python3 tools/profile/bb_only.py 20 > "$OUT/bb_plain.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bbkt" -o bb -- python3 tools/profile/bb_only.py 20 > "$OUT/bb_kt.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/bbfetch" -o bb -- python3 tools/profile/bb_only.py 8 > "$OUT/bb_fetch.txt" 2>&1
+python3 tools/profile/unbinned_only.py 24 > "$OUT/unb_plain.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/unbkt" -o unb -- python3 tools/profile/unbinned_only.py 24 > "$OUT/unb_kt.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/unbfetch" -o unb -- python3 tools/profile/unbinned_only.py 8 > "$OUT/unb_fetch.txt" 2>&1
 # keep what travels back small: the per-dispatch kernel trace is large, the stats and counter files are not
 find "$OUT" -name '*kernel_trace.csv' -size +4M -delete
 ls "$OUT" "$OUT"/*/ | head -60

@@ -65,6 +65,7 @@ def main(rnd):
                     KERNEL, row['Calls'], us, algo / us / 1e6, algo / us / 1e6 / 8 * 100, bench['roofline']['avg_launch_us']))
     print('traffic / algorithmic = %.4f (read %.4f GB, write %.1f KB per launch)' % ((rd + wr) / algo, rd / 1e9, wr / 1e3))
     summarize_bb(tag, dst)
+    summarize_unbinned(tag, dst)
     summarize_scan(tag, dst)
 
 
@@ -108,6 +109,31 @@ def summarize_bb(tag, dst):
         json.dump(out, f, indent=1)
     print('BB kernel: %.1f us -> %.0f GB/s (%.3f of 8 TB/s), traffic / algorithmic %.4f' % (
         st['average_us'], out['achieved_GBps'], out['frac_of_8TBps'], out['traffic_over_algorithmic']))
+
+
+def summarize_unbinned(tag, dst):
+    """The unbinned pass (tools/profile/unbinned_only.py): kernel trace + FETCH_SIZE -> rNN_unbinned.json."""
+    kt = os.path.join(SRC, 'unbkt', 'unb_kernel_stats.csv')
+    if not os.path.exists(kt):
+        return
+    shutil.copy(kt, os.path.join(dst, tag + '_unbinned_kernel_stats.csv'))
+    needle = 'k_morph_reduce<1, false, true, 2>'
+    st = _kernel_stats(kt, needle)
+    score = _kernel_stats(kt, 'k_score_events')
+    fetch, n = _kernel_counters(os.path.join(SRC, 'unbfetch', 'unb_counter_collection.csv'), needle)
+    algo = 8 * 8 * 32 * 10 ** 6
+    rd = fetch['FETCH_SIZE'] * 1024 * 2
+    out = {'command': 'rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE (separate runs) -- python3 tools/profile/unbinned_only.py',
+           'workload': 'extended unbinned likelihood, C2 shape (4 sources, 5^3 anchors), 10^6 events, 8 evaluations per launch in disjoint grid cells',
+           'kernel': needle.replace(', ', ','), 'kernel_trace': st, 'set_data_kernel_trace': score,
+           'algorithmic_bytes_per_launch': algo, 'algorithmic_note': '8 evaluations * 8 B * 2^3 corners * 4 sources * 10^6 events (no counts row in this mode)',
+           'achieved_GBps': algo / st['average_us'] / 1e3, 'frac_of_8TBps': algo / st['average_us'] / 1e3 / 8000,
+           'FETCH_SIZE_KB_mean': fetch['FETCH_SIZE'], 'fetch_launches': n, 'hbm_read_bytes_per_launch': rd,
+           'traffic_over_algorithmic': rd / algo, 'hip_event_line': open(os.path.join(SRC, 'unb_plain.txt')).read().strip()}
+    with open(os.path.join(dst, tag + '_unbinned.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('unbinned kernel: %.1f us -> %.0f GB/s (%.3f of 8 TB/s), traffic / algorithmic %.4f; k_score_events %.1f us' % (
+        st['average_us'], out['achieved_GBps'], out['frac_of_8TBps'], out['traffic_over_algorithmic'], score['average_us'] if score else -1))
 
 
 def _scan_block(src, needle, points=131072, flop_per_eval=2.0 * 32 * 10 ** 6):

@@ -15,6 +15,8 @@ POINTS = 131072
 
 def counters(order):
     agg, launches, name = collections.defaultdict(float), 0, ''
+    if not os.path.exists(os.path.join(SRC, 'pmc_%s' % order, 'pmc_counter_collection.csv')):
+        return None
     with open(os.path.join(SRC, 'pmc_%s' % order, 'pmc_counter_collection.csv')) as f:
         for row in csv.DictReader(f):
             if 'k_scan_mfma' in row['Kernel_Name']:
@@ -57,6 +59,24 @@ def main(rnd):
         out['evaluations_per_s_by_kernel_trace'] = POINTS / (trace['average_us'] * 1e-6)
     with open(os.path.join(dst, tag + '_scan_dense_data_pmc.json'), 'w') as f:
         json.dump(out, f, indent=1)
+    sparse = counters('sparse')
+    if sparse:
+        st = {}
+        with open(os.path.join(SRC, 'kts', 'kt_kernel_stats.csv')) as f:
+            for row in csv.DictReader(f):
+                if 'k_scan_mfma' in row['Name']:
+                    st = dict(name=row['Name'], calls=int(row['Calls']), average_us=float(row['AverageNs']) / 1e3,
+                              min_us=float(row['MinNs']) / 1e3, max_us=float(row['MaxNs']) / 1e3)
+        shutil.copy(os.path.join(SRC, 'kts', 'kt_kernel_stats.csv'), os.path.join(dst, tag + '_sparse_scan_kernel_stats.csv'))
+        with open(os.path.join(dst, tag + '_sparse_scan_pmc.json'), 'w') as f:
+            json.dump(dict(round=rnd, command='tools/profile_scan_dense.sh: rocprofv3 --pmc <8 SQ counters> / --kernel-trace --stats (own run) '
+                                              '-- python3 tools/profile/sparse_scan_only.py',
+                           workload='10^6-point scan of C2 on the default path (non-empty-bin form): k_scan_mfma over the compacted rows, '
+                                    'ordered by count (one logarithm per lane, work item and 32-bin strip)',
+                           kernel_trace=st, evaluations_per_s_by_kernel_trace=(1e6 / (st['average_us'] * 1e-6) if st else None),
+                           previous_round='profiles/r02_sparse_scan_pmc.json: k_scan_mfma<2,8,false,true> 14.6 ms, 7.95 vector instructions per MFMA, matrix pipe busy 57.7 %',
+                           **sparse), f, indent=1)
+        print('default-path scan: %s' % st, sparse['derived'])
     d1, d0 = out['count_sorted_rows']['derived'], out['rows_in_bin_order']['derived']
     print('vector instructions per MFMA %.2f -> %.2f; LDS conflict share of wave cycles %.1f %% -> %.1f %%; matrix pipe busy %.1f %% -> %.1f %%' % (
         d0['other_vector_instructions_per_mfma'], d1['other_vector_instructions_per_mfma'],
