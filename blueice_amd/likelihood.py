@@ -499,10 +499,16 @@ class DeviceLogLikelihood(LogLikelihoodBase):
         names = list(points.keys())
         cols = [np.atleast_1d(np.asarray(points[n], dtype=float)) for n in names]
         P = max((len(c) for c in cols), default=1)
-        cols = [np.broadcast_to(c, (P,)) for c in cols]
+        cols = [c if len(c) == P else np.broadcast_to(c, (P,)) for c in cols]
+        known = self.__dict__.get('_batch_names')          # (validated names and defaults: rebuilt when the parameters change)
+        key = (tuple(self.shape_parameters), tuple(self.source_name_list))
+        if known is None or known[0] != key:
+            known = self._batch_names = (key, set(), self._kwargs_to_settings()[1])
         for k in names:
-            self._kwargs_to_settings(**{k: 0.0})       # name validation only
-        _, defaults = self._kwargs_to_settings()
+            if k not in known[1]:
+                self._kwargs_to_settings(**{k: 0.0})       # name validation only
+                known[1].add(k)
+        defaults = known[2]
         z = np.empty((P, len(self.shape_parameters)))
         prior = np.zeros(P)
         for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):

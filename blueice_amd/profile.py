@@ -78,11 +78,12 @@ class BatchObjective:
         return -ll[0], -g
 
 
-def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=30, ftol=1e-15):
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=20, ftol=1e-15, slow_window=8, slow_tol=1e-11):
     """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
     lo / hi [F]: box (+-inf = none).  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
     gtol, or two successive steps that lowered f by less than ftol * max(1, |f|): the rounding floor),
-    info['stalled'] [P] (no descent step found: a kink of the morph), info['iterations'], info['calls'] (device launches)."""
+    info['stalled'] [P] (no descent step found, or less than slow_tol * max(1, |f|) gained over the last slow_window
+    iterations: a kink of the morph, where the search zigzags between two grid cells), info['iterations'], info['calls']."""
     x = np.clip(np.array(x0, dtype=float), lo, hi)
     P, F = x.shape
     rows_all = np.arange(P)
@@ -96,6 +97,8 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
     stalled = np.zeros(P, dtype=bool)
     converged = np.zeros(P, dtype=bool)
     flat = np.zeros(P, dtype=np.int32)                   # successive steps without a measurable decrease
+    history = np.full((slow_window, P), np.inf)          # f of the last slow_window iterations (ring buffer)
+    crawled = np.zeros(P, dtype=bool)
     at_lo = lambda xx: xx <= lo
     at_hi = lambda xx: xx >= hi
     # no step carries a boxed variable (a shape parameter) further than a quarter of its range -- a tenth on a plain
@@ -107,6 +110,21 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
         pg = np.where(blocked, 0.0, g)
         converged |= ~done & (np.max(np.abs(pg), axis=1, initial=0.0) <= gtol)
         done |= converged
+        # hardly anything gained over the last slow_window iterations: the zigzag across a kink of the morph
+        slot = it % slow_window
+        with np.errstate(invalid='ignore'):
+            crawling = ~done & (history[slot] - f <= slow_tol * np.maximum(1.0, np.abs(f)))
+        history[slot] = f
+        # ... the first time, distrust the Hessian estimate and go on with gradient steps; the second time, stop
+        again = crawling & crawled
+        first = crawling & ~crawled
+        if np.any(first):
+            B[first] = eye
+            fresh[first] = True
+            history[:, first] = np.inf
+            crawled[first] = True
+        stalled |= again
+        done |= again
         act = np.flatnonzero(~done)
         if not len(act):
             break
