@@ -58,7 +58,7 @@ bool ensure_sorted_rows(bi_ctx* c) {
     c->sorted_epoch = c->epoch;
     c->sorted_ok = false;
     const int64_t B = c->B, Bp = c->Bp, rows = c->A * c->S;
-    if (!c->scan_pow || c->T != 1 || !c->dense_counts || c->unbinned || c->bb_source >= 0 || B < 4096 || B > INT32_MAX || rows > 65535) return false;
+    if (!c->scan_pow || c->T != 1 || !c->dense_counts || c->unbinned || c->bb_source >= 0 || B < 64 || B > INT32_MAX || rows > 65535) return false;
     if ((rows + 1) * Bp * (int64_t)sizeof(double) > c->compact_budget) return false;
     DevBuf d_iota, d_perm, d_tmp;
     auto drop = [&]() { dev_free(d_iota); dev_free(d_perm); dev_free(d_tmp); };

@@ -267,6 +267,56 @@ def test_gradient_random_configurations_against_finite_differences(seed):
 
 
 @pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_beeston_barlow_gradient_random_configurations(seed):
+    """bi_eval_grad with Beeston-Barlow on random models (0-3 shape axes incl. single-anchor ones, 1-5 sources, any source
+    as the Beeston-Barlow one): value = bi_eval's, slopes against central differences of the oracle inside grid cells.
+    With a single source every bin has U_b == 0 -- the reference's special case, differentiated as such."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(7600 + seed)
+    ctx = DeviceContext(0)
+    for rep in range(4):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 3, 5]))
+        B = int(rng.choice([3, 37, 512, 700]))
+        bb = int(rng.integers(0, S))
+        model, counts = random_case(rng, d, S, B, bb)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'], n_model=model['n_model'], bb_source=bb)
+        ctx.upload_counts(counts)
+        P = 5
+        z = np.empty((P, d))
+        h = np.empty(d)
+        for ax, g in enumerate(model['anchor_z']):
+            if len(g) == 1:
+                z[:, ax], h[ax] = g[0], 0.0
+                continue
+            k = rng.integers(0, len(g) - 1, P)
+            z[:, ax] = g[k] + (g[k + 1] - g[k]) * rng.uniform(0.2, 0.8, P)
+            h[ax] = 1e-5 * np.min(np.diff(g))
+        r = rng.uniform(0.3, 2.0, (P, S))
+        ll, gz, gs, st = ctx.eval_grad(z if d else None, r)
+        ref, rst = ctx.eval(z if d else None, r)
+        np.testing.assert_array_equal(st, rst)
+        f = lambda zz, rr: orc.loglikelihood(model, counts, zz, rr, bb_source=bb, forgive_zero_u=True)
+        for i in np.flatnonzero(st == 0):
+            want = f(z[i], r[i])
+            assert abs(ll[i] - ref[i]) <= 1e-13 * max(1, abs(ref[i])) and abs(ll[i] - want) <= RTOL * max(1, abs(want))
+            scale = max(1.0, abs(want))
+            for ax in range(d):
+                if h[ax] == 0.0:
+                    continue
+                e = np.zeros(d); e[ax] = h[ax]
+                fd = (f(z[i] + e, r[i]) - f(z[i] - e, r[i])) / (2 * h[ax])
+                assert abs(gz[i, ax] - fd) <= 1e-4 * max(abs(fd), scale / max(np.ptp(model['anchor_z'][ax]), 1e-9) * 1e-3), \
+                    (seed, rep, d, S, B, bb, i, ax, gz[i, ax], fd)
+            for s in range(S):
+                e = np.zeros(S); e[s] = 1e-6 * r[i, s]
+                fd = (f(z[i], r[i] + e) - f(z[i], r[i] - e)) / (2 * e[s])
+                assert abs(gs[i, s] - fd) <= 1e-4 * max(abs(fd), 1e-3 * scale), (seed, rep, d, S, B, bb, i, s, gs[i, s], fd)
+    ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
 def test_device_histogram_random_spaces_equal_numpy_histogramdd(seed):
     """bi_upload_events (set_data on the device, likelihood.py:603-609) on random analysis spaces: 1-4 axes, uniform and
     non-uniform edges, events exactly on edges (interior, first, last), outside, +-inf, nan."""

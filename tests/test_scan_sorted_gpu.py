@@ -149,3 +149,45 @@ def test_sparse_product_form_with_subnormal_intermediates():
         want = orc.loglikelihood(model, counts, z[i], r[i])
         assert np.isfinite(want) and abs(ll[i] - want) <= 1e-12 * abs(want), (i, ll[i], want)
     ctx.close()
+
+
+_FIRST, _COUNT = (int(v) for v in __import__('os').environ.get('BLUEICE_FUZZ_SEEDS', '0:0').split(':'))
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_sorted_rows_random_models_match_oracle(seed):
+    """Random small models (0-3 shape axes, ragged bin counts, exact zeros in the templates), ONE dense dataset with the
+    odd count thrown in, scans large enough for the matrix-core kernel: count-sorted rows against the oracle point by
+    point, nan / -inf pattern included.  BLUEICE_FUZZ_SEEDS=first:count widens the campaign."""
+    from test_fuzz_gpu import random_case, random_points
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(8000 + seed)
+    ctx = DeviceContext(0)
+    ctx.set_param('sparse', 0)
+    used = 0
+    for rep in range(3):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 3, 4, 5, 8]))
+        B = int(rng.choice([64, 100, 511, 512, 700, 1300]))
+        model, _ = random_case(rng, d, S, B, -1)
+        lam = (model['mus'].reshape(-1, S)[0][:, None] * model['ps'].reshape(-1, S, B)[0]).sum(axis=0)
+        counts = rng.poisson(np.maximum(lam, 0.02) * (12.0 / max(lam.mean(), 1e-9))).astype(float)      # ~12 events per bin
+        if rng.random() < 0.4:
+            counts[rng.integers(B)] = rng.choice([np.nan, -1.0, 2.5])
+        if rng.random() < 0.3:
+            counts[rng.integers(0, B, 5)] = 0.0
+        P = int(rng.integers(700, 1600))
+        z, r = random_points(rng, model, P, S)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        ctx.upload_counts(counts)
+        before = ctx.get_param('n_sorted_scans')
+        got, st = ctx.eval(z if d else None, r)
+        used += ctx.get_param('n_sorted_scans') > before
+        for i in range(0, P, 7):
+            w = orc.loglikelihood(model, counts, z[i], r[i])
+            g = got[i]
+            assert (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= 1e-10 * max(1, abs(w))), \
+                (seed, rep, d, S, B, i, g, w, st[i])
+    assert used >= 1 or _COUNT
+    ctx.close()
