@@ -987,6 +987,21 @@ class LogLikelihoodSum:
                 grads[name] = grads.get(name, 0.) + weight * slope
         return total, grads
 
+    def values_and_gradients(self, points, livetime_days=None, **options):
+        """The batched form, as on the single likelihoods: points = dict name -> array [P] -> (ll [P], OrderedDict name ->
+        slopes [P]), the weighted sums of the terms' (one device call per term).  What the batched profile-fit engine
+        iterates with on a sum of likelihoods."""
+        if not self.supports_gradient:
+            raise NotImplementedError("a term of this sum has no analytic gradient (unbinned)")
+        total, grads = 0., OrderedDict()
+        for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights)):
+            lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
+            v, g = ll.values_and_gradients({k: x for k, x in points.items() if k in names}, livetime_days=lt, **options)
+            total = total + weight * v
+            for name, slope in g.items():
+                grads[name] = grads.get(name, 0.) + weight * slope
+        return total, grads
+
     def split_results(self, result_dict):
         return [{k: v for k, v in result_dict.items() if k in names} for names in self.likelihood_parameters]
 
