@@ -99,6 +99,7 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
     flat = np.zeros(P, dtype=np.int32)                   # successive steps without a measurable decrease
     history = np.full((slow_window, P), np.inf)          # f of the last slow_window iterations (ring buffer)
     crawled = np.zeros(P, dtype=bool)
+    reach = np.ones(P)                                   # length (max norm) of the last accepted step: the scale of a fresh gradient step
     at_lo = lambda xx: xx <= lo
     at_hi = lambda xx: xx >= hi
     # no step carries a boxed variable (a shape parameter) further than a quarter of its range -- a tenth on a plain
@@ -139,9 +140,10 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             d = np.zeros_like(ga)
         slope = np.sum(d * ga, axis=1)
         reset = ~(slope < 0) | fresh[act] | ~np.all(np.isfinite(d), axis=1)
-        if np.any(reset):                                            # steepest descent, first step of length ~1 in x
-            pga = pg[act][reset]
-            d[reset] = -pga / np.maximum(1.0, np.sum(np.abs(pga), axis=1, keepdims=True))
+        if np.any(reset):      # steepest descent; the step is ~1 long in x at the start, a few times the last accepted step later
+            pga = pg[act][reset]   # (near the optimum a unit step would cost twenty halvings, each a device call)
+            length = np.minimum(1.0, 4.0 * reach[act][reset])[:, None]
+            d[reset] = -pga / np.maximum(1.0 / length, np.sum(np.abs(pga), axis=1, keepdims=True) / length)
             B[act[reset]] = eye
             fresh[act[reset]] = True
             slope = np.sum(d * ga, axis=1)
@@ -208,6 +210,7 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
                 sBs = np.sum(sg * Bs, axis=1)
                 Bg = Bg - (Bs[:, :, None] * Bs[:, None, :]) / sBs[:, None, None] + (yg[:, :, None] * yg[:, None, :]) / sy[good][:, None, None]
                 B[rows[good]] = Bg
+            reach[rows] = np.maximum(np.max(np.abs(acc_x[w] - xa[w]), axis=1), 1e-12)
             gain = f[rows] - acc_f[w]
             flat[rows] = np.where(gain <= ftol * np.maximum(1.0, np.abs(acc_f[w])), flat[rows] + 1, 0)
             x[rows], f[rows], g[rows] = acc_x[w], acc_f[w], acc_g[w]
