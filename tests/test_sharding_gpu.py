@@ -236,4 +236,28 @@ def test_scan_dealt_on_the_device_equals_one_plan(sparse):
             p.close()
         for b in (send, recv, full):
             b.free()
+    # fewer valid points than ranks: some shares are empty, and a scan whose every point is rejected has no share at all
+    for zz, rr, n_ok in ((z[:4], r[:4], 4), (z[5:6], r[5:6], 0)):
+        world = 8
+        stride = 1
+        send, recv, full = ctx.device_alloc(8), ctx.device_alloc(8 * world), ctx.device_alloc(8 * len(zz))
+        recv.from_host(np.full(world, np.nan))
+        plans = []
+        for rank in range(world):
+            plan = ctx.plan_share(zz, rr, None, rank, world)
+            assert plan.n_valid == n_ok and plan.share[1] - plan.share[0] == (1 if rank < n_ok else 0)
+            plan.run(send.ptr)
+            plan.status()
+            if plan.share[1] > plan.share[0]:
+                recv.from_host(send.to_host(np.float64, 1), offset_bytes=8 * rank)
+            plans.append(plan)
+        plans[0].unsort(recv.ptr, stride, full.ptr)
+        got = full.to_host(np.float64, len(zz))
+        ref = ctx.eval(zz, rr)[0]
+        np.testing.assert_allclose(got[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-12)
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+        for p in plans:
+            p.close()
+        for b in (send, recv, full):
+            b.free()
     ctx.close()
