@@ -303,13 +303,11 @@ int ensure_plan_tables(bi_ctx* c) {
 // the dealing of a scan over several GPUs done where the sort already happens (every rank plans the same P points and
 // gets the same order; rank r takes sorted positions [lo_r, hi_r)).  Its results then come out in sorted order
 // (out[0 .. hi - lo)), and the plan keeps the sorted -> original index map for unsort_share.
-int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out, int share_rank = 0, int share_world = 1) {
-    int rc = ensure_plan_tables(c);
-    if (rc) return rc;
-    const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
+// the model / data description the planning kernels take by value (tables: ensure_plan_tables)
+PlanMeta plan_meta_of(const bi_ctx* c, bool sparse) {
+    const int S = c->S, d = c->d, de = (int)c->eff_axes.size();
     PlanMeta m{};
-    m.d = d; m.S = S; m.de = de; m.nc = nc; m.unbinned = c->unbinned ? 1 : 0; m.sparse = sparse ? 1 : 0;   // (split scans switch m.sparse on below)
+    m.d = d; m.S = S; m.de = de; m.nc = 1 << de; m.unbinned = c->unbinned ? 1 : 0; m.sparse = sparse ? 1 : 0;
     m.T = c->T; m.Bp = c->Bp; m.n_rows = c->A * S;
     int off = 0;
     for (int i = 0; i < d; ++i) { m.n_anchor[i] = c->n_anchor[(size_t)i]; m.grid_off[i] = off; off += c->n_anchor[(size_t)i]; m.astride[i] = c->astride[(size_t)i]; }
@@ -320,6 +318,246 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     m.c_off = (const int64_t*)c->pt_c_off.p; m.cnt_off = (const int64_t*)c->pt_cnt_off.p; m.c_np = (const int64_t*)c->pt_c_np.p;
     m.Tz = (const double*)c->pt_Tz.p;
     m.rowsum = (const double*)c->pt_rowsum.p;
+    return m;
+}
+
+// Gradient mode (bi_eval_grad) for large batches: one work item per point, its descriptors written where they are read.
+// The coefficient MATRIX of a point -- [2^d * S stream rows][G columns: value, d/dz_j, d/drate_s] -- is 2 KB at C2; built on
+// the host that is 268 MB to fill, stage and copy for 131 072 points (105 of the call's 145 ms), built here it is a few
+// microseconds of stores.  One thread per point: the scalar half of likelihood.py:345-415 as in k_plan_geometry, then
+// d w_c / d z_i = (+-1/delta_i) prod_{j != i} w^(j), d mus_s / d z_i, and the columns.  Rejected points keep their status,
+// get a work item of zero tiles, and are answered on the host.
+constexpr int kGradMaxCorners = 1 << 6;          // d_eff <= 6 on this path (the host path has no such limit)
+constexpr int kGradFillThreads = 64;
+// per-thread work arrays live in LDS, [index][lane] (conflict-free): w[64], dmus[6][16], mus[16], r[16], lg[16], t[8], 1/delta[8].
+// In registers they would be indexed dynamically, i.e. sit in scratch -- 1.9 KB per lane, which the runtime provisions for
+// every wave slot of the chip (~1 GB) on every launch: 3 ms per call.
+constexpr int kGradFillDoubles = kGradMaxCorners + 6 * 16 + 16 + 16 + 16 + kMaxDim + kMaxDim;
+__global__ __launch_bounds__(kGradFillThreads) void k_grad_fill(PlanMeta m, int64_t P, const double* __restrict__ z,
+                                                                const double* __restrict__ rate_scale, const int64_t* __restrict__ dataset, int G,
+                                                                int64_t* __restrict__ rowoff, double* __restrict__ coef, int64_t* __restrict__ cnt_off,
+                                                                int32_t* __restrict__ tiles, int64_t* __restrict__ perm, double* __restrict__ slot_lg,
+                                                                int32_t* __restrict__ status) {
+    extern __shared__ double s_grad[];
+    const int lane = threadIdx.x;
+#define BI_AT(base, i) s_grad[((base) + (i)) * kGradFillThreads + lane]
+#define W_(c) BI_AT(0, c)
+#define DMUS_(i, s) BI_AT(kGradMaxCorners, (i) * 16 + (s))
+#define MUS_(s) BI_AT(kGradMaxCorners + 96, s)
+#define R_(s) BI_AT(kGradMaxCorners + 112, s)
+#define LG_(q) BI_AT(kGradMaxCorners + 128, q)
+#define T_(i) BI_AT(kGradMaxCorners + 144, i)
+#define ID_(i) BI_AT(kGradMaxCorners + 144 + kMaxDim, i)
+    const int64_t p = (int64_t)blockIdx.x * kGradFillThreads + threadIdx.x;
+    if (p >= P) return;
+    const int NS = m.nc * m.S, W = 1 + m.d + m.S;
+    int32_t st = 0;
+    const int64_t ds = dataset ? dataset[p] : 0;
+    if (ds < 0 || ds >= m.T) st = BI_ST_BAD_DATASET;
+    int64_t cell = 0;
+    if (!st) {
+        for (int i = 0; i < m.d; ++i) {
+            const double* g = m.grid + m.grid_off[i];
+            const int n = m.n_anchor[i];
+            const double zi = z[p * m.d + i];
+            if (!(g[0] <= zi && zi <= g[n - 1])) { st = BI_ST_OUT_OF_BOUNDS; break; }
+            int k = 0;
+            double ti = 0.0, id = 0.0;
+            if (n > 1) {
+                if (zi == g[n - 1]) {
+                    k = n - 2;
+                } else {
+                    while (k + 1 < n && g[k + 1] <= zi) ++k;
+                    k = min(k, n - 2);
+                }
+                ti = (zi - g[k]) / (g[k + 1] - g[k]);
+                id = 1.0 / (g[k + 1] - g[k]);
+            }
+            T_(i) = ti;
+            ID_(i) = id;
+            cell += (int64_t)k * m.astride[i];
+        }
+    }
+    if (!st) {
+        for (int corner = 0; corner < m.nc; ++corner) {
+            double wc = 1.0;
+            for (int i = 0; i < m.de; ++i) {
+                const double ti = T_(m.eff_axes[i]);
+                wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? ti : (1 - ti));
+            }
+            W_(corner) = wc;
+        }
+        bool any_fin = false, phys = true;
+        double tot = 0.0;
+        for (int s = 0; s < m.S; ++s) {
+            double v = 0.0;
+            for (int corner = 0; corner < m.nc; ++corner) {
+                const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * W_(corner);
+                v = v + term;
+            }
+            MUS_(s) = v;
+            if (rate_scale) v *= rate_scale[p * m.S + s];
+            R_(s) = v;
+            any_fin |= (v < __builtin_inf());
+            tot += v;
+            if (!m.any_allow_neg) { if (!(v >= 0 && v < __builtin_inf())) phys = false; }
+            else if (!(0 <= v) && !m.allow_neg[s]) phys = false;
+        }
+        if (m.any_allow_neg && (!any_fin || tot < 0)) phys = false;
+        if (!phys) st = BI_ST_UNPHYSICAL;
+    }
+    status[p] = st;
+    int64_t* ro = rowoff + p * NS;
+    double* co = coef + p * NS * G;
+    for (int q = 0; q < G; ++q) { perm[p * G + q] = (!st && q < W) ? p * W + q : -1; slot_lg[p * G + q] = 0.0; }
+    if (st) {                                    // a work item that does nothing
+        for (int k = 0; k < NS; ++k) ro[k] = 0;
+        cnt_off[p] = 0;
+        tiles[p] = 0;
+        return;
+    }
+    const int64_t row_stride = m.sparse ? m.c_np[ds] : m.Bp;
+    const int64_t row_base = m.sparse ? m.c_off[ds] : 0;
+    for (int q = 0; q < W; ++q) LG_(q) = 0.0;
+    // d w_c / d z_i = (+-1/delta_i) prod_{j != i} w^(j)
+    auto dw = [&](int corner, int i) {
+        double v = (((corner >> (m.de - 1 - i)) & 1) ? 1.0 : -1.0) * ID_(m.eff_axes[i]);
+        for (int j = 0; j < m.de; ++j) {
+            if (j == i) continue;
+            const double tj = T_(m.eff_axes[j]);
+            v *= ((corner >> (m.de - 1 - j)) & 1) ? tj : (1 - tj);
+        }
+        return v;
+    };
+    // d mus_s / d z_i = sum over corners of d w_c / d z_i times the anchor's expectation
+    for (int i = 0; i < m.de; ++i) {
+        for (int s = 0; s < m.S; ++s) DMUS_(i, s) = 0.0;
+        for (int c2 = 0; c2 < m.nc; ++c2) {
+            const double v = dw(c2, i);
+            for (int s = 0; s < m.S; ++s) DMUS_(i, s) += v * m.mus[(cell + m.corner_off[c2]) * m.S + s];
+        }
+    }
+    int k = 0;
+    for (int corner = 0; corner < m.nc; ++corner) {
+        const int64_t a = cell + m.corner_off[corner];
+        const double wc = W_(corner);
+        for (int s = 0; s < m.S; ++s, ++k) {
+            const int64_t row = a * m.S + s;
+            ro[k] = row_base + row * row_stride;
+            double* col = co + (int64_t)k * G;
+            for (int q = 0; q < G; ++q) col[q] = 0.0;
+            const double rs = rate_scale ? rate_scale[p * m.S + s] : 1.0;
+            const double tz = m.sparse ? m.Tz[ds * m.n_rows + row] : 0.0;
+            const double c0 = wc * R_(s);
+            col[0] = c0;
+            LG_(0) += c0 * tz;
+            for (int i = 0; i < m.de; ++i) {     // total derivative: through the weights and through mus(z)
+                const double v = dw(corner, i) * R_(s) + wc * DMUS_(i, s) * rs;
+                col[1 + m.eff_axes[i]] = v;
+                LG_(1 + m.eff_axes[i]) += v * tz;
+            }
+            const double cr = wc * MUS_(s);
+            col[1 + m.d + s] = cr;
+            LG_(1 + m.d + s) += cr * tz;
+        }
+    }
+    LG_(0) += m.lgsum[ds];
+    for (int q = 0; q < W; ++q) slot_lg[p * G + q] = LG_(q);
+    cnt_off[p] = m.sparse ? m.cnt_off[ds] : ds * m.Bp;
+    tiles[p] = (int32_t)(row_stride / kTile);
+#undef BI_AT
+#undef W_
+#undef DMUS_
+#undef MUS_
+#undef R_
+#undef LG_
+#undef T_
+#undef ID_
+}
+
+// bi_eval_grad for batches planned on the device (plain binned likelihoods): -> ll [P], grad [P][d + S], status [P]
+int eval_grad_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse, int G,
+                     double* ll, double* grad, int32_t* status) {
+    int rc = ensure_plan_tables(c);
+    if (rc) return rc;
+    const int S = c->S, d = c->d, W = 1 + d + S, NS = (1 << (int)c->eff_axes.size()) * S;
+    PlanMeta m = plan_meta_of(c, sparse);
+    DevBuf d_z, d_rs, d_ds, d_row, d_coef, d_cnt, d_tiles, d_perm, d_lg, d_st, d_part, d_flag, d_out;
+    auto cleanup = [&]() { dev_free(d_z); dev_free(d_rs); dev_free(d_ds); dev_free(d_row); dev_free(d_coef); dev_free(d_cnt); dev_free(d_tiles);
+                           dev_free(d_perm); dev_free(d_lg); dev_free(d_st); dev_free(d_part); dev_free(d_flag); dev_free(d_out); };
+    const size_t nP = (size_t)P;
+    int max_tiles = n_tiles_of(c);
+    if (sparse) max_tiles = (int)(*std::max_element(c->h_c_np.begin(), c->h_c_np.end()) / kTile);
+    const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
+    const int nbx = (int)std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + P - 1) / P));
+    if ((rc = dev_alloc(c, d_z, nP * std::max(d, 1) * 8)) || (rate_scale && (rc = dev_alloc(c, d_rs, nP * S * 8))) ||
+        (dataset && (rc = dev_alloc(c, d_ds, nP * 8))) || (rc = dev_alloc(c, d_row, nP * NS * 8)) || (rc = dev_alloc(c, d_coef, nP * NS * G * 8)) ||
+        (rc = dev_alloc(c, d_cnt, nP * 8)) || (rc = dev_alloc(c, d_tiles, nP * 4)) || (rc = dev_alloc(c, d_perm, nP * G * 8)) ||
+        (rc = dev_alloc(c, d_lg, nP * G * 8)) || (rc = dev_alloc(c, d_st, nP * 4)) || (rc = dev_alloc(c, d_part, nP * nbx * G * 8)) ||
+        (rc = dev_alloc(c, d_flag, nP * nbx * G * 4)) || (rc = dev_alloc(c, d_out, nP * W * 8))) { cleanup(); return rc; }
+    hipError_t e = hipSuccess;
+    if (d) e = hipMemcpyAsync(d_z.p, z, nP * d * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && rate_scale) e = hipMemcpyAsync(d_rs.p, rate_scale, nP * S * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && dataset) e = hipMemcpyAsync(d_ds.p, dataset, nP * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const size_t lds = (size_t)kGradFillDoubles * kGradFillThreads * sizeof(double);                   // 112 KB of the CU's 160
+        e = hipFuncSetAttribute((const void*)k_grad_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(k_grad_fill, dim3((unsigned)((P + kGradFillThreads - 1) / kGradFillThreads)), dim3(kGradFillThreads), lds, c->stream, m, P, (const double*)d_z.p,
+                           rate_scale ? (const double*)d_rs.p : nullptr, dataset ? (const int64_t*)d_ds.p : nullptr, G, (int64_t*)d_row.p,
+                           (double*)d_coef.p, (int64_t*)d_cnt.p, (int32_t*)d_tiles.p, (int64_t*)d_perm.p, (double*)d_lg.p, (int32_t*)d_st.p);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { cleanup(); return fail(c, BI_ERR_HIP, "bi_eval_grad (device planning): %s", hipGetErrorString(e)); }
+    LaunchArgs a{};
+    a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
+    a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
+    a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = max_tiles; a.chunks = (int)c->tile_chunks;
+    for (int64_t i0 = 0; i0 < P; i0 += 65535) {
+        const int64_t ni = std::min<int64_t>(65535, P - i0);
+        LaunchArgs b = a;
+        b.rowoff = (const int64_t*)d_row.p + i0 * NS;
+        b.coef = (const double*)d_coef.p + i0 * NS * G;
+        b.item_cnt = (const int64_t*)d_cnt.p + i0;
+        b.item_tiles = (const int32_t*)d_tiles.p + i0;
+        b.partial = (double*)d_part.p + i0 * nbx * G;
+        b.pflags = (unsigned*)d_flag.p + i0 * nbx * G;
+        launch_morph_grad(c, G, b, dim3((unsigned)nbx, (unsigned)ni), false);
+        const int64_t n_slots = ni * G;
+        const int lanes = nbx > 64 ? kThreads : 64;
+        const int per_block = kThreads / lanes;
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
+                           (const double*)b.partial, (const unsigned*)b.pflags, nbx, G, lanes, n_slots, (const int64_t*)d_perm.p + i0 * G,
+                           (const double*)d_lg.p + i0 * G, (double*)d_out.p, (int32_t*)nullptr);
+    }
+    std::vector<double> h_out(nP * W);
+    std::vector<int32_t> h_st(nP);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_st.data(), d_st.p, nP * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_grad (device planning): %s", hipGetErrorString(e));
+    const double ninf = -std::numeric_limits<double>::infinity(), qnan = std::numeric_limits<double>::quiet_NaN();
+    for (int64_t p = 0; p < P; ++p) {
+        if (status) status[p] = h_st[(size_t)p];
+        if (h_st[(size_t)p]) {
+            ll[p] = ninf;
+            for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = qnan;
+        } else {
+            ll[p] = h_out[(size_t)p * W];
+            for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = h_out[(size_t)p * W + 1 + j];
+        }
+    }
+    return BI_OK;
+}
+
+int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
+                       bi_plan** out, int share_rank = 0, int share_world = 1) {
+    int rc = ensure_plan_tables(c);
+    if (rc) return rc;
+    const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
+    PlanMeta m = plan_meta_of(c, sparse);                    // (split scans switch m.sparse on below)
 
     bi_plan* plan = new bi_plan();
     plan->P = P; plan->sparse = sparse; plan->epoch = c->epoch; plan->device_planned = true; plan->no_reuse = false;

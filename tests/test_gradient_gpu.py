@@ -229,3 +229,44 @@ def test_beeston_barlow_fit_with_analytic_gradient():
     assert 0 < calls['n'] < scalar_calls / 2
     best, ll_b, info = lf.bestfit_batched(return_info=True)
     assert info['analytic_gradient'] and ll_b[0] >= ll_fd - 1e-6 * abs(ll_fd)
+
+
+@pytest.mark.parametrize('sparse', [0, 2])
+@pytest.mark.parametrize('name', ['c1_like', 'd2_nonuniform', 'd3_small', 'd0_multi_source'])
+def test_large_gradient_batches_planned_on_the_device(name, sparse):
+    """bi_eval_grad builds the descriptors of batches of >= 512 points on the device (k_grad_fill): same values, slopes
+    and status words as the host-planned path, rejected points (outside the box, nan, unphysical rates, bad dataset)
+    and several datasets included."""
+    from blueice_amd.device import DeviceContext
+    c = load_case(name)
+    ctx = DeviceContext(0)
+    ctx.set_param('sparse', sparse)
+    ctx.upload_model(c['model']['anchor_z'], c['model']['ps'], c['model']['mus'])
+    rng = np.random.default_rng(9)
+    counts = np.stack([c['counts'], rng.poisson(c['counts'] + 0.3).astype(float), np.zeros_like(c['counts'])])
+    ctx.upload_counts(counts)
+    P = 900
+    zs = np.array([[rng.uniform(g[0], g[-1]) for g in c['model']['anchor_z']] for _ in range(P)]).reshape(P, c['d'])
+    rs = rng.uniform(0.4, 1.6, size=(P, c['S']))
+    ds = rng.integers(0, 3, P)
+    if c['d']:
+        zs[3, 0] = c['model']['anchor_z'][0][-1] + 1.0
+        zs[4, c['d'] - 1] = np.nan
+        zs[5] = [g[-1] for g in c['model']['anchor_z']]          # the top corner of the box
+        zs[6] = [g[0] for g in c['model']['anchor_z']]
+    rs[7, 0] = -0.5
+    rs[8] = 0.0
+    ds[9] = 11
+    got = ctx.eval_grad(zs if c['d'] else None, rs, ds)
+    ctx.set_param('device_plan_min', 0)                          # the same call planned on the host
+    want = ctx.eval_grad(zs if c['d'] else None, rs, ds)
+    np.testing.assert_array_equal(got[3], want[3])
+    assert got[3][7] == 2 and got[3][9] == 16 and (not c['d'] or (got[3][3] == 1 and got[3][4] == 1))
+    ok = want[3] == 0
+    assert ok.sum() > P - 10
+    np.testing.assert_allclose(got[0][ok], want[0][ok], rtol=1e-13)
+    assert np.all(np.isneginf(got[0][~ok])) and np.all(np.isnan(got[1][~ok])) and np.all(np.isnan(got[2][~ok]))
+    scale = np.maximum(1.0, np.abs(want[0][ok]))[:, None]
+    np.testing.assert_allclose(got[1][ok], want[1][ok], rtol=1e-10, atol=1e-11 * scale.max())
+    np.testing.assert_allclose(got[2][ok], want[2][ok], rtol=1e-10, atol=1e-11 * scale.max())
+    ctx.close()
