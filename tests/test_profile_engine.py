@@ -168,3 +168,33 @@ def test_stencil_batching_gives_scipy_its_own_differences(d2):
     v, g = f_b(top)
     assert np.all(np.isfinite(g))
     assert not np.all(np.isfinite(f_st(top)[1]))              # unbounded: the forward step leaves the anchor box (+inf), as in scipy
+
+
+def test_first_crossing_finds_brentqs_root():
+    """The batched bracket search of one_parameter_interval on plain functions: the root nearest to the starting end, to
+    brentq's precision, in a handful of batched rounds; brentq's error on equal signs; exact zeros at the ends."""
+    from scipy.optimize import brentq
+    from blueice_amd.inference import _first_crossing
+    calls = []
+
+    def batched(f):
+        def tfun(hs):
+            calls.append(len(hs))
+            return np.array([f(h) for h in hs])
+        return tfun
+
+    for f, a, b in ((lambda x: x ** 3 - 2 * x - 5, 2.0, 3.0), (lambda x: np.exp(-x) - 0.1, 0.0, 50.0),
+                    (lambda x: 2.7 - (x - 1) ** 2, 1.0, 40.0), (lambda x: np.cos(x), 3.0, 0.0)):
+        calls.clear()
+        got = _first_crossing(batched(f), a, b)
+        want = brentq(f, min(a, b), max(a, b), xtol=1e-13)
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (got, want)
+        assert len(calls) <= 9 and sum(calls) <= 140           # rounds, evaluations
+    # several roots: the one nearest to a
+    f = lambda x: np.sin(x)
+    assert abs(_first_crossing(batched(f), 2.0, 11.0) - np.pi) <= 1e-9
+    assert abs(_first_crossing(batched(f), 11.0, 2.0) - 3 * np.pi) <= 1e-9
+    with pytest.raises(ValueError, match='different signs'):
+        _first_crossing(batched(lambda x: x * x + 1), -1.0, 1.0)
+    assert _first_crossing(batched(lambda x: x - 1.0), 1.0, 5.0) == 1.0
+    assert _first_crossing(batched(lambda x: x - 5.0), 1.0, 5.0) == 5.0
