@@ -40,6 +40,9 @@ __device__ __forceinline__ void log_table_load() {
 }
 
 __device__ __forceinline__ bool pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
+// Factors of the product forms of sum n log mu (k_scan_mfma): up to eight of them, each above 2^-127, multiply to at least
+// 2^-1016 -- a normal number -- in any grouping; a comparison with it is false for nan, zero and negative numbers too.
+constexpr double kProdFloor = 0x1p-127;
 
 // the core: x must be a positive normal number (anything else gives a meaningless but harmless value);
 // k_adjust is added to the binary exponent
@@ -2144,30 +2147,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
 #define BI_EPILOGUE(cb)                                                                                            \
     do {                                                                                                           \
         if (alldata[cb]) { /* dense data: n log mu in every bin; mu <= 0 / nan comes out of the checked logarithm */ \
+            if ((PROD == 2 && uniform[cb]) || (PROD == 1 && ones_twos[cb])) { /* (wave-uniform) product forms */       \
+                bool low = false;                                                                                  \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) low |= !(acc[cb][r] > kProdFloor);                   \
+                if (__ballot(low) == 0ull) {                                                                       \
+                    /* PROD 2: one count per lane, n log of the product over the lane's four bins; PROD 1: counts  */ \
+                    /* of 1 and 2 only, ONE logarithm of the product of mu^n.  At most eight factors above         */ \
+                    /* kProdFloor: no partial product can be subnormal, one that overflows stays +inf to the end   */ \
+                    double f[4];                                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+                        f[r] = (PROD == 1 && n[cb][r] == 2.0) ? acc[cb][r] * acc[cb][r] : acc[cb][r];              \
+                    const double prod = (f[0] * f[1]) * (f[2] * f[3]);                                             \
+                    if (__ballot(!pos_normal(prod)) == 0ull) {                                                     \
+                        s[cb & 3] = fma(PROD == 2 ? n[cb][0] : 1.0, bin_log_fast(prod), s[cb & 3]);                \
+                        break;                                                                                     \
+                    }                                                                                              \
+                }                                                                                                  \
+            }                                                                                                      \
             bool checked = false;                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
             if (__ballot(checked) == 0ull) {                                                                       \
-                if (PROD == 2 && uniform[cb]) { /* one count per lane: n log of the product over the lane's four bins */ \
-                    const double f01 = acc[cb][0] * acc[cb][1], f23 = acc[cb][2] * acc[cb][3];                     \
-                    const double prod = f01 * f23;                                                                 \
-                    if (__ballot(!(pos_normal(f01) && pos_normal(f23) && pos_normal(prod))) == 0ull) {             \
-                        s[cb & 3] = fma(n[cb][0], bin_log_fast(prod), s[cb & 3]);                                  \
-                        break;                                                                                     \
-                    }                                                                                              \
-                }                                                                                                  \
-                if (PROD == 1 && ones_twos[cb]) { /* counts of 1 and 2 only: ONE logarithm of the product mu^n over the lane's four bins */ \
-                    double f[4];                                                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
-                        f[r] = n[cb][r] == 2.0 ? acc[cb][r] * acc[cb][r] : acc[cb][r];                             \
-                    /* every intermediate must stay a positive normal number: a subnormal pair product next to a  */ \
-                    /* large one gives a normal total that has already lost mantissa bits                         */ \
-                    const double f01 = f[0] * f[1], f23 = f[2] * f[3];                                             \
-                    const double prod = f01 * f23;                                                                 \
-                    if (__ballot(!(pos_normal(f01) && pos_normal(f23) && pos_normal(prod))) == 0ull) {             \
-                        s[cb & 3] += bin_log_fast(prod);                                                           \
-                        break;                                                                                     \
-                    }                                                                                              \
-                }                                                                                                  \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb][r], bin_log_fast(acc[cb][r]), s[r]); \
             } else {                                                                                               \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb][r] * bin_log(acc[cb][r]);              \
@@ -2207,13 +2206,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
                     const double b01 = acc[1][0] * acc[1][1], b23 = acc[1][2] * acc[1][3];
                     const double pa = a01 * a23, pb = b01 * b23;
                     const double pp = pa * pb;
-                    // (bitwise on purpose: fifteen class tests and scalar ANDs, no branches)
+                    // eight factors above kProdFloor: no partial product can be subnormal, and one that overflows stays
+                    // +inf through the remaining (positive) factors -- eight compares and ONE class test, no branches
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
-                    const bool ok = pos_normal(acc[0][0]) & pos_normal(acc[0][1]) & pos_normal(acc[0][2]) & pos_normal(acc[0][3]) &
-                                    pos_normal(acc[1][0]) & pos_normal(acc[1][1]) & pos_normal(acc[1][2]) & pos_normal(acc[1][3]) &
-                                    pos_normal(a01) & pos_normal(a23) & pos_normal(b01) & pos_normal(b23) & pos_normal(pa) &
-                                    pos_normal(pb) & pos_normal(pp);
+                    const bool ok = (acc[0][0] > kProdFloor) & (acc[0][1] > kProdFloor) & (acc[0][2] > kProdFloor) &
+                                    (acc[0][3] > kProdFloor) & (acc[1][0] > kProdFloor) & (acc[1][1] > kProdFloor) &
+                                    (acc[1][2] > kProdFloor) & (acc[1][3] > kProdFloor) & pos_normal(pp);
 #pragma clang diagnostic pop
                     if (__ballot(!ok) == 0ull) {
                         tot = n[0][0] * bin_log_fast(pp);

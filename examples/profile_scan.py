@@ -1,6 +1,6 @@
 """A profiled likelihood scan and an upper limit through the reference's API -- run as
 
-    python examples/profile_scan.py
+    PYTHONPATH=. python examples/profile_scan.py
 
 `plot_likelihood_ratio` / `one_parameter_interval` of the reference fit the nuisance parameters once per hypothesis, one
 scalar likelihood call after the other (blueice/inference.py:332-443).  Here every hypothesis is fitted at the same time:
