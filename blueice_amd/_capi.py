@@ -55,6 +55,7 @@ SIGNATURES = {
     'bi_plan_points': (C.c_int, [_p, _i64, _p, _p, _p, C.POINTER(_p)]),
     'bi_run_plan': (C.c_int, [_p, _p, _p]),
     'bi_plan_points_share': (C.c_int, [_p, _i64, _p, _p, _p, C.c_int, C.c_int, C.POINTER(_p)]),
+    'bi_plan_points_resident': (C.c_int, [_p, _i64, _p, _p, _p, C.c_int, C.c_int, C.POINTER(_p)]),
     'bi_plan_share_info': (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'bi_plan_unsort': (C.c_int, [_p, _p, _p, _i64, _p]),
     'bi_plan_read': (C.c_int, [_p, _p, _p, _p]),

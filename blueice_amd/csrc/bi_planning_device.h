@@ -553,7 +553,7 @@ int eval_grad_device(bi_ctx* c, int64_t P, const double* z, const double* rate_s
 }
 
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out, int share_rank = 0, int share_world = 1) {
+                       bi_plan** out, int share_rank = 0, int share_world = 1, bool resident = false) {
     int rc = ensure_plan_tables(c);
     if (rc) return rc;
     const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
@@ -566,26 +566,31 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                            dev_free(d_keys2); dev_free(d_idx); dev_free(d_idx2); dev_free(d_a); dev_free(d_b); dev_free(d_tmp); dev_free(d_scal); };
     auto abort_plan = [&](int code) { cleanup(); free_plan_buffers(plan); delete plan; return code; };
     const size_t nP = (size_t)P;
-    if ((rc = dev_alloc(c, d_z, nP * std::max(d, 1) * sizeof(double))) || (rc = dev_alloc(c, d_wts, nP * nc * sizeof(double))) ||
+    // resident: z / rate_scale / dataset ARE device arrays (bi_plan_points_resident) and are read where they lie
+    if ((!resident && (rc = dev_alloc(c, d_z, nP * std::max(d, 1) * sizeof(double)))) || (rc = dev_alloc(c, d_wts, nP * nc * sizeof(double))) ||
         (rc = dev_alloc(c, d_rates, nP * S * sizeof(double))) || (rc = dev_alloc(c, d_keys, nP * 8)) || (rc = dev_alloc(c, d_keys2, nP * 8)) ||
         (rc = dev_alloc(c, d_idx, nP * 8)) || (rc = dev_alloc(c, d_idx2, nP * 8)) || (rc = dev_alloc(c, d_a, nP * 8)) ||
         (rc = dev_alloc(c, d_b, nP * 8)) || (rc = dev_alloc(c, d_scal, 64)) ||
         (rc = dev_alloc(c, plan->status, nP * sizeof(int32_t))) || (rc = dev_alloc(c, plan->out, nP * sizeof(double))))
         return abort_plan(rc);
     hipError_t e = hipSuccess;
-    if (d) e = hipMemcpyAsync(d_z.p, z, nP * d * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && rate_scale) {
+    const double* z_dev = resident ? z : (const double*)d_z.p;
+    const double* rs_dev = resident ? rate_scale : nullptr;
+    const int64_t* ds_dev = resident ? dataset : nullptr;
+    if (d && !resident) e = hipMemcpyAsync(d_z.p, z, nP * d * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && rate_scale && !resident) {
         if ((rc = dev_alloc(c, d_rs, nP * S * sizeof(double)))) return abort_plan(rc);
         e = hipMemcpyAsync(d_rs.p, rate_scale, nP * S * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        rs_dev = (const double*)d_rs.p;
     }
-    if (e == hipSuccess && dataset) {
+    if (e == hipSuccess && dataset && !resident) {
         if ((rc = dev_alloc(c, d_ds, nP * 8))) return abort_plan(rc);
         e = hipMemcpyAsync(d_ds.p, dataset, nP * 8, hipMemcpyHostToDevice, c->stream);
+        ds_dev = (const int64_t*)d_ds.p;
     }
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning upload: %s", hipGetErrorString(e)));
     const unsigned nblk = (unsigned)((P + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, (const double*)d_z.p,
-                       rate_scale ? (const double*)d_rs.p : nullptr, dataset ? (const int64_t*)d_ds.p : nullptr,
+    hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
                        (double*)d_wts.p, (double*)d_rates.p, (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p);
     // sort (key, point) pairs: keys are cell * T + dataset, rejected points carry the largest key
     size_t tmp_bytes = 0;

@@ -494,6 +494,40 @@ int bi_plan_points_share(bi_ctx* c, int64_t P, const double* z, const double* ra
     return plan_points(c, P, z, rate_scale, dataset, out, /*transient=*/false, share_rank, share_world);
 }
 
+int bi_plan_points_resident(bi_ctx* c, int64_t P, const double* z_dev, const double* rate_scale_dev, const int64_t* dataset_dev,
+                            int share_rank, int share_world, bi_plan** out) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!out) return fail(c, BI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (P < 0 || P > (int64_t)1 << 30) return fail(c, BI_ERR_INVALID, "P outside [0, 2^30]");
+    if (share_world < 1 || share_rank < 0 || share_rank >= share_world)
+        return fail(c, BI_ERR_INVALID, "share %d outside [0,%d)", share_rank, share_world);
+    if (c->d > 0 && P > 0 && !z_dev) return fail(c, BI_ERR_INVALID, "z_dev is NULL");
+    if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "resident points are planned on the device: not available with Beeston-Barlow");
+    bool any_neg = false;
+    for (int q = 0; q < c->S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
+    if (any_neg) return fail(c, BI_ERR_INVALID, "resident points are planned on the device: not available with sources that may have negative rates");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (P == 0) return plan_points(c, 0, nullptr, nullptr, nullptr, out);
+    const void* ptrs[3] = {c->d > 0 ? (const void*)z_dev : nullptr, rate_scale_dev, dataset_dev};
+    const char* names[3] = {"z_dev", "rate_scale_dev", "dataset_dev"};
+    for (int i = 0; i < 3; ++i) {
+        if (!ptrs[i]) continue;
+        hipPointerAttribute_t at;
+        const hipError_t e = hipPointerGetAttributes(&at, ptrs[i]);
+        if (e != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) || at.device != c->device) {
+            (void)hipGetLastError();
+            return fail(c, BI_ERR_INVALID, "%s is not device memory of GPU %d", names[i], c->device);
+        }
+    }
+    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !c->unbinned;
+    if (!sparse && !c->dense_counts)
+        return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
+                                     "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
+    return plan_points_device(c, P, z_dev, rate_scale_dev, dataset_dev, sparse, out, share_rank, share_world, true);
+}
+
 int bi_plan_share_info(const bi_plan* p, int64_t* n_valid, int64_t* lo, int64_t* hi) {
     if (!p || !p->shared) return BI_ERR_INVALID;
     if (n_valid) *n_valid = p->n_valid;

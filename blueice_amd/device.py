@@ -386,6 +386,29 @@ class DeviceContext:
         plan.n_valid, plan.share, plan.world = nv.value, (lo.value, hi.value), int(world)
         return plan
 
+    def plan_resident(self, P, z, rate_scale=None, dataset=None, rank=0, world=1):
+        """plan() / plan_share() for points that are already in HBM: `z` [P][d] (and `rate_scale` [P][S], `dataset`
+        [P] int64) are DeviceBuffers (or device addresses) on this GPU, read where they lie.  world > 1: this rank's
+        share of a dealt scan, as plan_share.  Plain likelihoods only (no Beeston-Barlow, no negative-rate sources)."""
+        def addr(b, item_bytes, what):
+            if b is None:
+                return None
+            if isinstance(b, DeviceBuffer):
+                if b.nbytes < int(P) * item_bytes:
+                    raise ValueError("%s holds %d bytes, %d points need %d" % (what, b.nbytes, P, int(P) * item_bytes))
+                return C.c_void_p(b.ptr)
+            return C.c_void_p(int(b))
+        h = C.c_void_p()
+        self._check(self._lib.bi_plan_points_resident(self._h, int(P), addr(z, 8 * max(self.d or 0, 0), 'z'),
+                                                      addr(rate_scale, 8 * (self.S or 0), 'rate_scale'), addr(dataset, 8, 'dataset'),
+                                                      int(rank), int(world), C.byref(h)))
+        plan = EvalPlan(self, h, int(P))
+        if world > 1:
+            nv, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+            self._check(self._lib.bi_plan_share_info(h, C.byref(nv), C.byref(lo), C.byref(hi)))
+            plan.n_valid, plan.share, plan.world = nv.value, (lo.value, hi.value), int(world)
+        return plan
+
     # -- plain device buffers (gather staging) ------------------------------------------------------
     def device_alloc(self, nbytes):
         """-> DeviceBuffer of `nbytes` on this context's GPU.  `.free()` releases it; buffers still alive when the
@@ -474,6 +497,7 @@ class EvalPlan:
 
     def run(self, out_dev_ptr=None):
         self.ctx._check(self.ctx._lib.bi_run_plan(self.ctx._h, self._h, out_dev_ptr))
+        return self
 
     def unsort(self, gathered_ptr, stride, full_ptr):
         """A share of a dealt scan: gathered [world][stride] (device; rank r's results in sorted order) -> full [P] in

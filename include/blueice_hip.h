@@ -250,6 +250,17 @@ int bi_run_plan(bi_ctx* ctx, bi_plan* plan, double* out_dev /* NULL: internal bu
 int bi_plan_points_share(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
                          int share_rank, int share_world, bi_plan** out);
 int bi_plan_share_info(const bi_plan* plan, int64_t* n_valid, int64_t* lo, int64_t* hi);
+/* The same with the points ALREADY IN HBM: z_dev [P][d], rate_scale_dev [P][S] or NULL, dataset_dev [P] or NULL are device
+ * arrays on the context's GPU (bi_device_alloc + bi_memcpy_to_device, or any producer that has finished writing them) and are
+ * read where they lie -- no host pass, no copy; they may be freed or overwritten as soon as the call returns.
+ * share_world = 1: the whole batch (bi_plan_points); > 1: this rank's share of a dealt scan (bi_plan_points_share).
+ * Always planned on the device, so the restrictions of the device planner apply as errors instead of a silent host path:
+ * no Beeston-Barlow model, no source that may have a negative rate (likelihood.py:403-415: their infinite rate scales
+ * are answered on the host), P <= 2^30; BI_ERR_INVALID as well for a pointer that is not device memory of this GPU.
+ * The batched callers of the reference hold their points in numpy arrays (inference.py:424-432), so this entry has no
+ * counterpart there: it is for drivers that produce hypotheses on the device or reuse one grid for many datasets. */
+int bi_plan_points_resident(bi_ctx* ctx, int64_t P, const double* z_dev, const double* rate_scale_dev,
+                            const int64_t* dataset_dev, int share_rank, int share_world, bi_plan** out);
 int bi_plan_unsort(bi_ctx* ctx, bi_plan* plan, const double* gathered_dev, int64_t stride, double* full_dev);
 int bi_plan_read(bi_ctx* ctx, bi_plan* plan, double* out /*[P]*/, int32_t* status /*[P] or NULL*/);
 /* The bitwise OR of the plan's per-point status words after the last bi_run_plan (waits for the stream): what a caller

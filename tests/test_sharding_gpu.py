@@ -261,3 +261,93 @@ def test_scan_dealt_on_the_device_equals_one_plan(sparse):
         for b in (send, recv, full):
             b.free()
     ctx.close()
+
+
+@pytest.mark.parametrize('sparse', [0, 1])
+def test_points_resident_in_hbm_equal_host_points(sparse):
+    """bi_plan_points_resident: the points are read where they lie in HBM.  Whole batch: the very bits of the plan made from
+    host arrays (same planner, same work items); a share: the bits of bi_plan_points_share; with datasets; without rate
+    scales; what the device planner cannot do is an error, and so is a pointer that is not device memory."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.set_param('sparse', sparse)
+    T = 3
+    rng = np.random.default_rng(8)
+    counts = np.stack([m.counts(dense=not sparse) for _ in range(T)])
+    counts[1] = rng.permutation(counts[1])
+    counts[2, ::7] += 1
+    ctx.upload_counts(counts)
+    P = 2500
+    z, r = m.random_points(P, seed=31)
+    z[9, 0] = -9.0
+    r[40, 1] = np.nan
+    ds = rng.integers(0, T, P).astype(np.int64)
+    ds[100] = 17                                            # no such dataset
+    dz, dr, dd = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes), ctx.device_alloc(ds.nbytes)
+    dz.from_host(z); dr.from_host(r); dd.from_host(ds)
+    for use_r, use_ds in ((True, True), (True, False), (False, False)):
+        a = ctx.plan(z, r if use_r else None, ds if use_ds else None)
+        b = ctx.plan_resident(P, dz, dr if use_r else None, dd if use_ds else None)
+        assert b.bytes == a.bytes and b.launches == a.launches
+        (la, sa), (lb, sb) = a.run().read(), b.run().read()
+        np.testing.assert_array_equal(lb, la)
+        np.testing.assert_array_equal(sb, sa)
+        assert np.isneginf(lb[9]) and (not use_r or np.isneginf(lb[40])) and (not use_ds or np.isneginf(lb[100]))
+        assert np.isfinite(np.delete(lb, [9, 40, 100])).all()
+        a.close(); b.close()
+    # a share of a dealt scan
+    world = 3
+    stride = -(-P // world)
+    out_a, out_b = ctx.device_alloc(8 * stride), ctx.device_alloc(8 * stride)
+    for rank in range(world):
+        a = ctx.plan_share(z, r, ds, rank, world)
+        b = ctx.plan_resident(P, dz, dr, dd, rank, world)
+        assert (b.n_valid, b.share) == (a.n_valid, a.share)
+        a.run(out_a.ptr); b.run(out_b.ptr)
+        assert a.status() == b.status()
+        n = a.share[1] - a.share[0]
+        np.testing.assert_array_equal(out_b.to_host(np.float64, n), out_a.to_host(np.float64, n))
+        a.close(); b.close()
+    # the buffers may go as soon as the plan exists
+    b = ctx.plan_resident(P, dz, dr, dd)
+    want = ctx.eval(z, r, ds)[0]
+    dz.from_host(np.zeros_like(z)); dr.free()
+    np.testing.assert_array_equal(b.run().read()[0], want)
+    b.close()
+    dr = ctx.device_alloc(r.nbytes)
+    dr.from_host(r); dz.from_host(z)
+    # errors: host memory, too small a buffer, an empty batch is fine
+    with pytest.raises(ValueError, match='not device memory'):
+        ctx.plan_resident(P, z.ctypes.data, dr, dd)
+    with pytest.raises(ValueError, match='not device memory'):
+        ctx.plan_resident(P, dz, dr, ds.ctypes.data)
+    with pytest.raises(ValueError, match='holds'):
+        ctx.plan_resident(P + 1, dz, dr, dd)
+    with pytest.raises(ValueError, match='share'):
+        ctx.plan_resident(P, dz, dr, dd, 3, 3)
+    e = ctx.plan_resident(0, dz)
+    assert len(e.run().read()[0]) == 0
+    e.close()
+    ctx.close()
+    # Beeston-Barlow models and sources with negative rates are planned on the host: refused, not rerouted
+    bb = SyntheticModel.named('mini3', bb_source=0)
+    c2 = DeviceContext(0)
+    bb.upload(c2)
+    c2.upload_counts(bb.counts(dense=True))
+    zz, rr = bb.random_points(600, seed=1)
+    bz, br = c2.device_alloc(zz.nbytes), c2.device_alloc(rr.nbytes)
+    bz.from_host(zz); br.from_host(rr)
+    with pytest.raises(ValueError, match='Beeston-Barlow'):
+        c2.plan_resident(600, bz, br)
+    c2.close()
+    c3 = DeviceContext(0)
+    m.upload(c3)
+    c3.set_allow_negative(np.array([1] + [0] * (m.S - 1)))
+    c3.upload_counts(m.counts(dense=True))
+    bz, br = c3.device_alloc(zz.nbytes), c3.device_alloc(rr.nbytes)
+    with pytest.raises(ValueError, match='negative rates'):
+        c3.plan_resident(600, bz, br)
+    c3.close()
