@@ -223,8 +223,8 @@ int fail(bi_ctx* c, int code, const char* fmt, ...) {
             return fail((c), BI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr size_t kCacheMaxBuf = (size_t)64 << 20;     // only buffers up to 64 MiB are recycled
-constexpr size_t kCacheMaxTotal = (size_t)1 << 30;    // at most 1 GiB parked
+constexpr size_t kCacheMaxBuf = (size_t)1 << 30;      // only buffers up to 1 GiB are recycled (a 10^6-point scan: 256 + 640 MB)
+constexpr size_t kCacheMaxTotal = (size_t)4 << 30;    // at most 4 GiB parked (given back when an allocation fails)
 constexpr size_t kCacheMaxEntries = 256;
 
 void dev_free(DevBuf& b) {
