@@ -1326,9 +1326,20 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
 }
 
 // 1024 threads: 16 waves share one staged tile; every 16-lane row of a wave takes its own dataset, so a wave has four
-// (dataset, tile) runs in flight and a block 64 -- the runs are short (~77 entries at C2) and each starts with a chain
-// of dependent loads (offsets -> entries -> LDS), which only parallelism hides.
+// (dataset, tile) runs in flight and a block 64.  The runs are short (~80 entries at C2) and each starts with a chain of
+// dependent loads (offsets -> entries -> LDS): with one run after the other per row the kernel sat at 134 us for 0.4 GB
+// (3 TB/s), every wave waiting a full memory latency two or three times per run.  Now a row keeps the loads of THREE
+// runs in flight (ring buffers in registers, the loop unrolled over the ring so that nothing is copied and nothing
+// newer than what it needs is waited for): offsets four runs ahead, entries two runs ahead.  Every load is
+// unconditional -- a run behind the row's last one is the last one again (requested, never stored), an entry load
+// reads up to kDotPad entries past its run (the lists are padded by that much) and is masked afterwards -- because a
+// branch around a load makes the compiler wait for ALL outstanding loads.  Index arithmetic is 32-bit, relative to the
+// block's first entry (the launch keeps a block below 2^31 entries).  Per lane the entries are added in ascending
+// order with fma: a fixed order, independent of the launch geometry.
+typedef uint32_t bi_uint4 __attribute__((ext_vector_type(4)));
 constexpr int kDotThreads = 1024;
+constexpr int kDotAhead = 2;                   // 16-byte loads per lane requested up front: 2 x 64 = 128 entries per run
+constexpr int kDotPad = 64 * kDotAhead + 16;   // entries behind the lists that the read-ahead may touch (read, masked, never used)
 
 __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_t* __restrict__ tm_entries,
                                                                    const int64_t* __restrict__ tm_off, int64_t T, int n_tl,
@@ -1337,21 +1348,75 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
     __shared__ double s_mu[kDotTile];
     const int tl = blockIdx.x;
     const int64_t bin0 = (int64_t)tl * kDotTile;
-    for (int i = threadIdx.x; i < kDotTile; i += kDotThreads) s_mu[i] = bin0 + i < B ? logmu[bin0 + i] : 0.0;
-    __syncthreads();
     const int row = threadIdx.x >> 4, gl = threadIdx.x & 15;           // 64 rows of 16 lanes
-    const int64_t per = (n + gridDim.y - 1) / gridDim.y;
-    const int64_t c0 = (int64_t)blockIdx.y * per, c1 = min(n, c0 + per);
+    const int per = (int)((n + gridDim.y - 1) / gridDim.y);
+    const int c0u = (int)blockIdx.y * per, c1 = min((int)n, c0u + per);
+    const int c0 = min(c0u, (int)n - 1);                               // (clamped: a block without datasets still loads validly)
     const int64_t* __restrict__ off = tm_off + (int64_t)tl * T + t0;
-    for (int64_t q = c0 + row; q < c1; q += kDotThreads / 16) {
-        const int64_t a = off[q], b = off[q + 1];
-        double s = 0.0;
-        for (int64_t j = a + gl; j < b; j += 16) {
-            const uint32_t e = tm_entries[j];
-            s += (double)(e >> 13) * s_mu[e & (kDotTile - 1)];
+    const int64_t base = off[c0];                                  // block-uniform: the entries of this block start here
+    const uint32_t* __restrict__ ent = tm_entries + base;
+    const uint32_t* __restrict__ off32 = reinterpret_cast<const uint32_t*>(off);   // low words: all a block-relative index needs
+    const uint32_t base32 = (uint32_t)base;
+    constexpr int kStep = kDotThreads / 16, kAhead = kDotAhead, kRing = 6;
+    const int q_last = max(c0, c1 - 1);
+    // (a step only ISSUES loads into the rings; whatever touches a loaded value -- the subtraction of the base, the mask
+    //  of the entries past the run's end -- happens in the step that consumes it, two or four steps later: the compiler
+    //  waits where a value is first used, and it does not move that use out of the step it was written in)
+    auto load_offsets = [&](int q, uint32_t& ra, uint32_t& rb) {
+        const int qc = min(q, q_last);
+        ra = off32[2 * qc];
+        rb = off32[2 * qc + 2];
+    };
+    // (a lane takes four consecutive entries per load: a row's load covers 256 contiguous bytes of its run)
+    auto load_entries = [&](uint32_t ra, bi_uint4 (&e)[kAhead]) {
+        const uint32_t* __restrict__ p = ent + (int)(ra - base32) + 4 * gl;
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + 64 * k, 16);     // (4-byte aligned 16-byte load)
+    };
+    bi_uint4 E[3][kAhead];
+    uint32_t RA[kRing], RB[kRing];
+    const int q0 = c0 + row;
+    // the pipeline's first requests go out before the tile is staged: their latency passes under the staging
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_offsets(q0 + u * kStep, RA[u], RB[u]);
+    {   // (all loads first, addresses clamped instead of predicated: eight loads in flight per thread, not one at a time)
+        double v[kDotTile / kDotThreads];
+#pragma unroll
+        for (int k = 0; k < kDotTile / kDotThreads; ++k) v[k] = logmu[min(bin0 + threadIdx.x + k * kDotThreads, B - 1)];
+#pragma unroll
+        for (int k = 0; k < kDotTile / kDotThreads; ++k)
+            s_mu[threadIdx.x + k * kDotThreads] = bin0 + threadIdx.x + k * kDotThreads < B ? v[k] : 0.0;
+    }
+    load_entries(RA[0], E[0]);
+    load_entries(RA[1], E[1]);
+    __syncthreads();
+    if (c0u >= c1) return;
+    const int n_iter = (c1 - c0 + kStep - 1) / kStep;             // block-uniform: rows past their last run idle along
+    for (int it = 0; it < n_iter; it += kRing) {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {
+            if (it + u < n_iter) {                               // (scalar condition)
+                const int q = q0 + (it + u) * kStep;
+                load_offsets(q + 4 * kStep, RA[(u + 4) % kRing], RB[(u + 4) % kRing]);
+                load_entries(RA[(u + 2) % kRing], E[(u + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this step's arithmetic, not after it
+                const bi_uint4 (&e)[kAhead] = E[u % 3];
+                const int a = (int)(RA[u % kRing] - base32), b = (int)(RB[u % kRing] - base32);
+                const int len = b - a - 4 * gl;                  // entries of the run from this lane's first on
+                double s = 0.0, lm[4 * kAhead];
+#pragma unroll
+                for (int k = 0; k < 4 * kAhead; ++k) lm[k] = s_mu[e[k >> 2][k & 3] & (kDotTile - 1)];      // LDS reads in flight together
+#pragma unroll
+                for (int k = 0; k < 4 * kAhead; ++k)
+                    s = __builtin_fma((double)(64 * (k >> 2) + (k & 3) < len ? e[k >> 2][k & 3] >> 13 : 0u), lm[k], s);
+                for (int j = a + gl + 64 * kAhead; j < b; j += 16) {                        // (runs beyond 128 entries)
+                    const uint32_t x = ent[j];
+                    s = __builtin_fma((double)(x >> 13), s_mu[x & (kDotTile - 1)], s);
+                }
+                s = row16_sum(s);
+                if (gl == 0 && q < c1) partial[(int64_t)tl * n + q] = s;
+            }
         }
-        s = row16_sum(s);
-        if (gl == 0) partial[(int64_t)tl * n + q] = s;
     }
 }
 
@@ -1973,20 +2038,20 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __res
     for (int w = 1; w < kThreads / 64; ++w) { m += sh[w]; f |= shf[w]; }
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (t >= n) return;
-    // four running sums: the loads of a thread do not wait for one another (123 block-major partials per dataset from
+    // eight running sums: the loads of a thread do not wait for one another (123 block-major partials per dataset from
     // the tiled kernel are 123 trips to L2 otherwise); fixed order all the same
     const double* __restrict__ p = partial + t * t_stride;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int b = 0;
-#pragma unroll 2
-    for (; b + 3 < nbx; b += 4) {
-        s0 += p[(int64_t)b * b_stride];
-        s1 += p[(int64_t)(b + 1) * b_stride];
-        s2 += p[(int64_t)(b + 2) * b_stride];
-        s3 += p[(int64_t)(b + 3) * b_stride];
+    for (; b + 7 < nbx; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(int64_t)(b + k) * b_stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
     }
-    for (; b < nbx; ++b) s0 += p[(int64_t)b * b_stride];
-    const double s = (s0 + s1) + (s2 + s3);
+    for (; b < nbx; ++b) acc[0] += p[(int64_t)b * b_stride];
+    const double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     double r = (s - m) - lgsum[t0 + t];
     if (f) r = __builtin_nan("");
     out[t] = r;

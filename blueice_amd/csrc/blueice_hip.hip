@@ -1070,11 +1070,12 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
         if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
             (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
             (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t))) ||
-            (rc = dev_alloc(c, c->tm_entries, (size_t)std::max<int64_t>(nnz, 1) * sizeof(uint32_t)))) {
+            (rc = dev_alloc(c, c->tm_entries, (size_t)(nnz + kDotPad) * sizeof(uint32_t)))) {     // (+ pad: the kernel's unconditional read-ahead)
             drop();
             return rc;
         }
         hipError_t e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync((uint32_t*)c->tm_entries.p + nnz, 0, (size_t)kDotPad * sizeof(uint32_t), c->stream);
         hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
                            (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p);
         hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
@@ -1129,7 +1130,9 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
             EventScope ev(c);
             if (tiled) {
                 // datasets split over blockIdx.y so that ~4 blocks per CU exist; every block stages its tile once
-                const unsigned by = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ni + 255) / 256, 4 * (int64_t)c->prop.multiProcessorCount / n_tl));      // two resident blocks per CU (64 KB of LDS each): two full rounds
+                // (and few enough datasets per block for its 32-bit entry indices: datasets x kDotTile < 2^31)
+                const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((ni + 255) / 256, 2 * (int64_t)c->prop.multiProcessorCount / n_tl),      // two resident blocks per CU (64 KB of LDS each): ONE round, every block's start-up paid once
+                                                                 (ni + 262143) / 262144});
                 hipLaunchKernelGGL(k_dataset_dot_tiled, dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
                                    (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
                                    (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
