@@ -21,7 +21,7 @@ from .exceptions import NoOpimizationNecessary, OptimizationFailed
 from .profile import bestfit_batched, supports_batched_fits
 from .utils import is_numeric
 
-__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'one_parameter_interval',
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'bestfit_toys', 'one_parameter_interval',
            'likelihood_ratio_scan']
 
 
@@ -158,6 +158,25 @@ def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bound
     for n, v in zip(names, x):
         out[n] = 10 ** v if (rates_in_log_space and n.endswith('_rate_multiplier')) else v
     return out, -res.fun
+
+
+def bestfit_toys(lf, t0=0, t1=None, **kwargs):
+    """Fit every dataset the likelihood holds -- the toys of `simulate_toys`, or a stack handed to `set_binned_data` --
+    at the same time: one problem per dataset on the batched profile-fit engine, one device call per optimiser iteration
+    for all of them.  The reference's toy-MC loop is `d = lf.base_model.simulate(); lf.set_data(d); bestfit_scipy(lf)`,
+    one toy after the other (blueice/model.py:69-91, inference.py:131-178).  kwargs: as `bestfit_batched` (fixed
+    parameters, guess, ...).  -> (OrderedDict name -> fitted values [t1 - t0], max log likelihood [t1 - t0]).
+
+    Device-generated toys exist as non-empty-bin lists only; evaluating them at a parameter point of their own needs the
+    compacted templates of every toy (rows x non-empty bins x 8 bytes per toy: 41 MB at 4 sources x 5^3 anchors and
+    10^4 events), within `compact_budget` (16 GB unless raised with lf.ctx.set_param BEFORE the toys are made)."""
+    ctx = getattr(lf, 'ctx', None)
+    if ctx is None:
+        raise NotImplementedError("bestfit_toys needs a likelihood with its datasets on one device context")
+    t1 = ctx.T if t1 is None else t1
+    if not 0 <= t0 < t1 <= ctx.T:
+        raise ValueError("datasets [%d, %d) of %d" % (t0, t1, ctx.T))
+    return bestfit_batched(lf, datasets=np.arange(t0, t1), **kwargs)
 
 
 def _first_crossing(tfun, a, b, xtol=1e-11, points_per_round=16, max_rounds=12):

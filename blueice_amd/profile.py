@@ -33,11 +33,13 @@ class BatchObjective:
     """f(x [n, F], rows [n]) -> (-ll [n], d(-ll)/dx [n, F]) for problems `rows` of P, whose fixed parameters are
     `points` (name -> array [P]) and `fixed` (name -> scalar)."""
 
-    def __init__(self, lf, float_names, points, fixed, livetime_days=None):
+    def __init__(self, lf, float_names, points, fixed, livetime_days=None, datasets=None):
         self.lf, self.names = lf, list(float_names)
         self.points = {k: np.asarray(v, dtype=float) for k, v in points.items()}
         self.fixed = dict(fixed)
         self.livetime_days = livetime_days
+        self.datasets = None if datasets is None else np.asarray(datasets, dtype=np.int64)   # [P]: the dataset of every problem
+        self.kinks = None                                     # per floating parameter: where differences must not straddle
         self.analytic = bool(getattr(lf, 'supports_gradient', False)) and hasattr(lf, 'values_and_gradients')
         self.calls = self.evaluations = 0
 
@@ -50,12 +52,13 @@ class BatchObjective:
 
     def __call__(self, x, rows):
         self.calls += 1
+        more = {} if self.datasets is None else {'dataset': self.datasets[rows]}
         if self.analytic:
             self.evaluations += len(x)
             try:       # (a trial point at which a Beeston-Barlow assertion of the reference would fire is a point to avoid)
-                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, bb_assert='nan')
+                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, bb_assert='nan', **more)
             except TypeError:
-                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days)
+                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, **more)
             g = np.stack([np.broadcast_to(grads[n], ll.shape) for n in self.names], axis=1)
             return -ll, -g
         # central differences, all 2F + 1 stencil points of all problems in one batched call
@@ -67,20 +70,40 @@ class BatchObjective:
             stencil[2 + 2 * j, :, j] -= h[:, j]
         pts = self._points_of(stencil.reshape(-1, F), np.tile(rows, 2 * F + 1))
         self.evaluations += len(stencil) * n
-        ll = np.asarray(self.lf.eval_points(pts, livetime_days=self.livetime_days)).reshape(2 * F + 1, n)
+        if more:
+            more = {'dataset': np.tile(more['dataset'], 2 * F + 1)}
+        ll = np.asarray(self.lf.eval_points(pts, livetime_days=self.livetime_days, **more)).reshape(2 * F + 1, n)
         g = np.empty((n, F))
         for j in range(F):
             up, dn = ll[1 + 2 * j], ll[2 + 2 * j]
-            both = np.isfinite(up) & np.isfinite(dn)
+            can_up, can_dn = np.isfinite(up), np.isfinite(dn)
+            # a difference must not straddle a kink of the morph: ON one the forward difference (the right slope, which is
+            # what the analytic gradient reports there), next to one the difference that stays on this side of it
+            ks = self.kinks[j] if self.kinks is not None else ()
+            if len(ks):
+                xj, hj = x[:, j], h[:, j]
+                on = np.isin(xj, ks)
+                above = np.searchsorted(ks, xj, side='right')          # first kink > x
+                below = np.searchsorted(ks, xj, side='left') - 1       # last kink < x
+                kink_up = (above < len(ks)) & (ks[np.minimum(above, len(ks) - 1)] <= xj + hj)
+                kink_dn = (below >= 0) & (ks[np.maximum(below, 0)] >= xj - hj)
+                can_dn = can_dn & ~on & ~kink_dn
+                can_up = can_up & ~(kink_up & ~on)
             with np.errstate(all='ignore'):                            # at a bound: the one-sided difference
-                g[:, j] = np.where(both, (up - dn) / (2 * h[:, j]),
-                                   np.where(np.isfinite(up), (up - ll[0]) / h[:, j], (ll[0] - dn) / h[:, j]))
+                g[:, j] = np.where(can_up & can_dn, (up - dn) / (2 * h[:, j]),
+                                   np.where(can_up, (up - ll[0]) / h[:, j], (ll[0] - dn) / h[:, j]))
         return -ll[0], -g
 
 
-def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=20, ftol=1e-15, slow_window=8, slow_tol=1e-11):
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=20, ftol=1e-15, slow_window=8, slow_tol=1e-11,
+                     kinks=None):
     """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
-    lo / hi [F]: box (+-inf = none).  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
+    lo / hi [F]: box (+-inf = none).  kinks: per variable, the interior points at which f has a kink along it (the anchors
+    of a shape parameter: the morph is linear between them).  A variable sitting ON one -- every fit starts there, the
+    base value of a shape parameter is an anchor -- has two one-sided slopes, taken from two more rows evaluated just
+    below and just above it (whichever of the two `fun` reports AT the kink is its own convention).  Both pointing
+    uphill: the variable is held like one at a bound (and the point can count as converged); otherwise the search
+    continues down the steeper side.  -> (x [P, F], f [P], info) with info['converged'] [P] (projected gradient below
     gtol, or two successive steps that lowered f by less than ftol * max(1, |f|): the rounding floor),
     info['stalled'] [P] (no descent step found, or less than slow_tol * max(1, |f|) gained over the last slow_window
     iterations: a kink of the morph, where the search zigzags between two grid cells), info['iterations'], info['calls']."""
@@ -105,9 +128,38 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
     # no step carries a boxed variable (a shape parameter) further than a quarter of its range -- a tenth on a plain
     # gradient step --: the morph is only piecewise smooth, and a long first stride lands in another grid cell's basin
     span = np.where(np.isfinite(hi - lo), hi - lo, np.inf)
+    kinks = None if kinks is None or not any(len(k) for k in kinks) else [np.asarray(k, dtype=float) for k in kinks]
+    kink_calls = 0
     it = 0
     for it in range(1, max_iter + 1):
         blocked = (at_lo(x) & (g > 0)) | (at_hi(x) & (g < 0))       # moving against the gradient would leave the box
+        if kinks is not None:
+            live = np.flatnonzero(~done)
+            on = np.zeros((len(live), F), dtype=bool)
+            for j, ks in enumerate(kinks):
+                if len(ks):
+                    on[:, j] = np.isin(x[live, j], ks)
+            pi, ji = np.nonzero(on)
+            if len(pi):
+                rows_k = live[pi]
+                k = np.arange(len(pi))
+                xt = np.concatenate([x[rows_k], x[rows_k]])          # one row just below, one just above the kink
+                xt[k, ji] = np.nextafter(xt[k, ji], -np.inf)
+                xt[len(pi) + k, ji] = np.nextafter(xt[len(pi) + k, ji], np.inf)
+                ft, gt = fun(xt, np.concatenate([rows_k, rows_k]))
+                calls += 1
+                kink_calls += 1
+                gl, gr = gt[k, ji], gt[len(pi) + k, ji]
+                gl = np.where(np.isfinite(ft[:len(pi)]) & np.isfinite(gl), gl, 0.0)
+                gr = np.where(np.isfinite(ft[len(pi):]) & np.isfinite(gr), gr, 0.0)
+                hold = (gr >= 0) & (gl <= 0)                         # uphill on both sides: a minimum along this variable
+                go_left = ~hold & (gl > 0) & ((gr >= 0) | (gl > -gr))
+                g[rows_k, ji] = np.where(go_left, gl, gr)            # the slope of the side the search goes down
+                blocked[rows_k[hold], ji[hold]] = True
+                # leaving a kink: a plain gradient step, whose components have the signs of the sides just chosen
+                away = np.unique(rows_k[~hold])
+                B[away] = eye
+                fresh[away] = True
         pg = np.where(blocked, 0.0, g)
         converged |= ~done & (np.max(np.abs(pg), axis=1, initial=0.0) <= gtol)
         done |= converged
@@ -151,11 +203,25 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             cap = np.where(fresh[act], 0.1, 0.25)[:, None] * span[None, :] / np.maximum(np.abs(d), 1e-300)
         alpha = np.minimum(1.0, np.min(cap, axis=1))
         xa, fa = x[act], f[act]
+        # a step ends at the first kink it would cross (the function is smooth only up to there): the box of this step
+        # is the grid cell the step runs in; the next iteration decides AT the kink whether and how to go on
+        clo, chi = np.broadcast_to(lo, xa.shape), np.broadcast_to(hi, xa.shape)
+        if kinks is not None:
+            clo, chi = clo.copy(), chi.copy()
+            for j, ks in enumerate(kinks):
+                if not len(ks):
+                    continue
+                up = np.searchsorted(ks, xa[:, j], side='right')
+                dn = np.searchsorted(ks, xa[:, j], side='left') - 1
+                nxt = np.where(up < len(ks), ks[np.minimum(up, len(ks) - 1)], hi[j])
+                prv = np.where(dn >= 0, ks[np.maximum(dn, 0)], lo[j])
+                chi[:, j] = np.where(d[:, j] > 0, np.minimum(nxt, hi[j]), hi[j])
+                clo[:, j] = np.where(d[:, j] < 0, np.maximum(prv, lo[j]), lo[j])
         todo = np.arange(len(act))
         acc_x, acc_f, acc_g = xa.copy(), fa.copy(), ga.copy()
         accepted = np.zeros(len(act), dtype=bool)
         for _ in range(max_halvings):
-            xt = np.clip(xa[todo] + alpha[todo, None] * d[todo], lo, hi)
+            xt = np.clip(xa[todo] + alpha[todo, None] * d[todo], clo[todo], chi[todo])
             ft, gt = fun(xt, act[todo])
             calls += 1
             with np.errstate(invalid='ignore'):
@@ -192,7 +258,7 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             # the update lives in the subspace of the variables that moved freely: one that was pinned, or that the step
             # ran into a bound with (a clipped, arbitrarily short move against a finite change of slope), would plant a
             # huge curvature in B and shrink every later step to nothing
-            pinned = ~free[w] | (acc_x[w] <= lo) | (acc_x[w] >= hi)
+            pinned = ~free[w] | (acc_x[w] <= clo[w]) | (acc_x[w] >= chi[w])
             s = np.where(pinned, 0.0, s)
             y = np.where(pinned, 0.0, y)
             sy = np.sum(s * y, axis=1)
@@ -224,11 +290,11 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
             B[retry] = eye
             fresh[retry] = True
             flat[retry] = 0
-    return x, f, dict(converged=converged, stalled=stalled, failed=failed, iterations=it, calls=calls)
+    return x, f, dict(converged=converged, stalled=stalled, failed=failed, iterations=it, calls=calls, kink_calls=kink_calls)
 
 
 def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, max_iter=200, return_info=False,
-                    multi_start=True, keep_starts=2, scout_iterations=6, also_from=(), **fixed):
+                    multi_start=True, keep_starts=2, scout_iterations=6, also_from=(), datasets=None, **fixed):
     """Maximise `lf` over its floating parameters for P hypotheses at once.
 
     points: dict parameter name -> array [P] of values held fixed per problem (the scan grid / the hypotheses);
@@ -238,9 +304,16 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
     multi_start: also start from the other grid cells of every floating shape parameter (see below); the reference's
     single start is multi_start=False.  also_from: more starting points, each a dict name -> scalar or array [P] (floating
     parameters it does not name start at their guess) -- e.g. the global best fit's nuisances for a profile fit.
+    datasets: array [P] of dataset indices, one per problem (the likelihood holds several datasets: `set_binned_data` with
+    a stack, `simulate_toys`) -- every toy of a toy-MC ensemble fitted at the same time instead of the reference's loop
+    over `d = simulate(); lf.set_data(d); bestfit_scipy(lf)`; with `points`, problem p is (hypothesis p, dataset p).
     -> (OrderedDict name -> fitted values [P], max log likelihood [P]) [, info]."""
     points = {} if points is None else {k: np.atleast_1d(np.asarray(v, dtype=float)) for k, v in points.items()}
-    P = max([len(v) for v in points.values()] + [1])
+    if datasets is not None:
+        datasets = np.atleast_1d(np.asarray(datasets, dtype=np.int64))
+    P = max([len(v) for v in points.values()] + [1 if datasets is None else len(datasets)])
+    if datasets is not None:
+        datasets = np.ascontiguousarray(np.broadcast_to(datasets, (P,)))
     points = {k: np.broadcast_to(v, (P,)) for k, v in points.items()}
     guess = guess or {}
     names, x0, lo, hi = [], [], [], []
@@ -268,7 +341,14 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         raise NoOpimizationNecessary("There are no parameters to fit, no optimization is necessary")
     x0 = np.stack(x0, axis=1)
     lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)
-    obj = BatchObjective(lf, names, points, fixed, livetime_days)
+    obj = BatchObjective(lf, names, points, fixed, livetime_days, datasets)
+    # interior anchors of the floating shape parameters: where the morph, and with it the likelihood, has a kink
+    kinks = []
+    for key in names:
+        anchors = lf.shape_parameters[key][0] if key in lf.shape_parameters else None
+        zs = np.sort(np.array([float(a) for a in (anchors or ()) if is_numeric(a)]))
+        kinks.append(zs[1:-1] if len(zs) > 2 else np.zeros(0))
+    obj.kinks = kinks
     # Other starting points: the morph is smooth only inside a grid cell of the anchors, and with noisy templates the
     # likelihood can have one local maximum per cell along a shape parameter.  Besides the reference's starting point
     # (the base value) every problem is therefore also started from the centre of each OTHER cell along each floating
@@ -296,16 +376,16 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         starts.append(alt)
     n_st = len(starts)
     if n_st == 1:
-        x, f, info = batched_minimize(obj, x0, lo, hi, gtol=gtol, max_iter=max_iter)
+        x, f, info = batched_minimize(obj, x0, lo, hi, gtol=gtol, max_iter=max_iter, kinks=kinks)
     else:
         rows_of = lambda k: np.tile(np.arange(P), k)
         scout = lambda xx, rr: obj(xx, rr % P)                       # row r of the stacked problem set is problem r % P
-        xs, fs, _ = batched_minimize(scout, np.concatenate(starts), lo, hi, gtol=gtol, max_iter=scout_iterations)
+        xs, fs, _ = batched_minimize(scout, np.concatenate(starts), lo, hi, gtol=gtol, max_iter=scout_iterations, kinks=kinks)
         fs = np.where(np.isfinite(fs), fs, np.inf).reshape(n_st, P)
         keep = min(keep_starts + len(also_from), n_st)
         order = np.argsort(fs, axis=0, kind='stable')[:keep]          # [keep, P] start indices, best first
         xk = xs.reshape(n_st, P, -1)[order, np.arange(P)[None, :]].reshape(keep * P, -1)
-        x, f, info = batched_minimize(scout, xk, lo, hi, gtol=gtol, max_iter=max_iter)
+        x, f, info = batched_minimize(scout, xk, lo, hi, gtol=gtol, max_iter=max_iter, kinks=kinks)
         f2 = np.where(np.isfinite(f), f, np.inf).reshape(keep, P)
         win = np.argmin(f2, axis=0)
         pick = win * P + np.arange(P)

@@ -63,8 +63,12 @@ class OracleLikelihood:
                 w = np.where(n > 0, n / mu, 0.0) - 1.0
             for s, name in enumerate(self.source_name_list):
                 grads[name + '_rate_multiplier'][p] = mus[s] * (w @ ps[s])
-            for i, name in enumerate(self.shape_parameters):      # shape slopes: central differences of the oracle
-                lo, hi = self.get_bounds(name)
+            for i, name in enumerate(self.shape_parameters):      # shape slopes: differences of the oracle INSIDE the
+                # grid cell the point belongs to (g[k] <= z < g[k+1], the last one closed: scipy's and the device's
+                # convention), so that a point on an anchor gets the slope of the cell above it, as from bi_eval_grad
+                grid = np.asarray(self.model['anchor_z'][i], dtype=float)
+                k = int(np.clip(np.searchsorted(grid, z[p][i], side='right') - 1, 0, len(grid) - 2))
+                lo, hi = grid[k], grid[k + 1]
                 zp, zm = z[p].copy(), z[p].copy()
                 zp[i] = min(z[p][i] + h, hi)
                 zm[i] = max(z[p][i] - h, lo)

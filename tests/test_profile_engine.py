@@ -198,3 +198,31 @@ def test_first_crossing_finds_brentqs_root():
         _first_crossing(batched(lambda x: x * x + 1), -1.0, 1.0)
     assert _first_crossing(batched(lambda x: x - 1.0), 1.0, 5.0) == 1.0
     assert _first_crossing(batched(lambda x: x - 5.0), 1.0, 5.0) == 5.0
+
+
+def test_batched_minimize_starting_on_kinks():
+    """A variable that sits ON a kink of the function (a shape parameter at an anchor: where every fit starts) has two
+    one-sided slopes.  `fun` reports the right one, as the device does (the point belongs to the upper cell); the
+    optimiser asks for the left one with one more row just below, holds the variable when both point uphill (and can
+    then call the point converged), and otherwise leaves the kink down the steeper side."""
+    from blueice_amd.profile import batched_minimize
+    # per problem: f = w * |x0| + (x0 - m)^2 + (x1 - 1)^2, kink of x0 at 0; minimum at x0 = 0 iff |2 m| <= w
+    m = np.array([0.0, 0.04, -0.04, 0.3, -0.3, 0.3, -0.3])
+    w = np.array([0.1, 0.1, 0.1, 0.1, 0.1, 1.0, 1.0])
+
+    def fun(x, rows):
+        x0, x1 = x[:, 0], x[:, 1]
+        sign = np.where(x0 >= 0, 1.0, -1.0)                       # at 0: the right slope
+        f = w[rows] * np.abs(x0) + (x0 - m[rows]) ** 2 + (x1 - 1) ** 2
+        return f, np.stack([w[rows] * sign + 2 * (x0 - m[rows]), 2 * (x1 - 1)], axis=1)
+
+    lo, hi = np.array([-2., -5.]), np.array([2., 5.])
+    x, f, info = batched_minimize(fun, np.zeros((7, 2)), lo, hi, gtol=1e-8, kinks=[np.array([-1., 0., 1.]), np.zeros(0)])
+    want = np.where(np.abs(2 * m) <= w, 0.0, m - np.sign(m) * w / 2)
+    np.testing.assert_allclose(x[:, 0], want, atol=1e-6)
+    np.testing.assert_allclose(x[:, 1], 1.0, atol=1e-6)
+    assert info['converged'].all() and info['kink_calls'] > 0
+    assert np.all(x[np.abs(2 * m) <= w, 0] == 0.0)                # held exactly on the kink, not near it
+    # without the kinks the one-sided slope at the start looks like a descent direction that is none
+    x2, f2, info2 = batched_minimize(fun, np.zeros((7, 2)), lo, hi, gtol=1e-8)
+    assert not info2['converged'][:3].all() and np.all(f <= f2 + 1e-12)
