@@ -332,6 +332,18 @@ def test_points_resident_in_hbm_equal_host_points(sparse):
     assert len(e.run().read()[0]) == 0
     e.close()
     ctx.close()
+    # the extended unbinned likelihood (rows = pdf values at the events): the same planner, the same bits
+    cu = DeviceContext(0)
+    m.upload(cu)
+    cu.set_unbinned(1e-12)
+    zu, ru = m.random_points(1500, seed=3)
+    uz, ur = cu.device_alloc(zu.nbytes), cu.device_alloc(ru.nbytes)
+    uz.from_host(zu); ur.from_host(ru)
+    a, b = cu.plan(zu, ru), cu.plan_resident(1500, uz, ur)
+    np.testing.assert_array_equal(b.run().read()[0], a.run().read()[0])
+    assert np.isfinite(b.read()[0]).all()
+    a.close(); b.close()
+    cu.close()
     # Beeston-Barlow models and sources with negative rates are planned on the host: refused, not rerouted
     bb = SyntheticModel.named('mini3', bb_source=0)
     c2 = DeviceContext(0)
