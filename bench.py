@@ -205,7 +205,10 @@ class Ranks:
 # ---------------------------------------------------------------------------------------------------------
 def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     """A profile scan of P parameter points over the resident model (BASELINE.json configs[3]), STRONG scaling.  One step =
-    host buffers of ALL P points in -> full result vector on every rank, everything inside the clock:
+    ALL P points in -> full result vector on every rank, everything inside the clock.  Timed twice: with the points
+    handed over as host arrays (`value_host_points`: the reference's calling convention, H2D inside the clock) and with
+    the points already in HBM when the clock starts (`value`; bi_plan_points_resident; not for Beeston-Barlow models,
+    which are planned on the host).  Per step:
       N > 1  every rank hands all P points to its device planner, whose (cell, dataset) sort IS the dealing: rank r
              evaluates a contiguous, balanced range of the sorted list (cells stay together, no host pass over the
              points); the ranks' vectors are gathered in HBM (RCCL) and one kernel scatters them into point order;
