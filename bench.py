@@ -957,6 +957,14 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
     _, one = lf.bestfit_scipy(**fixed)
     ex['api_toy_fit_sequential_s'] = time.perf_counter() - t                  # set_data + fit of ONE toy, the loop body
     assert toy_ll[7] >= one - 1e-6 * abs(one), (toy_ll[7], one)
+    # ... and an ensemble of 2048 toys drawn and fitted in chunks of 256 (the toys' compacted templates: 10.5 GB per chunk)
+    t = time.perf_counter()
+    ens, ens_ll = lf.toy_mc_fits(2048, chunk=256, seed=100, **fixed)
+    dt = time.perf_counter() - t
+    ex['api_toy_mc_2048_draw_and_fit_s'] = dt
+    ex['api_toy_mc_fits_per_s'] = 2048 / dt
+    ex['api_toy_mc_fitted_rate_mean_std'] = [float(np.mean(ens['s0_rate_multiplier'])), float(np.std(ens['s0_rate_multiplier']))]
+    assert np.all(np.isfinite(ens_ll))
     lf.set_binned_data(counts.reshape(model.bins))
     # template building: the binning of one source's Monte Carlo sample (10^6 events, 3 dimensions, 100^3 bins) -- what
     # prepare() does once per source and anchor model (blueice/source.py:287-299)

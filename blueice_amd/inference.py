@@ -21,8 +21,8 @@ from .exceptions import NoOpimizationNecessary, OptimizationFailed
 from .profile import bestfit_batched, supports_batched_fits
 from .utils import is_numeric
 
-__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'bestfit_toys', 'one_parameter_interval',
-           'likelihood_ratio_scan']
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'bestfit_toys', 'toy_mc_fits',
+           'one_parameter_interval', 'likelihood_ratio_scan']
 
 
 def best_anchor(lf):
@@ -177,6 +177,36 @@ def bestfit_toys(lf, t0=0, t1=None, **kwargs):
     if not 0 <= t0 < t1 <= ctx.T:
         raise ValueError("datasets [%d, %d) of %d" % (t0, t1, ctx.T))
     return bestfit_batched(lf, datasets=np.arange(t0, t1), **kwargs)
+
+
+def toy_mc_fits(lf, n_toys, chunk=256, seed=0, truth=None, livetime_days=None, **fit_kwargs):
+    """A toy-MC ensemble with a fit per toy, start to finish on the device: `n_toys` binned toys drawn at the parameter
+    values `truth` (dict; defaults elsewhere) and fitted, `chunk` toys at a time (`simulate_toys` + `bestfit_toys`) -- the
+    reference's `for _ in range(n_toys): d = lf.base_model.simulate(); lf.set_data(d); bestfit_scipy(lf)`
+    (blueice/model.py:69-91, inference.py:131-178).  The toys are numbered globally (the generator's counters are
+    (seed, toy number, bin)), so the ensemble does not depend on `chunk`: that only bounds the HBM taken by the toys'
+    compacted templates (see `bestfit_toys`).  fit_kwargs: parameters held fixed, `guess`, ... as `bestfit_batched`.
+    -> (OrderedDict name -> fitted values [n_toys], max log likelihood [n_toys]).  Afterwards the likelihood's data are
+    the toys of the last chunk."""
+    ctx = getattr(lf, 'ctx', None)
+    if ctx is None or not hasattr(lf, 'simulate_toys'):
+        raise NotImplementedError("toy_mc_fits needs a binned likelihood on one device context")
+    best, lls = None, []
+    try:
+        for t0 in range(0, int(n_toys), int(chunk)):
+            n = min(int(chunk), int(n_toys) - t0)
+            ctx.set_param('toy_offset', t0)
+            lf.simulate_toys(n, seed=seed, livetime_days=livetime_days, **(truth or {}))
+            b, ll = bestfit_toys(lf, livetime_days=livetime_days, **fit_kwargs)
+            lls.append(ll)
+            if best is None:
+                best = OrderedDict((k, [v]) for k, v in b.items())
+            else:
+                for k, v in b.items():
+                    best[k].append(v)
+    finally:
+        ctx.set_param('toy_offset', 0)
+    return OrderedDict((k, np.concatenate(v)) for k, v in best.items()), np.concatenate(lls)
 
 
 def _first_crossing(tfun, a, b, xtol=1e-11, points_per_round=16, max_rounds=12):
