@@ -242,6 +242,13 @@ void dev_free(DevBuf& b) {
     b.view = false;
 }
 
+void drop_recycle_cache(bi_ctx* c) {
+    (void)hipGetLastError();
+    for (auto& q : c->cache) (void)hipFree(q.p);
+    c->cache.clear();
+    c->cache_bytes = 0;
+}
+
 int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p && b.bytes >= bytes) return BI_OK;
     if (b.p) dev_free(b);
@@ -262,10 +269,7 @@ int dev_alloc(bi_ctx* c, DevBuf& b, size_t bytes) {
     }
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e != hipSuccess) {
-        // give parked memory back and retry once
-        for (auto& q : c->cache) (void)hipFree(q.p);
-        c->cache.clear();
-        c->cache_bytes = 0;
+        drop_recycle_cache(c);                  // give parked memory back and retry once
         e = hipMalloc(&b.p, bytes);
     }
     if (e != hipSuccess) {

@@ -63,6 +63,7 @@ const ParamDef kParams[] = {
     // ---- triggers (write-only) ---------------------------------------------------------------------------------
     {"single_timing_reset", kParamWrite, nullptr,
      BI_P_SET(c->single_ns[0] = c->single_ns[1] = c->single_ns[2] = 0; c->single_calls = 0; (void)v)},
+    {"drop_recycle_cache", kParamWrite, nullptr, BI_P_SET((void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); drop_recycle_cache(c); (void)v)},
     // fault injection for the in-launch finish, consumed by the NEXT launch that finishes through the mailbox: block
     // `v` of every work item never posts its partial sum (debug_skip_post), or posts it only after the collector's
     // wait has run out (debug_late_post); -1 = off
@@ -92,6 +93,7 @@ const ParamDef kParams[] = {
     BI_P_RO("single_ns_launch", c->single_ns[1]),
     BI_P_RO("single_ns_wait", c->single_ns[2]),
     BI_P_RO("user_allocations", (int64_t)c->user_allocs.size()),
+    BI_P_RO("recycle_cache_bytes", (int64_t)c->cache_bytes),
 };
 
 #undef BI_P_GET

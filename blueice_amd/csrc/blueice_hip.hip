@@ -1719,7 +1719,11 @@ int bi_device_alloc(bi_ctx* c, int64_t bytes, void** out) {
     if (!c || !out || bytes < 0) return BI_ERR_INVALID;
     *out = nullptr;
     HIP_TRY(c, hipSetDevice(c->device));
-    const hipError_t e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16));
+    hipError_t e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) {                       // the context's parked buffers (up to 4 GiB) go first
+        drop_recycle_cache(c);
+        e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16));
+    }
     if (e != hipSuccess) return fail(c, BI_ERR_NOMEM, "hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
     c->user_allocs.push_back(*out);           // whatever is still alive goes with the context (bi_destroy)
     return BI_OK;

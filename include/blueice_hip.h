@@ -343,6 +343,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   mail_timeout_ms   in-launch finish: how long an item's collecting block waits for a sibling's partial sum before it gives
  *                     up with BI_ST_INTERNAL (2000)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
+ *   drop_recycle_cache   (write) give the device buffers the context keeps for reuse (plan and scratch buffers of up to
+ *                     1 GiB each, 4 GiB in total; read-only recycle_cache_bytes) back to the driver now; an allocation that
+ *                     fails does the same before it gives up
  *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
  *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
  * read-only: tile_bins, padded_bins, n_scan_launches, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
