@@ -27,11 +27,13 @@ int build_compact_templates(bi_ctx* c) {
         tot_cnt += np;
     }
     if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
+    // (the row totals of ALL datasets land in one scratch block and come back in one copy: a synchronisation per dataset
+    //  was most of the time of compacting a few hundred toys)
     if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
-        (rc = dev_alloc(c, c->scratch, (size_t)rows * sizeof(double))))
+        (rc = dev_alloc(c, c->scratch, (size_t)T * rows * sizeof(double))))
         return rc;
     c->h_Tz.assign((size_t)T * rows, 0.0);
-    std::vector<double> tnz((size_t)rows);
+    std::vector<double> tnz((size_t)T * rows);
     // Few datasets (a scan's one): the compacted copy holds the non-empty bins ORDERED BY THEIR COUNT (ties by bin) -- every
     // consumer of the copy sums over its bins, so the order is free, and the matrix-core scan kernel turns runs of equal
     // counts into one logarithm per lane and strip (k_scan_mfma PROD = 2).  The CSR lists themselves stay in bin order.
@@ -61,14 +63,17 @@ int build_compact_templates(bi_ctx* c) {
         hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream,
                            cnt, nnz, np, (double*)c->cnt_c.p + c->h_cnt_off[(size_t)t]);
         hipLaunchKernelGGL(k_row_total, dim3((unsigned)rows), dim3(kThreads), 0, c->stream, (const double*)dst, np, np,
-                           (double*)c->scratch.p);
+                           (double*)c->scratch.p + t * rows);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(tnz.data(), c->scratch.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { drop(); return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e)); }
-        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)r];
+        if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); drop(); return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e)); }
     }
+    e = hipMemcpyAsync(tnz.data(), c->scratch.p, tnz.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
     drop();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "template compaction: %s", hipGetErrorString(e));
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t r = 0; r < rows; ++r) c->h_Tz[(size_t)(t * rows + r)] = c->h_rowsum[(size_t)r] - tnz[(size_t)(t * rows + r)];
     c->compact_sorted = sort_by_count;
     c->compact_ready = true;
     return BI_OK;
