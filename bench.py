@@ -703,6 +703,15 @@ def main():
         legs['C4'] = scan_leg(ctx, ranks, model, 10 ** 6, 3,
                               'C4: 10^6 scan points over the C2 model, dealt by grid cell (default path: exact '
                               'non-empty-bin form, %d bins with data)' % ctx.get_param('nnz_total'))
+        nnz = ctx.get_param('nnz_total')
+        per_rank_flops = 2.0 * NS * nnz * legs['C4']['points_per_rank_min_max'][1]
+        legs['C4']['roofline_scan'] = {
+            'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS,
+            'achieved': per_rank_flops / (legs['C4']['ms_per_step'] * 1e-3) / 1e12,
+            'note': 'fp64 FMA work of the morph over the %d bins with data (2 * 2^d*S flop per bin and evaluation) of the busiest '
+                    'rank over the whole step (device planning + k_scan_mfma on the compacted, count-ordered rows + finish + '
+                    'read-back); the logarithms run on the vector ALU, which shares the fp64 units with the matrix cores' % nnz}
+        legs['C4']['roofline_scan']['frac'] = legs['C4']['roofline_scan']['achieved'] / FP64_PEAK_TFLOPS
         ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
         before = ctx.get_param('n_valid_launches')

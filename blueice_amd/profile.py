@@ -220,21 +220,33 @@ def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halv
         todo = np.arange(len(act))
         acc_x, acc_f, acc_g = xa.copy(), fa.copy(), ga.copy()
         accepted = np.zeros(len(act), dtype=bool)
-        for _ in range(max_halvings):
-            xt = np.clip(xa[todo] + alpha[todo, None] * d[todo], clo[todo], chi[todo])
-            ft, gt = fun(xt, act[todo])
+        # Backtracking.  The first trial is the full step (most problems take it).  Every later round tries a LADDER of three
+        # steps per problem in the same device call -- the interpolated one, a quarter and a sixteenth of it -- and takes the
+        # longest that satisfies the Armijo condition: a device call costs the same for three times the rows, and the number
+        # of calls per iteration is set by the slowest problem.
+        ladder = np.array([1.0, 0.25, 0.0625])
+        spent = 0
+        while spent < max_halvings:
+            K = 1 if spent == 0 else len(ladder)
+            al = alpha[todo][:, None] * ladder[None, :K]                                        # [n, K]
+            xt = np.clip(xa[todo][:, None, :] + al[:, :, None] * d[todo][:, None, :], clo[todo][:, None, :], chi[todo][:, None, :])
+            ft, gt = fun(xt.reshape(-1, F), np.repeat(act[todo], K))
             calls += 1
+            spent += K
+            ft, gt = ft.reshape(-1, K), gt.reshape(-1, K, F)
             with np.errstate(invalid='ignore'):
-                ok = np.isfinite(ft) & (ft <= fa[todo] + c1 * np.sum(ga[todo] * (xt - xa[todo]), axis=1)) & \
-                     np.all(np.isfinite(gt), axis=1)
-            hit = todo[ok]
-            acc_x[hit], acc_f[hit], acc_g[hit] = xt[ok], ft[ok], gt[ok]
+                ok = np.isfinite(ft) & (ft <= fa[todo][:, None] + c1 * np.sum(ga[todo][:, None, :] * (xt - xa[todo][:, None, :]), axis=2)) & \
+                     np.all(np.isfinite(gt), axis=2)
+            some = ok.any(axis=1)
+            pick = np.argmax(ok, axis=1)[some]                       # the longest acceptable step of the ladder
+            hit = todo[some]
+            acc_x[hit], acc_f[hit], acc_g[hit] = xt[some, pick], ft[some, pick], gt[some, pick]
             accepted[hit] = True
-            # quadratic interpolation of the step where the trial was finite, halving otherwise; kept in [0.1, 0.5] alpha
-            miss = todo[~ok]
+            # quadratic interpolation from the shortest trial where it was finite, halving otherwise; kept in [0.1, 0.5] of it
+            miss = todo[~some]
             if not len(miss):
                 break
-            a_m, f_t = alpha[miss], ft[~ok]
+            a_m, f_t = al[~some, K - 1], ft[~some, K - 1]
             with np.errstate(all='ignore'):
                 quad = -slope[miss] * a_m ** 2 / (2.0 * (f_t - fa[miss] - slope[miss] * a_m))
             alpha[miss] = np.where(np.isfinite(quad), np.clip(quad, 0.1 * a_m, 0.5 * a_m), 0.5 * a_m)
