@@ -11,7 +11,7 @@ m.upload(ctx, threads=8)
 for sparse in (1, 0):
     ctx.set_param('sparse', sparse)
     ctx.upload_counts(m.counts())
-    for P in (64, 1024, 16384, 131072) if sparse else (64, 1024):
+    for P in (64, 256, 511, 512, 1024, 4096, 16384, 131072) if sparse else (64, 1024):
         z, r = m.random_points(P, seed=3)
         ctx.eval_grad(z, r)
         ctx.profile(True)
