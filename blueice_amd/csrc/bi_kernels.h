@@ -2027,7 +2027,20 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __res
     __shared__ unsigned shf[kThreads / 64];
     double m = 0.0;
     unsigned f = 0u;
-    for (int b = threadIdx.x; b < nmu; b += kThreads) { m += mu_partial[b]; f |= mu_flags[b]; }
+    {   // (four loads in flight per thread: every block of this kernel repeats this sum before it can start on its datasets)
+        double m4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = threadIdx.x;
+        for (; b + 3 * kThreads < nmu; b += 4 * kThreads) {
+            double v[4];
+            unsigned g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = mu_partial[b + k * kThreads]; g[k] = mu_flags[b + k * kThreads]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m4[k] += v[k]; f |= g[k]; }
+        }
+        for (; b < nmu; b += kThreads) { m4[0] += mu_partial[b]; f |= mu_flags[b]; }
+        m = (m4[0] + m4[1]) + (m4[2] + m4[3]);
+    }
     m = wave_sum(m);
     f = wave_or(f);
     if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = m; shf[threadIdx.x >> 6] = f; }
