@@ -29,7 +29,10 @@ int build_compact_templates(bi_ctx* c) {
     if ((tot_ps + tot_cnt) * (int64_t)sizeof(double) > c->compact_budget) return BI_OK;
     // (the row totals of ALL datasets land in one scratch block and come back in one copy: a synchronisation per dataset
     //  was most of the time of compacting a few hundred toys)
-    if ((rc = dev_alloc(c, c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = dev_alloc(c, c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
+    // (when the compacted copy has to grow it grows by an eighth more than asked: the next toy ensemble is a few tiles larger
+    //  or smaller, and giving 10 GB back to the driver and asking for 10 GB + 4 MB costs 0.4 s)
+    auto roomy = [&](DevBuf& b, size_t bytes) { return b.p && b.bytes >= bytes ? BI_OK : dev_alloc(c, b, bytes + bytes / 8); };
+    if ((rc = roomy(c->ps_c, (size_t)tot_ps * sizeof(double))) || (rc = roomy(c->cnt_c, (size_t)tot_cnt * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)T * rows * sizeof(double))))
         return rc;
     c->h_Tz.assign((size_t)T * rows, 0.0);
