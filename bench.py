@@ -392,6 +392,29 @@ def c5_leg(ctx, ranks, steps=24):
                 kernel='k_morph_reduce<1,true,true> (Beeston-Barlow, nontemporal loads)', bound='hbm',
                 bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=gbs / HBM_PEAK_GBS, evals_per_s=n / (ms * 1e-3), status_bits=int(st[0]))
+    # value AND gradient with respect to the 4 shape and 6 rate parameters in one pass (k_morph_bbgrad: the chain rule through
+    # the per-bin Beeston-Barlow root) -- against 1 + 10 value passes for forward differences, which is what a minimiser
+    # without it does (blueice/inference.py:111-124 under scipy's default BFGS)
+    ctx.eval_grad(z[:1], r[:1])
+    t = time.perf_counter()
+    for i in range(6):
+        gl, gz, gs, gst = ctx.eval_grad(z[i % 4:i % 4 + 1], r[i % 4:i % 4 + 1])
+    grad_ms = (time.perf_counter() - t) / 6 * 1e3
+    t = time.perf_counter()
+    lo_z = np.array([g[0] for g in m.anchor_z]); hi_z = np.array([g[-1] for g in m.anchor_z])
+    z8 = np.clip(np.repeat(z[1:2], 8, axis=0) + 1e-3 * np.arange(8)[:, None], lo_z, hi_z)
+    gl8, gz8, gs8, _ = ctx.eval_grad(z8, np.repeat(r[1:2], 8, axis=0))
+    grad8_ms = (time.perf_counter() - t) * 1e3
+    h = 1e-6                                                 # one slope against a central difference of the value kernel
+    zp, zm = z[1].copy(), z[1].copy()
+    zp[0] += h; zm[0] -= h
+    fd = (ctx.eval(zp, r[1])[0][0] - ctx.eval(zm, r[1])[0][0]) / (2 * h)
+    assert abs(fd - gz[0][0]) <= 1e-5 * max(1.0, abs(fd)), (fd, gz[0][0])
+    assert gl[0] == ctx.eval(z[1], r[1])[0][0]
+    kern['gradient'] = dict(kernel='k_morph_bbgrad<16,8> (value + 10 slopes in one pass)', ms_one_point=grad_ms,
+                            ms_eight_points_one_cell=grad8_ms, value_pass_ms=ms / n,
+                            forward_difference_equivalent_ms=11 * ms / n,
+                            slope_vs_central_difference_rel=float(abs(fd - gz[0][0]) / max(1.0, abs(fd))))
     scan = scan_leg(ctx, ranks, m, 256, 2, 'C5 grid cell: 256 Beeston-Barlow scan points (6 sources, 2^4 anchors, 50^4 bins), '
                     'dealt over the ranks, 8 points per 5.65 GB pass', sample=1)
     return kern, scan
