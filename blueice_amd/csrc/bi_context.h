@@ -166,6 +166,7 @@ struct bi_ctx {
     int64_t debug_skip_post = -1, debug_late_post = -1;   // fault injection for the next mailbox launch (bi_params.h)
     int64_t n_mail_resets = 0;                   // how often the mailbox had to be emptied after a collector gave up
     std::vector<void*> user_allocs;              // bi_device_alloc buffers still alive: freed with the context
+    int64_t bb_max_group = 8;                    // points per Beeston-Barlow work item (16: one wave per SIMD, accumulators partly in AGPRs)
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
     // the events of the last bi_simulate_events into this context: coordinates [k][N], source index [N]

@@ -34,6 +34,7 @@ const ParamDef kParams[] = {
          c->max_group = v;
          return BI_OK;
      }},
+    {"bb_max_group", kParamRW, BI_P_GET(c->bb_max_group), BI_P_SET(c->bb_max_group = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))))},
     {"blocks_per_cu", kParamRW, BI_P_GET(c->blocks_per_cu), BI_P_RANGE(1, 32, blocks_per_cu, "blocks_per_cu in [1,32]")},
     {"nt_loads", kParamRW, BI_P_GET(c->nt_loads), BI_P_RANGE(0, 2, nt_loads, "nt_loads: 0 = never, 1 = always, 2 = auto")},
     {"tile_chunks", kParamRW, BI_P_GET(c->tile_chunks), BI_P_SET(c->tile_chunks = v < 1 ? 1 : v)},

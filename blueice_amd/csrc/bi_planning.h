@@ -114,7 +114,7 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
     std::sort(pts.begin(), pts.end(), [](const Pt& a, const Pt& b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); });
 
     // ---- phase 3: chop groups into items, detect row reuse (serial, O(items * corners)) -------------
-    const int maxg = bb ? (int)std::min<int64_t>(c->max_group, 8) : (int)c->max_group;  // G=16 with BB spills
+    const int maxg = bb ? (int)std::min<int64_t>(c->max_group, c->bb_max_group) : (int)c->max_group;  // (G = 16 with BB: 310 VGPRs + 54 AGPRs)
     std::vector<int64_t> corner_off((size_t)nc);
     for (int k = 0; k < nc; ++k) corner_off[(size_t)k] = corner_offset(c, k);
     std::vector<PlanItem> items;

@@ -343,6 +343,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   mail_timeout_ms   in-launch finish: how long an item's collecting block waits for a sibling's partial sum before it gives
  *                     up with BI_ST_INTERNAL (2000)
  *   single_timing_reset   (write) zero the single-call wall-time accumulators below
+ *   bb_max_group      points per work item of a Beeston-Barlow batch (the points of a grid cell share a pass over the streams):
+ *                     1, 2, 4, 8 (default) or 16 -- sixteen keep their accumulators partly in AGPRs, one wave per SIMD
  *   drop_recycle_cache   (write) give the device buffers the context keeps for reuse (plan and scratch buffers of up to
  *                     1 GiB each, 4 GiB in total; read-only recycle_cache_bytes) back to the driver now; an allocation that
  *                     fails does the same before it gives up
