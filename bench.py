@@ -939,6 +939,12 @@ def extras(ctx, model, counts, z, r, PPS, bytes_per_eval):
     t = time.perf_counter()
     lf.bestfit_scipy(batch_stencil=False, **fixed)          # the reference's stream of scalar calls (round 2's number)
     ex['api_bestfit_scipy_scalar_stream_s'] = time.perf_counter() - t
+    lf.bestfit_batched(**fixed)
+    t = time.perf_counter()
+    eb, ell = lf.bestfit_batched(**fixed)                  # the same fit as ONE problem of the batched engine (kinks handled, 5 starts)
+    ex['api_bestfit_batched_single_fit_s'] = time.perf_counter() - t
+    ex['api_bestfit_batched_single_fit_max_loglikelihood'] = float(ell[0])
+    assert ell[0] >= ll - 1e-6 * abs(ll), (ell[0], ll)
     t = time.perf_counter()
     for i in range(300):
         lf(shape0=0.1 + 1e-4 * i, s0_rate_multiplier=1.05)
