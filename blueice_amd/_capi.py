@@ -68,6 +68,7 @@ SIGNATURES = {
     'bi_eval_begin': (C.c_int, [_p, _p, _p, _i64]),
     'bi_eval_end': (C.c_int, [_p, _p, _p]),
     'bi_eval_datasets_device': (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    'bi_counts_to_dense': (C.c_int, [_p]),
     'bi_device_alloc': (C.c_int, [_p, _i64, C.POINTER(_p)]),
     'bi_device_free': (C.c_int, [_p, _p]),
     'bi_memcpy_to_host': (C.c_int, [_p, _p, _p, _i64]),

@@ -1390,6 +1390,29 @@ int bi_download_counts(bi_ctx* c, int64_t t, double* out) {
 }
 
 
+int bi_counts_to_dense(bi_ctx* c) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (c->dense_counts) return BI_OK;
+    if (!c->csr_ready) return fail(c, BI_ERR_STATE, "no counts resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->T * c->Bp * sizeof(double);
+    if ((rc = dev_alloc(c, c->counts, bytes))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counts.p, 0, bytes, c->stream));
+    for (int64_t t = 0; t < c->T; ++t) {
+        const int64_t lo = c->h_nz_off[(size_t)t], nnz = c->h_nz_off[(size_t)t + 1] - lo;
+        if (nnz > 0)
+            hipLaunchKernelGGL(k_csr_to_dense, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream,
+                               (const int32_t*)c->nz_idx.p + lo, (const double*)c->nz_n.p + lo, nnz, (double*)c->counts.p + t * c->Bp);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->dense_counts = true;
+    ++c->epoch;                                  // plans made over the lists alone are stale
+    return BI_OK;
+}
+
+
 // ---- extended unbinned likelihood -----------------------------------------------------------------
 
 int bi_set_unbinned(bi_ctx* c, double outlier_likelihood) {

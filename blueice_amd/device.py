@@ -245,6 +245,11 @@ class DeviceContext:
         self._check(self._lib.bi_set_unbinned(self._h, float(outlier_likelihood)))
         self.T = 1
 
+    def counts_to_dense(self):
+        """Device-generated toys (non-empty-bin lists) also as the dense [T][B] array, for the paths that visit every bin
+        (Beeston-Barlow, sparse = 0)."""
+        self._check(self._lib.bi_counts_to_dense(self._h))
+
     def generate_toys(self, z, rate_scale=None, T=1, seed=0):
         """Replace the data by T Poisson toy datasets drawn on the device at parameter point (z, rate_scale)."""
         z = as_f64(z).reshape(self.d) if self.d else None

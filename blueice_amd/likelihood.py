@@ -659,6 +659,8 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         if prior is None:
             raise ValueError("cannot simulate outside the anchor box")
         self.ctx.generate_toys(zs, scale, n_toys, seed)
+        if self.model_statistical_uncertainty_handling is not None:
+            self.ctx.counts_to_dense()             # Beeston-Barlow reads n in every bin: the toys as a dense array too
         self._data = None
         self._binned = None
         self.is_data_set = True

@@ -165,6 +165,10 @@ int64_t bi_simulated_event_count(const bi_ctx* target);
  * context's data and are stored as non-empty-bin lists only (no [T][B] array, no host transfer);
  * bi_eval_datasets works on them directly, point evaluations when the compacted templates fit the budget. */
 int bi_generate_toys(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t T, uint64_t seed);
+/* Expands device-generated toys (non-empty-bin lists) into the dense [T][B] counts array as well, on the device: what
+ * the paths that visit every bin need -- Beeston-Barlow point evaluations and gradients (likelihood.py:618-660 read n in
+ * every bin), sparse = 0.  T * B * 8 bytes of HBM; a no-op when the counts are dense already. */
+int bi_counts_to_dense(bi_ctx* ctx);
 /* dense counts [B] of dataset t, from whatever form is resident */
 int bi_download_counts(bi_ctx* ctx, int64_t t, double* out);
 
