@@ -194,13 +194,15 @@ def bestfit_toys(lf, t0=0, t1=None, **kwargs):
     return bestfit_batched(lf, datasets=np.arange(t0, t1), **kwargs)
 
 
-def toy_mc_fits(lf, n_toys, chunk=256, seed=0, truth=None, livetime_days=None, **fit_kwargs):
+def toy_mc_fits(lf, n_toys, chunk=256, seed=0, truth=None, livetime_days=None, first_toy=0, **fit_kwargs):
     """A toy-MC ensemble with a fit per toy, start to finish on the device: `n_toys` binned toys drawn at the parameter
     values `truth` (dict; defaults elsewhere) and fitted, `chunk` toys at a time (`simulate_toys` + `bestfit_toys`) -- the
     reference's `for _ in range(n_toys): d = lf.base_model.simulate(); lf.set_data(d); bestfit_scipy(lf)`
     (blueice/model.py:69-91, inference.py:131-178).  The toys are numbered globally (the generator's counters are
     (seed, toy number, bin)), so the ensemble does not depend on `chunk`: that only bounds the HBM taken by the toys'
-    compacted templates (see `bestfit_toys`).  fit_kwargs: parameters held fixed, `guess`, ... as `bestfit_batched`.
+    compacted templates (see `bestfit_toys`).  first_toy: the number of this call's first toy -- ranks that each take a range
+    of one ensemble (one process per GPU) draw the toys one process would.  fit_kwargs: parameters held fixed, `guess`, ...
+    as `bestfit_batched`.
     -> (OrderedDict name -> fitted values [n_toys], max log likelihood [n_toys]).  Afterwards the likelihood's data are
     the toys of the last chunk."""
     ctx = getattr(lf, 'ctx', None)
@@ -210,7 +212,7 @@ def toy_mc_fits(lf, n_toys, chunk=256, seed=0, truth=None, livetime_days=None, *
     try:
         for t0 in range(0, int(n_toys), int(chunk)):
             n = min(int(chunk), int(n_toys) - t0)
-            ctx.set_param('toy_offset', t0)
+            ctx.set_param('toy_offset', int(first_toy) + t0)
             lf.simulate_toys(n, seed=seed, livetime_days=livetime_days, **(truth or {}))
             b, ll = bestfit_toys(lf, livetime_days=livetime_days, **fit_kwargs)
             lls.append(ll)
