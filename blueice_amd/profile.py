@@ -381,6 +381,38 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
                 alt = x0.copy()
                 alt[:, j] = np.where(inside, x0[:, j], 0.5 * (a + b))
                 starts.append(alt)
+    # A start that sits ON a kink (the base value of a shape parameter is an anchor) from which the function falls to BOTH
+    # sides: the kink rule of the optimiser goes down the steeper one, and the other grid cell -- whose maximum may be the
+    # higher one -- would never be seen.  Those problems, and only those, get one more start: a hair into the other side
+    # (the rows of all other problems in that start are nan and drop out at its first evaluation).
+    n_vee = 0
+    if multi_start:
+        on = np.zeros(x0.shape, dtype=bool)
+        for j, ks in enumerate(kinks):
+            if len(ks):
+                on[:, j] = np.isin(x0[:, j], ks)
+        pi, ji = np.nonzero(on)
+        if len(pi):
+            k = np.arange(len(pi))
+            xt = np.concatenate([x0[pi], x0[pi]])
+            xt[k, ji] = np.nextafter(xt[k, ji], -np.inf)
+            xt[len(pi) + k, ji] = np.nextafter(xt[len(pi) + k, ji], np.inf)
+            ft, gt = obj(xt, np.concatenate([pi, pi]))
+            gl, gr = gt[k, ji], gt[len(pi) + k, ji]
+            with np.errstate(invalid='ignore'):
+                vee = np.isfinite(ft[:len(pi)]) & np.isfinite(ft[len(pi):]) & (gl > 0) & (gr < 0)
+            for j in np.unique(ji[vee]):
+                sel = vee & (ji == j)
+                rows = pi[sel]
+                other = np.where(gl[sel] > -gr[sel], 1.0, -1.0)        # the optimiser takes the steeper side: start on the other
+                alt = np.full_like(x0, np.nan)
+                alt[rows] = x0[rows]
+                ks = kinks[j]
+                at = np.searchsorted(ks, x0[rows, j])
+                width = np.where(other > 0, np.append(ks, hi[j])[at + 1] - ks[at], ks[at] - np.append(lo[j], ks)[at])
+                alt[rows, j] = x0[rows, j] + other * 1e-6 * np.where(np.isfinite(width), width, 1.0)
+                starts.append(alt)
+                n_vee += len(rows)
     for extra in also_from:
         alt = x0.copy()
         for j, key in enumerate(names):
@@ -405,6 +437,7 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         x, f = x[pick], f[pick]
         info = dict(info, **{k: info[k][pick] for k in ('converged', 'stalled', 'failed')})
         info['starts'] = n_st
+        info['vee_starts'] = n_vee
         info['winning_start'] = order[win, np.arange(P)]
         del rows_of
     info['evaluations'] = obj.evaluations
