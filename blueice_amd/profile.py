@@ -313,8 +313,9 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
     fixed (kwargs): parameters held at one value in every problem; everything else floats, as in `bestfit_scipy`
     (rate multipliers first, guess 1; then shape parameters, guess = base value; blueice/inference.py:79-102).
     guess: dict name -> scalar or array [P] (e.g. the neighbouring hypothesis' solution).
-    multi_start: also start from the other grid cells of every floating shape parameter (see below); the reference's
-    single start is multi_start=False.  also_from: more starting points, each a dict name -> scalar or array [P] (floating
+    multi_start: also start from the other grid cells of every floating shape parameter (see below; 'cells' = from the
+    centre of every cell of their anchor grid, the thorough and expensive variant); the reference's single start is
+    multi_start=False.  also_from: more starting points, each a dict name -> scalar or array [P] (floating
     parameters it does not name start at their guess) -- e.g. the global best fit's nuisances for a profile fit.
     datasets: array [P] of dataset indices, one per problem (the likelihood holds several datasets: `set_binned_data` with
     a stack, `simulate_toys`) -- every toy of a toy-MC ensemble fitted at the same time instead of the reference's loop
@@ -367,6 +368,22 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
     # shape parameter (one axis at a time, not their product); all starts take `scout_iterations` steps together, then
     # the best `keep_starts` per problem run to convergence.  The price is a few more rows per device call.
     starts = [x0]
+    thorough = isinstance(multi_start, str) and multi_start == 'cells'
+    if thorough:
+        # the thorough variant: one start in the centre of EVERY cell of the floating shape parameters' anchor grid (their
+        # product: 4^d cells for five anchors per axis) -- for likelihoods with a hump per cell, at that many times the rows
+        import itertools
+        centres = []
+        for j, key in enumerate(names):
+            anchors = lf.shape_parameters.get(key, (None,))[0] if key in lf.shape_parameters else None
+            zs = np.sort(np.array([float(a) for a in (anchors or ()) if is_numeric(a)]))
+            if len(zs) > 1:
+                centres.append((j, 0.5 * (zs[:-1] + zs[1:])))
+        for combo in itertools.product(*[c for _, c in centres]):
+            alt = x0.copy()
+            for (j, _), v in zip(centres, combo):
+                alt[:, j] = v
+            starts.append(alt)
     if multi_start:
         for j, key in enumerate(names):
             anchors = lf.shape_parameters.get(key, (None,))[0] if key in lf.shape_parameters else None
@@ -427,7 +444,7 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         scout = lambda xx, rr: obj(xx, rr % P)                       # row r of the stacked problem set is problem r % P
         xs, fs, _ = batched_minimize(scout, np.concatenate(starts), lo, hi, gtol=gtol, max_iter=scout_iterations, kinks=kinks)
         fs = np.where(np.isfinite(fs), fs, np.inf).reshape(n_st, P)
-        keep = min(keep_starts + len(also_from), n_st)
+        keep = n_st if thorough else min(keep_starts + len(also_from), n_st)      # ('cells': every start runs to convergence)
         order = np.argsort(fs, axis=0, kind='stable')[:keep]          # [keep, P] start indices, best first
         xk = xs.reshape(n_st, P, -1)[order, np.arange(P)[None, :]].reshape(keep * P, -1)
         x, f, info = batched_minimize(scout, xk, lo, hi, gtol=gtol, max_iter=max_iter, kinks=kinks)
