@@ -263,7 +263,7 @@ def _first_crossing(tfun, a, b, xtol=1e-11, points_per_round=16, max_rounds=12):
     return float(lo - tl * (hi - lo) / (th - tl))
 
 
-def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper', bestfit_routine=None,
+def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper', bestfit_routine=None, fit_options=None,
                            t_ppf=None, **kwargs):
     """Profile-likelihood interval on parameter `target` (reference: blueice/inference.py:332-389).
     kind 'upper' / 'lower': `bound` is the far end of the line search; 'central': a 2-tuple.
@@ -272,14 +272,16 @@ def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper'
     search finds.  With a likelihood that evaluates batches (and no bestfit_routine of the caller's) the search runs on
     the batched profile-fit engine: every round profiles a fan of hypotheses in lock-step on the device (a handful of
     rounds of ~16 fits, each a few dozen device calls) instead of brentq's chain of nested sequential fits (3 387 scalar
-    likelihood calls per limit in SURVEY.md's probe); otherwise the reference's loop."""
+    likelihood calls per limit in SURVEY.md's probe); otherwise the reference's loop.  fit_options: dict of options of the
+    batched engine (`bestfit_batched`: multi_start='cells', gtol, ...)."""
+    fit_options = dict(fit_options or {})
     if target is None:
         target = lf.source_list[-1] + '_rate_multiplier'
     batched = bestfit_routine is None and supports_batched_fits(lf)
     fit = bestfit_routine or bestfit_scipy
     if batched:
         try:
-            best, ll = bestfit_batched(lf, **kwargs)
+            best, ll = bestfit_batched(lf, **fit_options, **kwargs)
             best, max_ll = {k: float(v[0]) for k, v in best.items()}, float(ll[0])
         except NoOpimizationNecessary:
             batched = False
@@ -310,7 +312,7 @@ def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper'
             need = np.array([not one_sided_ok(h) for h in hs])
             if np.any(need):
                 if nuisances:                       # every hypothesis starts where the reference starts AND at the global best fit's nuisances
-                    _, ll = bestfit_batched(lf, points={target: hs[need]}, also_from=[{k: best[k] for k in nuisances}], **kwargs)
+                    _, ll = bestfit_batched(lf, points={target: hs[need]}, also_from=[{k: best[k] for k in nuisances}], **fit_options, **kwargs)
                 else:                               # nothing left to profile: plain evaluations
                     ll = np.asarray(lf.eval_points(dict(kwargs, **{target: hs[need]})))
                 out[need] = 2 * (max_ll - ll) - crit[need]
@@ -332,7 +334,7 @@ def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper'
     raise ValueError("kind must be 'upper', 'lower' or 'central'")
 
 
-def likelihood_ratio_scan(lf, *space, bestfit_routine=None, **kwargs):
+def likelihood_ratio_scan(lf, *space, bestfit_routine=None, fit_options=None, **kwargs):
     """-log likelihood ratio over a 1-d or 2-d grid of parameter values: the numbers behind the reference's
     `plot_likelihood_ratio` (blueice/inference.py:392-443) without the plotting.
     space: (name, values) tuples.  Parameters given in kwargs are fixed, all others are fitted at every grid
@@ -352,7 +354,7 @@ def likelihood_ratio_scan(lf, *space, bestfit_routine=None, **kwargs):
         pts.update({k: v for k, v in kwargs.items()})
         ll = np.asarray(lf.eval_points(pts)).reshape(grids[0].shape)
     elif floating and bestfit_routine is None and supports_batched_fits(lf):
-        ll = bestfit_batched(lf, points=pts, **kwargs)[1].reshape(grids[0].shape)
+        ll = bestfit_batched(lf, points=pts, **(fit_options or {}), **kwargs)[1].reshape(grids[0].shape)
     else:
         fit = bestfit_routine or bestfit_scipy
         ll = np.empty(grids[0].shape)

@@ -391,8 +391,9 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
                 continue
             zs = np.sort(np.array([float(a) for a in anchors if is_numeric(a)]))
             for a, b in zip(zs[:-1], zs[1:]):
-                inside = (x0[:, j] >= a) & (x0[:, j] <= b)       # (a start ON an anchor belongs to both neighbours: the kink rule
-                #  sends it down the steeper side; extra starts in their centres bought nothing on C2 for 50 % more rows)
+                inside = (x0[:, j] > a) & (x0[:, j] < b)         # (a start ON an anchor -- the usual case: base values are
+                #  anchors -- is inside neither neighbour: both get a start.  40 % more rows on C2, where it changes nothing;
+                #  on the 40-bin test model a quarter of a profiled scan's points end up to 0.5 higher for it)
                 if np.all(inside):
                     continue
                 alt = x0.copy()
