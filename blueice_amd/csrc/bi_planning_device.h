@@ -12,11 +12,11 @@ namespace {
 
 // Blocks of a matrix-core scan kernel variant that one CU holds at a time (registers decide it), asked from the runtime
 // once per variant: the planner sizes the split of a cell's strips so that the blocks run in full rounds.
-int scan_resident_blocks(bool valid, int cb, int NS) {
-    static std::atomic<int> cache[2][2][4][2];
+int scan_resident_blocks(bool valid, int cb, int NS, bool by_count = false) {
+    static std::atomic<int> cache[3][2][4][2];
     const int kg = NS <= 4 ? 0 : (NS <= 8 ? 1 : (NS <= 16 ? 2 : 3));
     const int mask = NS == (4 << kg) ? 0 : 1;
-    std::atomic<int>& slot = cache[valid ? 1 : 0][cb == 2 ? 0 : 1][kg][mask];
+    std::atomic<int>& slot = cache[by_count ? 2 : (valid ? 1 : 0)][cb == 2 ? 0 : 1][kg][mask];
     int v = slot.load();
     if (v > 0) return v;
     const void* f = nullptr;
@@ -33,7 +33,18 @@ int scan_resident_blocks(bool valid, int cb, int NS) {
             default: f = (const void*)KERNEL<CB, 8, true>; break;                                                  \
         }                                                                                                          \
     } while (0)
-    if (valid) BI_PICK(k_scan_valid, 4);
+    if (by_count) {
+        switch (kg * 2 + mask) {
+            case 0: f = (const void*)k_scan_sorted<1, false>; break;
+            case 1: f = (const void*)k_scan_sorted<1, true>; break;
+            case 2: f = (const void*)k_scan_sorted<2, false>; break;
+            case 3: f = (const void*)k_scan_sorted<2, true>; break;
+            case 4: f = (const void*)k_scan_sorted<4, false>; break;
+            case 5: f = (const void*)k_scan_sorted<4, true>; break;
+            case 6: f = (const void*)k_scan_sorted<8, false>; break;
+            default: f = (const void*)k_scan_sorted<8, true>; break;
+        }
+    } else if (valid) BI_PICK(k_scan_valid, 4);
     else if (cb == 2) BI_PICK(k_scan_mfma, 2);
     else BI_PICK(k_scan_mfma, 4);
 #undef BI_PICK
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
     const int64_t p = idx[i];
     const int g = (int)((i - gstart[i]) % kDevG);
     const int64_t item = item_incl[i] - 1;
+    const bool last_of_group = i + 1 == n || gstart[i + 1] == i + 1;
     const int64_t ds = (int64_t)(keys[i] % (uint64_t)m.T), cell = (int64_t)(keys[i] / (uint64_t)m.T);
     const int NS = m.nc * m.S;
     const int64_t row_stride = m.sparse ? m.c_np[ds] : m.Bp;
@@ -236,6 +248,11 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
             const double cf = wc * r[s];
             const double tz = m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0);
             coef[(item * NS + k + s) * kDevG + g] = cf;
+            // the unused slots of a group's last work item repeat its last point (their results are dropped: perm = -1):
+            // with coefficients of zero their expectations would be zero, and the product forms of the scan kernels
+            // would have to leave their fast path for the whole item
+            if (last_of_group)
+                for (int gg = g + 1; gg < kDevG; ++gg) coef[(item * NS + k + s) * kDevG + gg] = cf;
             if (m.sparse || m.linear_outside) zsum += cf * tz;
             if (g == 0) {
                 rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
@@ -766,16 +783,19 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             // non-empty-bin form --, 64 where most blocks of 16 bins hold no data at all
             const int cb = c->scan_cb ? (int)c->scan_cb : ((mostly_empty && !sparse) ? 4 : 2);
             plan->use_scan = true;
-            plan->scan_cb = cb;
             // dense data, rows in full: the count-sorted copy, if it can be had (every bin still visited, in another order)
             plan->sorted = !compacted && cb == 2 && ensure_sorted_rows(c);
             plan->by_count = plan->sorted || (compacted && cb == 2 && c->compact_sorted);
+            // rows in count order go to k_scan_sorted: strips of 64 bins, four work items at a time
+            const int strip_cb = plan->by_count ? 4 : cb;
+            plan->scan_cb = strip_cb;
             plan->n_groups = n_groups;
             // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
             const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * cb)), scan_resident_blocks(false, cb, NS), slot_cap);
+            const int resident = scan_resident_blocks(false, strip_cb, NS, plan->by_count);
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * strip_cb)), resident, slot_cap);
             c->last_scan_nslots = k.nbx;
-            c->last_scan_resident = scan_resident_blocks(false, cb, NS);
+            c->last_scan_resident = resident;
             dev_free(k.partial);
             dev_free(k.pflags);                     // the scan kernel raises no per-block flags (k_finish_scan reads none)
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double)))) return abort_plan(rc);

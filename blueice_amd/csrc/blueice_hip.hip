@@ -33,6 +33,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/blueice_hip.h"
@@ -42,6 +43,7 @@
 #include "bi_context.h"
 #include "bi_log_table.h"
 #include "bi_kernels.h"
+#include "bi_scan_sorted.h"
 #include "bi_geometry.h"
 #include "bi_launch.h"
 #include "bi_sparse.h"
@@ -591,10 +593,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
 #define BI_SCAN(CB, KG)                                                                                           \
     do {                                                                                                          \
-        if (CB == 2 && plan->by_count) { /* rows ordered by count (all bins of dense data, or the compacted non-empty bins): n log of the product over a lane's bins */ \
-            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 2>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 2>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
-        } else if (CB == 2 && plan->sparse) { /* compacted rows in bin order: blocks of counts 1 and 2 take the logarithm of the product mu^n */ \
+        if (CB == 2 && plan->sparse) { /* compacted rows in bin order: blocks of counts 1 and 2 take the logarithm of the product mu^n */ \
             if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 1>), sgrid, dim3(kThreads), 0, c->stream, sa); \
             else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 1>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
         } else if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
@@ -604,7 +603,18 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     do {                                                                                                          \
         if (kg == 1) BI_SCAN(CB, 1); else if (kg == 2) BI_SCAN(CB, 2); else if (kg == 4) BI_SCAN(CB, 4); else BI_SCAN(CB, 8); \
     } while (0)
-            if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
+    /* rows ordered by count (all bins of dense data, or the compacted non-empty bins): 64-bin strips, four items at a time */ \
+#define BI_SORTED(KG)                                                                                             \
+    do {                                                                                                          \
+        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_sorted<KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
+        else hipLaunchKernelGGL((k_scan_sorted<KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
+    } while (0)
+            if (plan->by_count) {
+                sa.n_groups = (int)plan->n_groups;
+                const dim3 sgrid((unsigned)(k.nbx / 4), (unsigned)((plan->n_groups + 7) / 8 * 8));
+                if (kg == 1) BI_SORTED(1); else if (kg == 2) BI_SORTED(2); else if (kg == 4) BI_SORTED(4); else BI_SORTED(8);
+            } else if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
+#undef BI_SORTED
 #undef BI_SCAN_KG
 #undef BI_SCAN
         }
