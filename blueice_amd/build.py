@@ -1,6 +1,10 @@
 """Build libblueice_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m blueice_amd.build [--force]
+
+build_host() compiles csrc/host_backend.cpp -- the minimal entry points of the same C ABI as plain C++ loops on the
+host -- into lib/libblueice_host.so.  That library is a BOUNDARY TEST BUILD: the package
+never loads it (blueice_amd/_capi.py binds libblueice_hip.so only); tests and tools/ load it by explicit path.
 """
 import os
 import subprocess
@@ -44,5 +48,23 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_SRC = os.path.join(CSRC, 'host_backend.cpp')
+HOST_OUT = os.path.join(OUT_DIR, 'libblueice_host.so')
+
+
+def build_host(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(HOST_OUT) and os.path.getmtime(HOST_OUT) >= max(os.path.getmtime(HOST_SRC), os.path.getmtime(HDR)):
+        return HOST_OUT
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-shared', '-fPIC',
+           '-ffp-contract=off',          # every multiplication and addition rounds on its own, as numpy's do
+           '-Wall', '-Wextra', '-o', HOST_OUT, HOST_SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return HOST_OUT
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    print(build_host(force='--force' in sys.argv, verbose=True))

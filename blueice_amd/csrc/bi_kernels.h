@@ -2101,7 +2101,7 @@ struct ScanArgs {
     double* partial;            // [items][nslots][16], zero on entry
     int NS;
     int nslots;                 // waves per group = gridDim.x * 4
-    int n_groups;               // k_scan_sorted: gridDim.y is n_groups rounded up to a multiple of 8 (one XCD per group)
+    int n_groups;               // k_scan_sorted (one-dimensional grid, dealt to the XCDs in contiguous ranges of blocks)
 };
 
 // sum of a double over the 4 DPP rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): one half-row exchange and one half-wave

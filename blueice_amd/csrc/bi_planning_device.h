@@ -737,7 +737,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // fewer waves): at C2 the 320 compacted strips of a cell go to 12 blocks of 7 strips in ONE round instead of 20 blocks
         // of 4 strips in two, dense data gets 8 full rounds instead of 2.7.  `resident` = blocks of that kernel variant a CU
         // holds (asked from the runtime); slot_cap bounds the waves where every wave owns a partial slot per item.
-        auto waves_per_group = [&](int64_t strips, int resident, int64_t slot_cap) -> int64_t {
+        // pipe_bound (k_scan_sorted): the kernel keeps the fp64 matrix pipe ~87 % busy, so the waves of a SIMD SHARE it
+        // and a CU's time is the sum of its blocks' strips, not the longest of them: what counts is the busiest CU --
+        // ceil(blocks / CUs) blocks when all are resident at once (640 blocks of 4 strips on 256 CUs are 3 x 4 = 12
+        // units on half of the CUs, 512 blocks of 5 strips are 10 on all of them: 11.6 instead of 13.8 ms for the 10^6-
+        // point scan of C2), the mean load plus a quarter of a block generation's length when they run in several
+        // rounds (measured: tools/tune_scan_sorted.py); one block per CU leaves a SIMD a single wave and nothing to
+        // cover its latencies with (+25 %).  Among the splits within 3 % of the best the coarsest is taken (fewer
+        // partial slots for the finish to add up).
+        auto waves_per_group = [&](int64_t strips, int resident, int64_t slot_cap, bool pipe_bound = false) -> int64_t {
             const int64_t capacity = (int64_t)c->prop.multiProcessorCount * std::max(1, resident);
             const int64_t b_max = std::max<int64_t>(1, std::min<int64_t>(strips / 4, slot_cap / 4));
             if (c->scan_waves_per_cu > 0) {      // forced (tuning): that many waves per CU over all groups, evened out
@@ -751,6 +759,24 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                 if ((strips + 4 * per_wave - 1) / (4 * per_wave) != b) return 1e300;          // not an evened-out split
                 return (double)((b * n_groups + capacity - 1) / capacity) * (double)per_wave;
             };
+            if (pipe_bound) {
+                const int64_t n_cu = std::max(1, c->prop.multiProcessorCount);
+                auto pipe_cost = [&](int64_t b) -> double {
+                    const int64_t per_wave = (strips + 4 * b - 1) / (4 * b);
+                    if ((strips + 4 * per_wave - 1) / (4 * per_wave) != b) return 1e300;
+                    const int64_t blocks = b * n_groups;
+                    if (blocks <= capacity) {
+                        const int64_t per_cu = (blocks + n_cu - 1) / n_cu;
+                        return (double)(per_cu * per_wave) * ((per_cu == 1 && resident > 1) ? 1.25 : 1.0);
+                    }
+                    return (double)blocks / (double)n_cu * (double)per_wave + 0.25 * (double)resident * (double)per_wave;
+                };
+                double best = 1e300;
+                for (int64_t b = 1; b <= b_max; ++b) best = std::min(best, pipe_cost(b));
+                for (int64_t b = 1; b <= b_max; ++b)
+                    if (pipe_cost(b) <= 1.03 * best) return b * 4;
+                return 4;
+            }
             double best_cost = 1e300;
             int64_t best_b = 1;
             for (int64_t b = 1; b <= b_max; ++b)
@@ -793,7 +819,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
             const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));
             const int resident = scan_resident_blocks(false, strip_cb, NS, plan->by_count);
-            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * strip_cb)), resident, slot_cap);
+            k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * strip_cb)), resident, slot_cap, plan->by_count);
             c->last_scan_nslots = k.nbx;
             c->last_scan_resident = resident;
             dev_free(k.partial);

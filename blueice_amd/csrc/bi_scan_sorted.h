@@ -84,15 +84,18 @@ constexpr int kScaleMax = 900;
 template <int KG, bool MASK>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_scan_sorted(ScanArgs a) {
     constexpr int CB = 4, STRIP = 64;
-    // Blocks are dispatched to the 8 XCDs round-robin in launch order (x fastest).  All blocks of a group go to ONE XCD:
-    // they walk the same coefficient list (4 KB per work item: 4 MB per cell of a 10^6-point scan, read again for every
-    // strip), which then stays in that XCD's L2 instead of being fetched into all eight.
-    const unsigned launch_id = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned in_xcd = launch_id >> 3;
-    const int grp = (int)((in_xcd / gridDim.x) * 8 + (launch_id & 7));
-    if (grp >= a.n_groups) return;
+    // Blocks are dispatched to the 8 XCDs round-robin in launch order.  The (group, block) pairs, group-major, are cut
+    // into eight contiguous ranges, one per XCD: the blocks of a group walk the same coefficient list (4 KB per work item,
+    // 4 MB per cell of a 10^6-point scan, read again for every strip), which then lives in ONE XCD's L2 (two, where a range
+    // ends inside a group) instead of being fetched into all eight -- and the XCDs carry equal numbers of blocks whatever
+    // the number of groups is.
+    const unsigned gx = (unsigned)a.nslots / 4, total = gx * (unsigned)a.n_groups;
+    const unsigned per_xcd = (total + 7) / 8;
+    const unsigned linear = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || linear >= total) return;
+    const int grp = (int)(linear / gx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = (int)(in_xcd % gridDim.x) * 4 + wave;
+    const int slot = (int)(linear % gx) * 4 + wave;
     const int64_t item0 = a.grp_first[grp];
     const int n_items = a.grp_items[grp];
     const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;

@@ -611,7 +611,8 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     } while (0)
             if (plan->by_count) {
                 sa.n_groups = (int)plan->n_groups;
-                const dim3 sgrid((unsigned)(k.nbx / 4), (unsigned)((plan->n_groups + 7) / 8 * 8));
+                const int64_t scan_blocks = (int64_t)(k.nbx / 4) * plan->n_groups;
+                const dim3 sgrid((unsigned)((scan_blocks + 7) / 8 * 8));
                 if (kg == 1) BI_SORTED(1); else if (kg == 2) BI_SORTED(2); else if (kg == 4) BI_SORTED(4); else BI_SORTED(8);
             } else if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
 #undef BI_SORTED
