@@ -55,6 +55,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_thread_share(world):
+    """Host threads ONE rank may use: the cores this process may run on, divided among the ranks of the node (every rank
+    uploads its replica and plans its batches with a few threads; eight ranks x 16 threads would be a worker pool the GPU
+    pool kills)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return max(1, cores // max(1, int(world)))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CPU baseline (the only place the oracle is used)
 # ---------------------------------------------------------------------------------------------------------
@@ -84,7 +92,7 @@ def cpu_baseline(model, counts, points, budget_s=15.0):
     from oracle import blueice_oracle as orc
     z, r = points
     cm = model.cell_model(z[0])
-    orc.loglikelihood(cm, counts, z[0], r[0])            # warm
+    value = float(orc.loglikelihood(cm, counts, z[0], r[0]))            # warm; also the checker of the timed outputs
     n, t0 = 0, time.perf_counter()
     while True:
         orc.loglikelihood(cm, counts, z[0], r[0])
@@ -92,7 +100,7 @@ def cpu_baseline(model, counts, points, budget_s=15.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 2000:
             break
-    return dict(value=n / dt, unit='evals/s', cores=1, kind='port',
+    return dict(value=n / dt, unit='evals/s', cores=1, kind='port', oracle_value=value,
                 sample='%d single-thread evaluations of the C2 model at one off-grid point (%.1f s); '
                        'numpy %s oracle = the reference arithmetic' % (n, dt, np.__version__))
 
@@ -203,6 +211,18 @@ class Ranks:
 # ---------------------------------------------------------------------------------------------------------
 # strong-scaling legs
 # ---------------------------------------------------------------------------------------------------------
+def predicted_ceiling(units, step_ms, kernel_ms, world):
+    """What a strong-scaling leg can reach at N ranks, from this run's own split of a step: the kernels' share divides by
+    N, everything else (planning of ALL units on every rank, copies, the gather, the read-back) is paid by every rank in
+    full.  `kernel_ms` is this run's kernel time per step on the busiest rank (HIP events), i.e. 1/world of the total."""
+    kernel_ms = min(kernel_ms, step_ms)          # (the step that carries the HIP events is a little slower than the timed ones)
+    fixed = step_ms - kernel_ms
+    total_kernel = kernel_ms * world
+    return dict(model='per-rank fixed ms + kernel ms / N', fixed_ms_per_rank=fixed, kernel_ms_total=total_kernel,
+                measured_at_n=world,
+                evals_per_s={str(n): units / ((fixed + total_kernel / n) * 1e-3) for n in (1, 2, 4, 8)})
+
+
 def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     """A profile scan of P parameter points over the resident model (BASELINE.json configs[3]), STRONG scaling.  One step =
     ALL P points in -> full result vector on every rank, everything inside the clock.  Timed twice: with the points
@@ -286,6 +306,13 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
         ranks.barrier()
         elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
         assert np.array_equal(out_res, out), '%s: resident points and host points disagree' % label
+    # where a step's time goes: one more step with HIP events around every kernel launch of this rank
+    ctx.profile(True)
+    step(work[-1], held[-1] if can_reside else None)
+    _, kernel_ms = ctx.profile_read()
+    ctx.profile(False)
+    kernel_ms = ranks.max_over_ranks(kernel_ms)
+    if can_reside:
         for bz, br in held:
             bz.free(); br.free()
     # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel) on THIS rank: every rank holds
@@ -306,7 +333,9 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
                 points_per_rank_min_max=seen['share'],
                 dealing=('device planner sort, inside the step' if device_deal else
                          ('none (one process)' if world == 1 else 'host (deal_points_by_cell), inside the step')),
-                sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(seen['bytes']), gather=ranks.kind)
+                sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(seen['bytes']), gather=ranks.kind,
+                step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, elapsed / steps * 1e3 - kernel_ms)),
+                predicted_ceiling=predicted_ceiling(P, elapsed / steps * 1e3, kernel_ms, world))
 
 
 def toy_leg(ctx, ranks, model, T, steps):
@@ -354,14 +383,37 @@ def toy_leg(ctx, ranks, model, T, steps):
         one, _ = ctx.eval_datasets(zk, r)
         assert one[0] == out[t], 'toy %d: %r on this rank, %r gathered' % (t, one[0], out[t])
         checked.append(t)
+    ctx.set_param('toy_offset', t0_)
+    ctx.generate_toys(z, r, t1_ - t0_, seed=4242)      # this rank's range again, for the kernel timing of one more call
+    step(-1)
+    ctx.profile(True)
+    step(0)
+    n_launch, kernel_ms = ctx.profile_read()
+    ctx.profile(False)
+    kernel_ms = ranks.max_over_ranks(kernel_ms)
     ctx.set_param('toy_offset', 0)
+    # algorithmic bytes of a call on this rank: the 2^d*S template rows once (log mu of every bin) + 4 bytes per list entry
+    # (13 bits of bin, 19 bits of count) of every dataset; the entries are gathered against a tile of log mu held in LDS
+    NS = 2 ** model.d * model.S
+    nbytes = 8.0 * NS * model.B + 4.0 * nnz
+    step_ms = elapsed / steps * 1e3
+    roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, bytes_per_call=nbytes, launches_per_call=int(n_launch),
+                kernel_ms_per_call=kernel_ms, achieved=nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None,
+                achieved_over_whole_step=nbytes / (step_ms * 1e-3) / 1e9, traffic=None,
+                note='algorithmic bytes per call / summed kernel time of the call (HIP events): the log-mu pass streams the '
+                     '2^d*S rows at HBM rate, the dataset pass reads 4-byte list entries against log mu tiles in LDS and is '
+                     'bound by that gather, not by HBM -- the fraction of the HBM peak is small by construction; what the '
+                     'call is measured by is evaluations per second')
+    roof['frac'] = roof['achieved'] / HBM_PEAK_GBS if roof['achieved'] else None
     return dict(workload='C3: 10^4 toy datasets (drawn on the device), one parameter point per call, datasets split '
                          'by range over the ranks', scaling='strong', datasets=T, steps=steps, value=T * steps / elapsed,
-                unit='evals/s', ms_per_step=elapsed / steps * 1e3, generate_s=gen_s, toys_rechecked_bitwise=checked,
-                nonempty_bins_this_rank=nnz, gather=ranks.kind)
+                unit='evals/s', ms_per_step=step_ms, generate_s=gen_s, toys_rechecked_bitwise=checked,
+                nonempty_bins_this_rank=nnz, gather=ranks.kind, roofline=roof,
+                step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, step_ms - kernel_ms)),
+                predicted_ceiling=predicted_ceiling(T, step_ms, kernel_ms, world))
 
 
-def c5_leg(ctx, ranks, steps=24):
+def c5_leg(ctx, ranks, steps=24, threads=8):
     """configs[4] on one grid cell of its anchor grid (2^4 anchors, 6 sources, 50^4 bins, Beeston-Barlow on source 0;
     blueice/likelihood.py:618-660), uploaded into `ctx` in place of the C2 model:
       kernel   `k_morph_reduce<1,true,true>`, one evaluation per launch -- all 113 stream rows, 5.65 GB per pass --
@@ -369,7 +421,7 @@ def c5_leg(ctx, ranks, steps=24):
       scan     256 scan points in that cell, STRONG scaling over the ranks (the host planner groups 8 points per pass)."""
     from blueice_amd.synthetic import SyntheticModel
     m = SyntheticModel.named('C5-2anchor', bb_source=0)
-    m.upload(ctx, threads=8)
+    m.upload(ctx, threads=min(8, threads))
     ctx.set_param('sparse', 0)
     ctx.upload_counts(m.counts(dense=True))
     z, r = m.random_points(4, seed=2)
@@ -506,6 +558,8 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': world, 'dry': True,
                           'steps': args.steps, 'warmup': args.warmup,
+                          'config': {'host_threads_per_rank': host_thread_share(world),
+                                     'host_cores_of_this_process': len(os.sched_getaffinity(0))},
                           'legs': {'C4': {'points': len(z), 'points_per_rank_min_max': [min(len(d) for d in deal), max(len(d) for d in deal)],
                                           'ranks': ranks_seen[:, 0].tolist(), 'devices': ranks_seen[:, 1].tolist(), 'gather': comm.kind}}}),
               flush=True)
@@ -552,6 +606,8 @@ def main():
 
     ctx = DeviceContext(default_device())
     info = ctx.info()
+    threads = host_thread_share(world)              # per rank: upload threads and the library's planner threads
+    ctx.set_param('host_threads', min(16, threads))
     ranks = Ranks(ctx, args.backend)
 
     def emit(result):
@@ -567,7 +623,7 @@ def main():
     if args.config != 'C2':
         if args.config in ('C3', 'C4', 'C4-dense'):
             model = SyntheticModel.named('C2')
-            model.upload(ctx, threads=4)
+            model.upload(ctx, threads=min(4, threads))
             steps = max(1, min(K, 5 if args.config != 'C4-dense' else 2))
             if args.config == 'C3':
                 leg = toy_leg(ctx, ranks, model, 10000, max(1, min(K, 50)))
@@ -581,7 +637,7 @@ def main():
         else:
             model = SyntheticModel.named(args.config, bb_source=0)
             t = time.perf_counter()
-            model.upload(ctx, threads=12)
+            model.upload(ctx, threads=min(12, threads))
             log('rank %d: %s resident after %.0f s' % (rank, args.config, time.perf_counter() - t))
             ctx.set_param('sparse', 0)
             ctx.upload_counts(model.counts(dense=True))
@@ -624,7 +680,7 @@ def main():
 
     # ---- headline ----------------------------------------------------------------------------------------
     model = SyntheticModel.named('C2')
-    model.upload(ctx, threads=4)
+    model.upload(ctx, threads=min(4, threads))
     counts = model.counts()
     ctx.set_param('sparse', 0)          # headline = the dense kernel: every evaluation visits every bin
     sets = [model.disjoint_cell_points(parity=i, seed=1000 * rank + i) for i in range(POOL)]
@@ -654,10 +710,18 @@ def main():
     gathered = ranks.gather(K * PPS) if ranks.multi else None      # the final gather: the only collective
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    # what the timed region computed (every N): the K * PPS results of THIS rank are read back -- all finite, every step
+    # that ran the same plan gave the same bits -- and kept for the oracle's verdict on step 0 (cpu_baseline leg, N = 1)
+    timed_out = send.to_host(np.float64, K * PPS).reshape(K, PPS)
+    assert np.all(np.isfinite(timed_out)), 'the timed steps left non-finite results (or results that were never written)'
+    for i in range(min(K, POOL), K):
+        assert np.array_equal(timed_out[i], timed_out[i % POOL]), 'step %d repeats the plan of step %d but not its results' % (i, i % POOL)
+    outputs = dict(outputs_checked=True, results_read_back=int(timed_out.size),
+                   check='all finite; steps that repeat a plan repeat its bits')
     if gathered is not None:
         # every rank evaluated different points: finite everywhere, and this rank's row is what it computed
         assert gathered.shape == (world, K * PPS) and np.all(np.isfinite(gathered)), 'gathered results are not finite'
-        np.testing.assert_array_equal(gathered[rank], send.to_host(np.float64, K * PPS))
+        np.testing.assert_array_equal(gathered[rank], timed_out.reshape(-1))
 
     # kernel time of the same steps, HIP events on the context stream around every launch
     ctx.profile(True)
@@ -703,7 +767,8 @@ def main():
                                    'dataset, in grid cells that share no anchor (no byte re-used), tensor '
                                    'replicated per GPU' % PPS,
                        'sources': model.S, 'anchors': list(model.n_anchor), 'bins': list(model.bins),
-                       'evals_per_step': PPS, 'device': info['arch'], 'gather': ranks.kind},
+                       'evals_per_step': PPS, 'device': info['arch'], 'gather': ranks.kind,
+                       'host_threads_per_rank': threads},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'k_morph_reduce<1,false,true> (G=1, no BB, nontemporal loads, in-launch finish)',
@@ -774,8 +839,16 @@ def main():
                                                      HBM_PEAK_GBS * 1e9 / (bytes_per_launch / PPS) / 1e3),
         }
 
+    if rank == 0:
+        result.update(outputs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(model, counts, (z, r))
+        # the oracle's value of evaluation 0 of step 0 (point z[0], dataset 0) against what the timed region wrote there
+        want = result['cpu_baseline'].pop('oracle_value')
+        rel = abs(timed_out[0, 0] - want) / max(1.0, abs(want))
+        assert rel <= 1e-10, 'timed step 0, evaluation 0: %r on the device, %r by the oracle' % (timed_out[0, 0], want)
+        result['outputs_rel_diff_vs_oracle_step0_eval0'] = rel
+        result['check'] = outputs['check'] + '; evaluation 0 of timed step 0 equals the oracle to 1e-10'
         result['cpu_baseline']['host_cores_available'] = os.cpu_count()
         calls = result.get('extras', {}).get('api_bestfit_scipy_likelihood_calls')
         if calls:                # the same fit on the host = that many evaluations at the measured single-thread rate
@@ -808,7 +881,7 @@ def main():
     for p in plans:
         p.close()
     if not args.no_legs:
-        kern, scan = c5_leg(ctx, ranks)
+        kern, scan = c5_leg(ctx, ranks, threads=threads)
         if rank == 0:
             result['legs']['C5-BB'] = kern
             result['legs']['C5-BB-scan'] = scan

@@ -51,6 +51,9 @@ const ParamDef kParams[] = {
     {"scan_min_items", kParamRW, BI_P_GET(c->scan_min_items), BI_P_SET(c->scan_min_items = v < 1 ? 1 : v)},
     {"scan_cb", kParamRW, BI_P_GET(c->scan_cb), BI_P_SET(c->scan_cb = (v == 2 || v == 4) ? v : 0)},
     {"scan_waves_per_cu", kParamRW, BI_P_GET(c->scan_waves_per_cu), BI_P_SET(c->scan_waves_per_cu = v < 0 ? 0 : v)},
+    {"host_threads", kParamRW, [](bi_ctx*) -> int64_t { return host_threads(); },
+     [](bi_ctx* c, int64_t v) -> int { if (v < 0 || v > 256) return fail(c, BI_ERR_INVALID, "host_threads in [0, 256] (0 = by the process's affinity, at most 16)"); host_threads_setting().store((int)v); return BI_OK; }},
+    {"scan_xcd", kParamRW, BI_P_GET(c->scan_xcd), BI_P_RANGE(0, 2, scan_xcd, "scan_xcd: 0 launch order, 1 contiguous ranges, 2 one XCD per group")},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},
     {"scan_split", kParamRW, BI_P_GET(c->scan_split), BI_P_FLAG(scan_split)},
     {"scan_pow", kParamRW, BI_P_GET(c->scan_pow), BI_P_SET(c->scan_pow = v ? 1 : 0; c->sorted_epoch = -1)},

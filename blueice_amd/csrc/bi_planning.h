@@ -7,10 +7,27 @@
 
 namespace {
 
+// Host threads the planner may start per call.  One process per GPU: eight ranks on a node each starting 16 threads are
+// 128 threads planning at once, on a pool that kills runs with large worker pools -- so the default is what THIS process
+// may run on (its scheduling affinity, at most 16), and a launcher that knows the rank count narrows it further
+// (bi_set_param("host_threads", n); process-wide: the pool is per call, not per context).
+inline std::atomic<int>& host_threads_setting() {
+    static std::atomic<int> v{0};
+    return v;
+}
+inline int host_threads() {
+    const int forced = host_threads_setting().load();
+    if (forced > 0) return forced;
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::max(1u, std::thread::hardware_concurrency());
+    return std::min(n, 16);
+}
+
 template <class F>
 void parallel_for(int64_t n, int64_t grain, F body) {  // body(begin, end)
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int64_t want = std::min<int64_t>({(int64_t)hw, 16, (n + grain - 1) / grain});
+    const int64_t want = std::min<int64_t>((int64_t)host_threads(), (n + grain - 1) / grain);
     if (want <= 1) { body(0, n); return; }
     std::vector<std::thread> pool;
     const int64_t step = (n + want - 1) / want;

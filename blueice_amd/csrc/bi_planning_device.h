@@ -742,9 +742,8 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // ceil(blocks / CUs) blocks when all are resident at once (640 blocks of 4 strips on 256 CUs are 3 x 4 = 12
         // units on half of the CUs, 512 blocks of 5 strips are 10 on all of them: 11.6 instead of 13.8 ms for the 10^6-
         // point scan of C2), the mean load plus a quarter of a block generation's length when they run in several
-        // rounds (measured: tools/tune_scan_sorted.py); one block per CU leaves a SIMD a single wave and nothing to
-        // cover its latencies with (+25 %).  Among the splits within 3 % of the best the coarsest is taken (fewer
-        // partial slots for the finish to add up).
+        // rounds (measured: tools/tune_scan_sorted.py).  Among the splits within 3 % of the best the coarsest is taken
+        // (fewer partial slots for the finish to add up).
         auto waves_per_group = [&](int64_t strips, int resident, int64_t slot_cap, bool pipe_bound = false) -> int64_t {
             const int64_t capacity = (int64_t)c->prop.multiProcessorCount * std::max(1, resident);
             const int64_t b_max = std::max<int64_t>(1, std::min<int64_t>(strips / 4, slot_cap / 4));
@@ -767,7 +766,10 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                     const int64_t blocks = b * n_groups;
                     if (blocks <= capacity) {
                         const int64_t per_cu = (blocks + n_cu - 1) / n_cu;
-                        return (double)(per_cu * per_wave) * ((per_cu == 1 && resident > 1) ? 1.25 : 1.0);
+                        // fewer waves on a SIMD than it could hold: less to cover a wave's latencies with (measured on the
+                        // dense-data scan of C2: two waves per SIMD 131 ms, three 123 ms; one wave ~ +25 %)
+                        const double thin = per_cu >= resident ? 1.0 : (per_cu == 1 ? 1.25 : 1.07);
+                        return (double)(per_cu * per_wave) * thin;
                     }
                     return (double)blocks / (double)n_cu * (double)per_wave + 0.25 * (double)resident * (double)per_wave;
                 };

@@ -91,8 +91,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     // the number of groups is.
     const unsigned gx = (unsigned)a.nslots / 4, total = gx * (unsigned)a.n_groups;
     const unsigned per_xcd = (total + 7) / 8;
-    const unsigned linear = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || linear >= total) return;
+    unsigned linear = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (a.xcd_mode == 0) linear = blockIdx.x;                       // (tuning: plain launch order)
+    else if (a.xcd_mode == 2) linear = (((blockIdx.x >> 3) / gx) * 8 + (blockIdx.x & 7)) * gx + (blockIdx.x >> 3) % gx;
+    if (linear >= total) return;
     const int grp = (int)(linear / gx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = (int)(linear % gx) * 4 + wave;

@@ -20,6 +20,7 @@
 // No CPU fallback exists: without a HIP device bi_create fails.
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -611,7 +612,8 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
     } while (0)
             if (plan->by_count) {
                 sa.n_groups = (int)plan->n_groups;
-                const int64_t scan_blocks = (int64_t)(k.nbx / 4) * plan->n_groups;
+                sa.xcd_mode = (int)c->scan_xcd;
+                const int64_t scan_blocks = (int64_t)(k.nbx / 4) * (c->scan_xcd == 2 ? (plan->n_groups + 7) / 8 * 8 : plan->n_groups);
                 const dim3 sgrid((unsigned)((scan_blocks + 7) / 8 * 8));
                 if (kg == 1) BI_SORTED(1); else if (kg == 2) BI_SORTED(2); else if (kg == 4) BI_SORTED(4); else BI_SORTED(8);
             } else if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);

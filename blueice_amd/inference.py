@@ -263,6 +263,18 @@ def _first_crossing(tfun, a, b, xtol=1e-11, points_per_round=16, max_rounds=12):
     return float(lo - tl * (hi - lo) / (th - tl))
 
 
+# options of bestfit_scipy that the reference's callers pass through `**kwargs` of the scan / interval drivers
+# (blueice/inference.py:332-443 forward them to the fit routine) -- they are NOT fixed parameters
+_FIT_ROUTINE_OPTIONS = ('minimize_kwargs', 'rates_in_log_space', 'pass_bounds_to_minimizer', 'use_gradient', 'batch_stencil',
+                        'guess')
+
+
+def _takes_fit_routine_options(kwargs):
+    """True when the caller handed options of the fit routine along with the fixed parameters: those calls keep the
+    reference's sequential loop over `bestfit_scipy(lf, **kwargs)`, which understands them."""
+    return any(k in kwargs for k in _FIT_ROUTINE_OPTIONS)
+
+
 def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper', bestfit_routine=None, fit_options=None,
                            t_ppf=None, **kwargs):
     """Profile-likelihood interval on parameter `target` (reference: blueice/inference.py:332-389).
@@ -277,7 +289,9 @@ def one_parameter_interval(lf, target, bound, confidence_level=0.9, kind='upper'
     fit_options = dict(fit_options or {})
     if target is None:
         target = lf.source_list[-1] + '_rate_multiplier'
-    batched = bestfit_routine is None and supports_batched_fits(lf)
+    # (options of bestfit_scipy among the kwargs -- minimize_kwargs, pass_bounds_to_minimizer, ... -- go where the
+    # reference sends them: to the fit routine, point by point)
+    batched = bestfit_routine is None and supports_batched_fits(lf) and not _takes_fit_routine_options(kwargs)
     fit = bestfit_routine or bestfit_scipy
     if batched:
         try:
@@ -350,10 +364,11 @@ def likelihood_ratio_scan(lf, *space, bestfit_routine=None, fit_options=None, **
                [p for p in lf.shape_parameters if p not in kwargs]
     floating = [p for p in floating if p not in names]
     pts = {n: g.ravel() for n, g in zip(names, grids)}
+    routine_options = _takes_fit_routine_options(kwargs)
     if not floating and hasattr(lf, 'eval_points'):
-        pts.update({k: v for k, v in kwargs.items()})
+        pts.update({k: v for k, v in kwargs.items() if k not in _FIT_ROUTINE_OPTIONS})
         ll = np.asarray(lf.eval_points(pts)).reshape(grids[0].shape)
-    elif floating and bestfit_routine is None and supports_batched_fits(lf):
+    elif floating and bestfit_routine is None and supports_batched_fits(lf) and not routine_options:
         ll = bestfit_batched(lf, points=pts, **(fit_options or {}), **kwargs)[1].reshape(grids[0].shape)
     else:
         fit = bestfit_routine or bestfit_scipy

@@ -501,7 +501,10 @@ class DeviceLogLikelihood(LogLikelihoodBase):
         P = max((len(c) for c in cols), default=1)
         cols = [c if len(c) == P else np.broadcast_to(c, (P,)) for c in cols]
         known = self.__dict__.get('_batch_names')          # (validated names and defaults: rebuilt when the parameters change)
-        key = (tuple(self.shape_parameters), tuple(self.source_name_list))
+        # (the defaults are base values: part of the key, so that a changed base value is seen -- the scalar call reads
+        # them afresh every time, and batched and scalar evaluations of one point must agree)
+        key = (tuple(self.shape_parameters), tuple(self.source_name_list),
+               tuple((self.pdf_base_config.get(n), sp[2]) for n, sp in self.shape_parameters.items()))
         if known is None or known[0] != key:
             known = self._batch_names = (key, set(), self._kwargs_to_settings()[1])
         for k in names:

@@ -41,6 +41,17 @@ class BatchObjective:
         self.datasets = None if datasets is None else np.asarray(datasets, dtype=np.int64)   # [P]: the dataset of every problem
         self.kinks = None                                     # per floating parameter: where differences must not straddle
         self.analytic = bool(getattr(lf, 'supports_gradient', False)) and hasattr(lf, 'values_and_gradients')
+        # does the likelihood take `bb_assert` (a trial point at which a Beeston-Barlow assertion of the reference would fire
+        # is a point to avoid, not an exception)?  Decided once, from the signature: a TypeError raised INSIDE a call is an error
+        self.bb_assert = {}
+        if self.analytic:
+            import inspect
+            try:
+                params = inspect.signature(lf.values_and_gradients).parameters
+                if 'bb_assert' in params or any(p.kind == p.VAR_KEYWORD for p in params.values()):
+                    self.bb_assert = {'bb_assert': 'nan'}
+            except (TypeError, ValueError):
+                pass
         self.calls = self.evaluations = 0
 
     def _points_of(self, x, rows):
@@ -55,10 +66,7 @@ class BatchObjective:
         more = {} if self.datasets is None else {'dataset': self.datasets[rows]}
         if self.analytic:
             self.evaluations += len(x)
-            try:       # (a trial point at which a Beeston-Barlow assertion of the reference would fire is a point to avoid)
-                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, bb_assert='nan', **more)
-            except TypeError:
-                ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, **more)
+            ll, grads = self.lf.values_and_gradients(self._points_of(x, rows), livetime_days=self.livetime_days, **self.bb_assert, **more)
             g = np.stack([np.broadcast_to(grads[n], ll.shape) for n in self.names], axis=1)
             return -ll, -g
         # central differences, all 2F + 1 stencil points of all problems in one batched call

@@ -120,13 +120,20 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
     rank, world = _world(comm)
     P = len(z)
 
-    def agree(word):
+    FAILED = 1 << 30                     # a rank's own step raised: carried to the others as a bit, raised by all together
+
+    def agree(word, error=None):
         # every rank takes part in every collective before anybody raises: a rank that bailed out earlier would leave
-        # the others waiting in the gather
+        # the others waiting in the gather (ncclAllGather has no timeout)
         if world > 1:
             word = int(comm.all_reduce(np.array([word], dtype=np.int64), 'bor')[0])
+        if error is not None:
+            raise error
+        if word & FAILED:
+            raise DeviceError("another rank's share of the scan failed: scan discarded")
         if word & ST_INTERNAL:
             raise DeviceError("a rank's launch gave up waiting for a partial sum (BI_ST_INTERNAL): scan discarded")
+        return word
 
     def status_of(plan):
         try:                                 # nobody reads a plan's status array on these routes: look at its OR
@@ -134,23 +141,45 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
         except DeviceError:
             return ST_INTERNAL
 
+    plan = None
     if world > 1 and ctx.bb_source < 0 and P > 0:
+        # The device planner may refuse the batch (infinite rate scales of a source that may go negative are answered on
+        # the host: BI_ERR_INVALID) or fail on one rank only (memory): the ranks agree before anybody takes a route, and
+        # if any of them has no plan ALL take the host-dealt route below, which answers such points
+        try:
+            plan = ctx.plan_share(z, rate_scale, dataset, rank, world)
+            word = 0
+        except DeviceError:
+            plan, word = None, FAILED
+        if int(comm.all_reduce(np.array([word], dtype=np.int64), 'bor')[0]) & FAILED:
+            if plan is not None:
+                plan.close()
+            plan = None
+    if plan is not None:
         stride = -(-P // world)
-        plan = ctx.plan_share(z, rate_scale, dataset, rank, world)
         send, recv, full = ctx.device_alloc(8 * stride), ctx.device_alloc(8 * stride * world), ctx.device_alloc(8 * P)
         send.from_host(np.zeros(stride))
         on_device = hasattr(comm, 'all_gather_device')
 
         def run():
-            plan.run(send.ptr)
-            word = status_of(plan)
+            word, error = 0, None
+            try:
+                plan.run(send.ptr)
+                word = status_of(plan)
+            except Exception as e:                   # (a HIP error, a stale plan ...: the others must not wait for this rank)
+                word, error = FAILED, e
             if on_device:
                 comm.all_gather_device(send.ptr, recv.ptr, stride)
             else:
                 recv.from_host(comm.all_gather(send.to_host(np.float64, stride)))
-            plan.unsort(recv.ptr, stride, full.ptr)
-            out = full.to_host(np.float64, P)
-            agree(word)
+            out = None
+            if error is None:
+                try:
+                    plan.unsort(recv.ptr, stride, full.ptr)
+                    out = full.to_host(np.float64, P)
+                except Exception as e:
+                    word, error = word | FAILED, e
+            agree(word, error)
             return out
 
         return run(), run
@@ -161,16 +190,19 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
     plan = ctx.plan(z[mine], rate_scale[mine], ds_mine) if len(mine) else None
 
     def run():
-        local, word = np.zeros(0), 0
+        local, word, error = np.zeros(len(mine)), 0, None
         if plan is not None:
-            plan.run()
-            local, st = plan.read()
-            word = int(np.bitwise_or.reduce(st)) if len(st) else 0
+            try:
+                plan.run()
+                local, st = plan.read()
+                word = int(np.bitwise_or.reduce(st)) if len(st) else 0
+            except Exception as e:
+                local, word, error = np.zeros(len(mine)), FAILED, e
         parts = gather_vector(local, [len(d) for d in deal], comm)
         out = np.empty(len(z))
         for idx, vals in zip(deal, parts):
             out[idx] = vals
-        agree(word)
+        agree(word & (FAILED | ST_INTERNAL), error)
         return out
 
     return run(), run

@@ -325,6 +325,12 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     which it is used (4; x2 for dense data), strip width (0 = by the data), waves per CU the
  *                     strips of all cells are spread over (0 = sized by the kernel's occupancy so that the blocks run in
  *                     full rounds, default)
+ *   host_threads      host threads the planner may start per call (PROCESS-wide): 0 = what the process may run on (its
+ *                     scheduling affinity), at most 16 (default); a launcher of N ranks per node sets its share, so that the ranks
+ *                     together never run more planner threads than the node has cores for them
+ *   scan_xcd          k_scan_sorted (rows in count order): how the (cell, block) pairs of a launch are dealt to the 8 XCDs, whose
+ *                     L2s each keep the coefficient lists of the cells they work on: 1 contiguous, equal ranges of the cell-major
+ *                     list (default), 2 cell g on XCD g mod 8, 0 plain launch order (every cell on every XCD)
  *   bb_exact          single-point Beeston-Barlow evaluations: N(z) = sum_b n_model[i, b] in numpy's own summation order (one more
  *                     pass over the 2^d rows of MC counts), so that the root formula sees the reference's bits: 0 never, 1
  *                     always, 2 when some bin can have U_b == 0 at the point (default)

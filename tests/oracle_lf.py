@@ -21,6 +21,10 @@ class OracleLikelihood:
         self.supports_gradient = analytic
         self.n_calls = self.n_batches = 0
 
+    def make_objective(self, **kw):
+        from blueice_amd import inference
+        return inference.make_objective(self, **kw)
+
     def get_bounds(self, name):
         if name in self.shape_parameters:
             zs = list(self.shape_parameters[name][0])
@@ -28,6 +32,10 @@ class OracleLikelihood:
         return 0, float('inf')
 
     def _arrays(self, points):
+        for k in points:                 # as DeviceLogLikelihood._batch_terms: unknown names are errors, not ignored
+            if k not in self.shape_parameters and not (k.endswith('_rate_multiplier') and k[:-16] in self.source_name_list):
+                from blueice_amd.exceptions import InvalidParameter
+                raise InvalidParameter("%s is not a known shape or rate parameter!" % k)
         P = max([np.size(v) for v in points.values()] + [1])
         z = np.stack([np.broadcast_to(np.asarray(points.get(n, self.pdf_base_config[n]), dtype=float), (P,))
                       for n in self.shape_parameters], axis=1) if self.shape_parameters else np.zeros((P, 0))

@@ -48,6 +48,26 @@ def test_devices_option_and_launcher_environment():
     assert res.returncode == 0 and _json_line(res.stdout)['n_gpus'] == 1
 
 
+def test_host_threads_are_shared_among_the_ranks():
+    """Eight ranks on a node must not each start a full set of upload / planner threads: a rank's share is the cores this
+    process may run on divided by the number of ranks ("Next round" 3)."""
+    cores = len(os.sched_getaffinity(0))
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--dry'], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_line(res.stdout)
+    assert line['n_gpus'] == 8 and len(line['legs']['C4']['ranks']) == 8
+    assert line['config']['host_threads_per_rank'] == max(1, cores // 8)
+    assert line['config']['host_threads_per_rank'] * 8 <= max(8, cores)
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.host_thread_share(1) == cores and bench.host_thread_share(10 ** 6) == 1
+    # the strong-scaling legs print what N ranks can reach from one run's own split of a step
+    pc = bench.predicted_ceiling(10 ** 6, step_ms=12.0, kernel_ms=9.0, world=1)
+    assert pc['fixed_ms_per_rank'] == 3.0 and abs(pc['evals_per_s']['8'] - 1e6 / ((3.0 + 9.0 / 8) * 1e-3)) < 1e-3
+    pc2 = bench.predicted_ceiling(10 ** 6, step_ms=3.0 + 9.0 / 4, kernel_ms=9.0 / 4, world=4)      # the same leg measured at N = 4
+    assert abs(pc2['evals_per_s']['8'] - pc['evals_per_s']['8']) < 1e-3 and abs(pc2['evals_per_s']['1'] - pc['evals_per_s']['1']) < 1e-3
+
+
 def test_a_failing_rank_fails_the_command():
     """Without a GPU every rank dies in DeviceContext(): the command must end non-zero and say why -- never print a line."""
     try:
@@ -80,3 +100,9 @@ def test_two_ranks_on_one_gpu_end_to_end():
     assert legs['C3']['datasets'] == 10000
     for leg in ('C4', 'C4-dense', 'C5-BB-scan'):
         assert legs[leg]['sample_max_rel_diff_vs_single_point_kernel'] <= 1e-11
+    assert line['outputs_checked'] is True
+    assert line['config']['host_threads_per_rank'] == max(1, len(os.sched_getaffinity(0)) // 2)
+    for leg in ('C4', 'C4-dense', 'C3', 'C5-BB-scan'):
+        pc = legs[leg]['predicted_ceiling']
+        assert pc['measured_at_n'] == 2 and pc['evals_per_s']['8'] >= pc['evals_per_s']['1'] > 0
+    assert legs['C3']['roofline']['bound'] == 'hbm' and legs['C3']['roofline']['launches_per_call'] >= 1

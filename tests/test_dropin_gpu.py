@@ -333,6 +333,9 @@ def test_intervals_and_scans_match_reference(ns):
     lo, hi = lf.one_parameter_interval('s0_rate_multiplier', bound=(2., 20.), kind='central', confidence_level=0.68,
                                        s1_rate_multiplier=0.)
     np.testing.assert_allclose([lo, hi], f['central_s0_68'], rtol=2e-3)
+    # options of the fit routine travel through the driver's kwargs, as in the reference
+    up2 = lf.one_parameter_interval('s1_rate_multiplier', bound=50., kind='upper', confidence_level=0.9, pass_bounds_to_minimizer=True)
+    assert abs(up2 - float(f['upper_s1_90'])) < 5e-3 * float(f['upper_s1_90'])
     # nothing left to fit -> the whole grid in one device call
     s0 = np.linspace(5., 10., 11)
     sh = np.linspace(-0.5, 0.9, 8)

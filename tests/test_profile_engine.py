@@ -132,6 +132,29 @@ def test_interval_and_profiled_scan_drivers_on_the_engine(d2):
     np.testing.assert_allclose(scan, want_scan.max() - want_scan, atol=2e-6)
 
 
+def test_fit_routine_options_pass_through_the_drivers(d2):
+    """The reference's drivers forward their **kwargs to the fit routine (blueice/inference.py:332-443), so callers hand
+    bestfit_scipy's options there: those calls must reach bestfit_scipy -- not the engine's list of fixed parameters, where a
+    strict likelihood raises InvalidParameter."""
+    from blueice_amd import inference
+    from blueice_amd.exceptions import InvalidParameter
+    lf = OracleLikelihood(d2['model'], d2['counts'], ['shift', 'stretch'], analytic=False)
+    with pytest.raises(InvalidParameter):
+        lf(pass_bounds_to_minimizer=True)                                  # the stand-in is as strict as the device class
+    fixed = dict(stretch=1.0, shift=0.1, s2_rate_multiplier=1.0)
+    plain = inference.one_parameter_interval(lf, 's0_rate_multiplier', bound=6.0, kind='upper', confidence_level=0.9, **fixed)
+    with_opts = inference.one_parameter_interval(lf, 's0_rate_multiplier', bound=6.0, kind='upper', confidence_level=0.9,
+                                                 pass_bounds_to_minimizer=True, minimize_kwargs=dict(tol=1e-9), **fixed)
+    assert abs(with_opts - plain) <= 2e-3 * plain
+    grid = np.linspace(0.6, 1.6, 5)
+    a = inference.likelihood_ratio_scan(lf, ('s0_rate_multiplier', grid), **fixed)
+    b = inference.likelihood_ratio_scan(lf, ('s0_rate_multiplier', grid), pass_bounds_to_minimizer=True, **fixed)
+    np.testing.assert_allclose(a, b, atol=2e-3)
+    # nothing left to fit: the options are dropped, the grid is one batched call
+    c = inference.likelihood_ratio_scan(lf, ('s0_rate_multiplier', grid), s1_rate_multiplier=1.0, rates_in_log_space=True, **fixed)
+    assert c.shape == (5,) and c.min() == 0
+
+
 def test_stencil_batching_gives_scipy_its_own_differences(d2):
     """bestfit_scipy with the finite-difference stencil evaluated as one batch: same minimiser, same differences, a
     fraction of the calls -- the fit it returns is the fit of the scalar stream."""

@@ -97,7 +97,7 @@ def _worker(kind, rank, world, port, rdzv, q):
         comm.close()
 
 
-def _run_ranks(target, kind, world, tmp_path):
+def _run_ranks(target, kind, world, tmp_path, timeout=900):
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -106,7 +106,7 @@ def _run_ranks(target, kind, world, tmp_path):
     procs = [ctx.Process(target=target, args=(kind, r, world, port, rdzv, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=900) for _ in procs]
+    got = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -313,3 +313,97 @@ def test_rccl_init_failures_are_agreed_on(kind, tmp_path):
         assert all(g[1] == 'timeout' for g in got), got
         assert [g[3] for g in got] == [0.0, 1.0]
         assert all(2.5 < g[4] < 12 for g in got), got
+
+
+# ---- sharded_scan_device: a failure on ONE rank is agreed on by all -------------------------------------
+class _ScriptedPlan:
+    def __init__(self, values, fail_run):
+        self.values, self.fail_run = values, fail_run
+
+    def run(self, ptr=None):
+        from blueice_amd.exceptions import DeviceError
+        if self.fail_run:
+            raise DeviceError('scripted HIP error on this rank')
+        if ptr is not None:
+            ptr.data[:len(self.values)] = self.values
+
+    def status(self):
+        return 0
+
+    def read(self):
+        return self.values, np.zeros(len(self.values), np.int32)
+
+    def unsort(self, recv, stride, full):
+        full.data[:] = np.concatenate([recv.data[r * stride:(r + 1) * stride] for r in range(len(recv.data) // stride)])[:len(full.data)]
+
+    def close(self):
+        pass
+
+
+class _ScriptedBuf:
+    def __init__(self, n):
+        self.data = np.zeros(n // 8)
+        self.ptr = self
+
+    def from_host(self, a):
+        a = np.ravel(a)
+        self.data[:len(a)] = a
+
+    def to_host(self, dtype, n):
+        return self.data[:n].copy()
+
+
+class _ScriptedCtx:
+    """The calls sharded_scan_device makes on a DeviceContext; the 'evaluation' of point i is its index."""
+    bb_source = -1
+
+    def __init__(self, anchor_z, rank, mode):
+        self.anchor_z, self.rank, self.mode = anchor_z, rank, mode
+
+    def device_alloc(self, n):
+        return _ScriptedBuf(n)
+
+    def plan_share(self, z, r, dataset, rank, world):
+        from blueice_amd.exceptions import DeviceError
+        if self.mode == 'plan_refused_everywhere' or (self.mode == 'plan_fails_on_one' and rank == 1):
+            raise DeviceError('scripted: the device planner refuses this batch')
+        n = len(z)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        return _ScriptedPlan(np.arange(lo, hi, dtype=float), self.mode == 'run_fails_on_one' and rank == 1)
+
+    def plan(self, z, r, dataset=None):
+        return _ScriptedPlan(z[:, 0].copy(), False)                        # host-dealt route: z carries the point's index
+
+
+def _scan_failure_worker(kind, rank, world, port, rdzv, q):
+    sys.path.insert(0, ROOT)
+    from blueice_amd.exceptions import DeviceError
+    from blueice_amd.sharding import sharded_scan_device
+    comm = _comm('socket', rank, world, port, rdzv)
+    try:
+        grid = [np.array([0.0, 1000.0])]
+        z = np.arange(40, dtype=float)[:, None]
+        try:
+            out, _ = sharded_scan_device(_ScriptedCtx(grid, rank, kind), z, np.ones((40, 1)), comm)
+            q.put((rank, 'ok', out.tolist()))
+        except DeviceError as e:
+            q.put((rank, 'raised', str(e)))
+        except BaseException as e:                        # (a bug in the test's stand-ins: report it instead of leaving the parent waiting)
+            q.put((rank, 'crashed', repr(e)))
+            raise
+        comm.barrier()                                    # the communicator is still in step on every rank
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize('kind', ['all_fine', 'plan_refused_everywhere', 'plan_fails_on_one', 'run_fails_on_one'])
+def test_scan_failures_on_one_rank_are_agreed_on(kind, tmp_path):
+    got = sorted(_run_ranks(_scan_failure_worker, kind, 2, tmp_path, timeout=120))
+    assert [g[0] for g in got] == [0, 1]
+    if kind == 'run_fails_on_one':
+        # nobody is left waiting in the gather: both ranks raise, the failing one its own error
+        assert [g[1] for g in got] == ['raised', 'raised'], got
+        assert 'another rank' in got[0][2] and 'scripted HIP error' in got[1][2]
+    else:
+        # no plan on some rank (refused for all, or failed on one): ALL ranks take the host-dealt route and answer
+        assert all(g[1] == 'ok' and g[2] == list(map(float, range(40))) for g in got), got
