@@ -360,7 +360,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
         for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
 
         int k0 = 0;
-        if constexpr (NT && G == 1 && MODE != 2) {
+        if constexpr (NT && G == 1 && MODE != 2 && MODE != 3) {
             // rows meant to stay in the Infinity Cache between calls (repeated evaluations in one cell): default policy
             k0 = a.n_keep;
 #pragma unroll 8
@@ -371,7 +371,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                 acc[0][1] = fma(c, v.y, acc[0][1]);
             }
         }
-        if constexpr (MODE == 2) if (a.nan_S > 0) {
+        if constexpr (MODE == 2 || MODE == 3) if (a.nan_S > 0) {
             // np.nansum over sources (likelihood.py:686): a source whose morphed density times its rate is nan at an
             // event contributes nothing there.  Per source the corners are summed first (the morph), then the test.
             const int S = a.nan_S, nc = a.n0 / S;
@@ -389,10 +389,19 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                         part[g][1] = fma(cf, v.y, part[g][1]);
                     }
                 }
+                if constexpr (MODE == 3) {        // gradient: a source dropped from the value is dropped from its slopes too
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (part[g][0] == part[g][0]) acc[g][0] += part[g][0];
-                    if (part[g][1] == part[g][1]) acc[g][1] += part[g][1];
+                    for (int j = 0; j < 2; ++j)
+                        if (part[0][j] == part[0][j]) {
+#pragma unroll
+                            for (int g = 0; g < G; ++g) acc[g][j] += part[g][j];
+                        }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (part[g][0] == part[g][0]) acc[g][0] += part[g][0];
+                        if (part[g][1] == part[g][1]) acc[g][1] += part[g][1];
+                    }
                 }
             }
             k0 = a.n0;
@@ -408,7 +417,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
             }
         }
         double2 nv;
-        if constexpr (MODE == 2) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
+        if constexpr (MODE == 2 || MODE == 3) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
         if (tab_pending) {
             if (threadIdx.x < 128) s_log_table[threadIdx.x] = tab;
             __syncthreads();
@@ -434,6 +443,23 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                 for (int j = 0; j < 2; ++j) {
                     const double lg = fast ? bin_log_fast(acc[g][j]) : bin_log(acc[g][j]);   // (wave-uniform choice)
                     if (bin0 + j < a.B) sum[g] += lg;
+                }
+            }
+        } else if constexpr (MODE == 3) {
+            // value + gradient of the extended unbinned likelihood (blueice/likelihood.py:678-690): column 0 is the event's
+            // density lambda_e = sum_s mu_s p_s(x_e), columns 1.. its derivatives; d log(lambda) = d lambda / lambda.  An event
+            // that takes the outlier likelihood (lambda not > 0) is a constant: no slope.  -sum_s d mu_s is added by the host.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double lam = acc[0][j];
+                const bool clamped = a.outlier != 0.0 && !(lam > 0.0);
+                if (clamped) lam = a.outlier;
+                const double lg = bin_log(lam);
+                if (bin0 + j < a.B) {
+                    sum[0] += lg;
+                    const double inv = clamped ? 0.0 : 1.0 / lam;
+#pragma unroll
+                    for (int g = 1; g < G; ++g) sum[g] += acc[g][j] * inv;
                 }
             }
         } else if constexpr (MODE == 1) {
@@ -520,6 +546,7 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
 }
 
 // MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
+// MODE 3: as MODE 1 (value + gradient columns of ONE point) for the extended unbinned likelihood.
 // MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
 // gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
 // chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.

@@ -38,7 +38,10 @@ void launch_morph_grad(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool nt
     EventScope ev(c);
 #define BI_GRAD_CASE(GG)                                                                                          \
     case GG:                                                                                                      \
-        if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 1>), grid, dim3(kThreads), 0, c->stream, a); \
+        if (c->unbinned) {                                                                                        \
+            if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 3>), grid, dim3(kThreads), 0, c->stream, a); \
+            else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 3>), grid, dim3(kThreads), 0, c->stream, a); \
+        } else if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 1>), grid, dim3(kThreads), 0, c->stream, a); \
         else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 1>), grid, dim3(kThreads), 0, c->stream, a);   \
         break;
     switch (G) {

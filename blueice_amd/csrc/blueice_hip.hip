@@ -840,7 +840,6 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
                  double* grad, int32_t* status) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (c->unbinned) return fail(c, BI_ERR_INVALID, "bi_eval_grad is implemented for binned likelihoods only");
     if (P < 0 || (P > 0 && (!ll || !grad))) return fail(c, BI_ERR_INVALID, "bad P / output pointers");
     if (c->d > 0 && P > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
     if (c->bb_source >= 0) {
@@ -856,14 +855,15 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     const int nc = 1 << de, NS = nc * S;
     bool any_neg = false;
     for (int q = 0; q < S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !any_neg;
-    if (!sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
+    const bool unb = c->unbinned;       // extended unbinned likelihood: the rows are pdf values at the events, no counts
+    const bool sparse = !unb && c->sparse && c->compact_ready && c->ps_nonneg && !any_neg;
+    if (!unb && !sparse && !c->dense_counts) return fail(c, BI_ERR_STATE, "dataset counts are not resident in dense form");
     const int64_t n_rows = c->A * S;
     const double ninf = -std::numeric_limits<double>::infinity();
     const double qnan = std::numeric_limits<double>::quiet_NaN();
 
     // large batches: the descriptors are built on the device (k_grad_fill), one work item per point
-    if (c->device_plan_min > 0 && P >= c->device_plan_min && de <= 6 && P <= ((int64_t)1 << 26))
+    if (!unb && c->device_plan_min > 0 && P >= c->device_plan_min && de <= 6 && P <= ((int64_t)1 << 26))
         return eval_grad_device(c, P, z, rate_scale, dataset, sparse, G, ll, grad, status);
 
     // Host half, per point and independent: phase 1 decides which points are evaluated at all (the reference's early
@@ -880,8 +880,8 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
         for (int64_t p = lo; p < hi; ++p) {
             ll[p] = ninf;
             for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = qnan;
-            const int64_t ds = dataset ? dataset[p] : 0;
-            if (ds < 0 || ds >= c->T) { st_of[(size_t)p] = BI_ST_BAD_DATASET; continue; }
+            const int64_t ds = (dataset && !unb) ? dataset[p] : 0;
+            if (!unb && (ds < 0 || ds >= c->T)) { st_of[(size_t)p] = BI_ST_BAD_DATASET; continue; }
             if (!point_geometry(c, z ? z + p * d : nullptr, g)) { st_of[(size_t)p] = BI_ST_OUT_OF_BOUNDS; continue; }
             interp_mus(c, g, r.data());
             const double* rs = rate_scale ? rate_scale + p * S : ones.data();
@@ -904,7 +904,7 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
         std::vector<double> mus((size_t)S), r((size_t)S), dmus((size_t)S * std::max(d, 1)), dw((size_t)nc * std::max(de, 1));
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t p = live[(size_t)i];
-            const int64_t ds = dataset ? dataset[p] : 0;
+            const int64_t ds = (dataset && !unb) ? dataset[p] : 0;
             point_geometry(c, z ? z + p * d : nullptr, g);
             interp_mus(c, g, mus.data());
             const double* rs = rate_scale ? rate_scale + p * S : ones.data();
@@ -948,9 +948,21 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
                         for (int q = 0; q < W; ++q) slot_lg[po + q] += col[q] * tz;
                     }
                 }
-            slot_lg[po] += c->h_lgsum[(size_t)ds];
+            if (unb) {
+                // -sum_s mu_s and its derivatives (likelihood.py:690): what the kernel's sums over the events are reduced by
+                double rsum = 0.0;
+                for (int s = 0; s < S; ++s) rsum += r[(size_t)s];
+                slot_lg[po] = rsum;
+                for (int ii = 0; ii < de; ++ii) {
+                    double v = 0.0;
+                    for (int s = 0; s < S; ++s) v += dmus[(size_t)ii * S + s] * rs[s];
+                    slot_lg[po + 1 + c->eff_axes[(size_t)ii]] = v;
+                }
+                for (int s = 0; s < S; ++s) slot_lg[po + 1 + d + s] = mus[(size_t)s];
+            } else
+                slot_lg[po] += c->h_lgsum[(size_t)ds];
             for (int q = 0; q < W; ++q) perm[po + q] = i * W + q;
-            cnt_off[(size_t)i] = sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp;
+            cnt_off[(size_t)i] = unb ? 0 : (sparse ? c->h_cnt_off[(size_t)ds] : ds * c->Bp);
             tiles[(size_t)i] = (int32_t)(row_stride / kTile);
         }
     });
@@ -979,6 +991,9 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     a.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
     a.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
     a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = max_tiles; a.chunks = (int)c->tile_chunks;
+    a.outlier = c->outlier;
+    a.nan_S = (unb && !c->ps_finite) ? c->S : 0;
+    if (unb) a.counts = (const double*)c->ps.p;        // (never read in this mode: any valid device address)
     const bool nt = !sparse && (c->nt_loads == 1 || (c->nt_loads == 2 && n_items == 1));
     for (int64_t i0 = 0; i0 < n_items; i0 += 65535) {
         const int64_t ni = std::min<int64_t>(65535, n_items - i0);
@@ -1004,7 +1019,7 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     for (int64_t i = 0; i < n_items; ++i) {
         const int64_t p = live[(size_t)i];
         ll[p] = h_out[(size_t)i * W];
-        for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = h_out[(size_t)i * W + 1 + j];
+        for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = (unb && !std::isfinite(ll[p])) ? qnan : h_out[(size_t)i * W + 1 + j];
     }
     return BI_OK;
 }

@@ -352,7 +352,6 @@ class DeviceLogLikelihood(LogLikelihoodBase):
     evaluation = host bookkeeping + one fused device call."""
 
     model_statistical_uncertainty_handling = None
-    supports_gradient = False          # bestfit_scipy(use_gradient=True) asks; only plain binned likelihoods say yes
 
     def __init__(self, pdf_base_config, likelihood_config=None, **kwargs):
         super().__init__(pdf_base_config, likelihood_config, **kwargs)
@@ -573,6 +572,107 @@ class DeviceLogLikelihood(LogLikelihoodBase):
         out[(st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0] = -np.inf
         return out
 
+    @staticmethod
+    def _prior_slope(log_prior, x):
+        if log_prior is None:
+            return 0.0
+        h = 1e-6 * max(1.0, abs(x))
+        return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
+
+    @property
+    def supports_gradient(self):
+        """bi_eval_grad covers binned likelihoods, with and without Beeston-Barlow (there the chain rule runs through the
+        per-bin root of likelihood.py:693-712), and the extended unbinned likelihood (d log lambda_e = d lambda_e / lambda_e,
+        events on the outlier clamp contribute no slope; likelihood.py:678-690), up to 1 + d + S = 16 gradient columns
+        (d <= 7 with Beeston-Barlow)."""
+        n = 1 + len(self.shape_parameters) + len(self.source_name_list)
+        if self.model_statistical_uncertainty_handling is not None and len(self.shape_parameters) > 7:
+            return False
+        return n <= 16
+
+    @_needs_data
+    def value_and_gradient(self, livetime_days=None, **kwargs):
+        """-> (ll, OrderedDict parameter name -> d ll / d parameter) for every registered rate and shape
+        parameter, from ONE pass over the templates (`bi_eval_grad`).  Inside a grid cell ll is smooth in
+        the shape parameters; exactly on an anchor the slope of the cell the point is assigned to is
+        returned.  Prior terms are differentiated numerically on the host (they are Python callables)."""
+        prior, zs, scale = self._host_terms(livetime_days, kwargs)
+        grads = OrderedDict()
+        names = ['%s_rate_multiplier' % s for s in self.rate_parameters] + list(self.shape_parameters)
+        if prior is None:
+            return -float('inf'), OrderedDict((n, float('nan')) for n in names)
+        multipliers, settings = self._kwargs_to_settings(**kwargs)
+        ll, gz, gs, st = self.ctx.eval_grad(zs if len(zs) else None, scale[None, :])
+        ll = self._interpret(float(ll[0]), int(st[0]))
+        gz, gs = gz[0], gs[0]
+        mult = np.array(multipliers, dtype=float)
+        with np.errstate(all='ignore'):
+            per_mult = np.where(mult != 0, scale / np.where(mult != 0, mult, 1.0), 0.0)
+        if np.any(mult == 0):          # d scale / d multiplier does not depend on the multiplier itself
+            _, _, unit = self._host_terms(livetime_days, {k: v for k, v in kwargs.items()
+                                                          if not k.endswith('_rate_multiplier')})
+            per_mult = np.where(mult != 0, per_mult, unit)
+        for s, name in enumerate(self.source_name_list):
+            if name in self.rate_parameters:
+                grads['%s_rate_multiplier' % name] = gs[s] * per_mult[s] + \
+                    self._prior_slope(self.rate_parameters[name], multipliers[s])
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            g = gz[i] + self._prior_slope(log_prior, settings[name])
+            # a shape parameter that doubles as the efficiency of some sources also scales their rates
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                if self.source_efficiency_names[s] == name and settings[name] != 0:
+                    g += gs[s] * scale[s] / settings[name]
+            grads[name] = g
+        return prior + ll, grads
+
+    @_needs_data
+    def values_and_gradients(self, points, livetime_days=None, dataset=None, bb_assert='raise'):
+        """The batched form of `value_and_gradient`: points = dict parameter name -> array [P] (as `eval_points`) ->
+        (ll [P], OrderedDict parameter name -> d ll / d parameter [P]) for every registered rate and shape parameter,
+        from ONE device call (`bi_eval_grad` over all P points).  Points outside the anchor box or with unphysical
+        rates give -inf and nan slopes.  What the batched profile-fit engine (blueice_amd.profile) advances P
+        minimisations with.  bb_assert: points at which one of the reference's Beeston-Barlow assertions would fire
+        (likelihood.py:649,655) raise AssertionError, as the scalar call does -- or, with 'nan', come back as nan so that a
+        line search can step around them."""
+        z, scale, prior, unit = self._batch_terms(points, livetime_days, want_unit=True)
+        P = len(z)
+        ll, gz, gs, st = self.ctx.eval_grad(z if z.shape[1] else None, scale, dataset)
+        if np.any(st & _capi.ST_INTERNAL):
+            raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
+        if np.any(st & _BB_FLAGS):
+            if bb_assert != 'nan':
+                raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
+            ll = np.where(st & _BB_FLAGS, np.nan, ll)
+        bad = (st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0
+        if np.any(st & _capi.ST_UNPHYSICAL) and self.config.get('unphysical_behaviour') == 'error':
+            raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(st & _capi.ST_UNPHYSICAL)), P))
+        out = ll + prior
+        out[bad] = -np.inf
+
+        def slope(log_prior, x):               # priors are Python callables: central differences, vectorised
+            if log_prior is None:
+                return 0.0
+            h = 1e-6 * np.maximum(1.0, np.abs(x))
+            return (_prior_of(log_prior, x + h) - _prior_of(log_prior, x - h)) / (2 * h)
+
+        grads = OrderedDict()
+        for s, name in enumerate(self.source_name_list):
+            if name in self.rate_parameters:
+                mult = np.broadcast_to(np.asarray(points.get(name + '_rate_multiplier', 1.0), dtype=float), (P,))
+                grads['%s_rate_multiplier' % name] = gs[:, s] * unit[:, s] + slope(self.rate_parameters[name], mult)
+        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
+            g = gz[:, i] + slope(log_prior, z[:, i])
+            # a shape parameter that doubles as the efficiency of some sources also scales their rates
+            for s in np.flatnonzero(self.source_apply_efficiency):
+                if self.source_efficiency_names[s] == name:
+                    with np.errstate(all='ignore'):
+                        g = g + np.where(z[:, i] != 0, gs[:, s] * scale[:, s] / np.where(z[:, i] != 0, z[:, i], 1.0), 0.0)
+            grads[name] = g
+        for g in grads.values():
+            g[bad] = np.nan
+        return out, grads
+
+    # -- toy-MC ---------------------------------------------------------------------------------
 
 
 class BinnedLogLikelihood(DeviceLogLikelihood):
@@ -669,105 +769,6 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         self.is_data_set = True
 
     # -- analytic gradient (one device pass; the reference differentiates numerically) ----------
-    @staticmethod
-    def _prior_slope(log_prior, x):
-        if log_prior is None:
-            return 0.0
-        h = 1e-6 * max(1.0, abs(x))
-        return (log_prior(x + h) - log_prior(x - h)) / (2 * h)
-
-    @property
-    def supports_gradient(self):
-        """bi_eval_grad covers binned likelihoods, with and without Beeston-Barlow (there the chain rule runs through the
-        per-bin root of likelihood.py:693-712), up to 1 + d + S = 16 gradient columns (d <= 7 with Beeston-Barlow)."""
-        n = 1 + len(self.shape_parameters) + len(self.source_name_list)
-        if self.model_statistical_uncertainty_handling is not None and len(self.shape_parameters) > 7:
-            return False
-        return n <= 16
-
-    @_needs_data
-    def value_and_gradient(self, livetime_days=None, **kwargs):
-        """-> (ll, OrderedDict parameter name -> d ll / d parameter) for every registered rate and shape
-        parameter, from ONE pass over the templates (`bi_eval_grad`).  Inside a grid cell ll is smooth in
-        the shape parameters; exactly on an anchor the slope of the cell the point is assigned to is
-        returned.  Prior terms are differentiated numerically on the host (they are Python callables)."""
-        prior, zs, scale = self._host_terms(livetime_days, kwargs)
-        grads = OrderedDict()
-        names = ['%s_rate_multiplier' % s for s in self.rate_parameters] + list(self.shape_parameters)
-        if prior is None:
-            return -float('inf'), OrderedDict((n, float('nan')) for n in names)
-        multipliers, settings = self._kwargs_to_settings(**kwargs)
-        ll, gz, gs, st = self.ctx.eval_grad(zs if len(zs) else None, scale[None, :])
-        ll = self._interpret(float(ll[0]), int(st[0]))
-        gz, gs = gz[0], gs[0]
-        mult = np.array(multipliers, dtype=float)
-        with np.errstate(all='ignore'):
-            per_mult = np.where(mult != 0, scale / np.where(mult != 0, mult, 1.0), 0.0)
-        if np.any(mult == 0):          # d scale / d multiplier does not depend on the multiplier itself
-            _, _, unit = self._host_terms(livetime_days, {k: v for k, v in kwargs.items()
-                                                          if not k.endswith('_rate_multiplier')})
-            per_mult = np.where(mult != 0, per_mult, unit)
-        for s, name in enumerate(self.source_name_list):
-            if name in self.rate_parameters:
-                grads['%s_rate_multiplier' % name] = gs[s] * per_mult[s] + \
-                    self._prior_slope(self.rate_parameters[name], multipliers[s])
-        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
-            g = gz[i] + self._prior_slope(log_prior, settings[name])
-            # a shape parameter that doubles as the efficiency of some sources also scales their rates
-            for s in np.flatnonzero(self.source_apply_efficiency):
-                if self.source_efficiency_names[s] == name and settings[name] != 0:
-                    g += gs[s] * scale[s] / settings[name]
-            grads[name] = g
-        return prior + ll, grads
-
-    @_needs_data
-    def values_and_gradients(self, points, livetime_days=None, dataset=None, bb_assert='raise'):
-        """The batched form of `value_and_gradient`: points = dict parameter name -> array [P] (as `eval_points`) ->
-        (ll [P], OrderedDict parameter name -> d ll / d parameter [P]) for every registered rate and shape parameter,
-        from ONE device call (`bi_eval_grad` over all P points).  Points outside the anchor box or with unphysical
-        rates give -inf and nan slopes.  What the batched profile-fit engine (blueice_amd.profile) advances P
-        minimisations with.  bb_assert: points at which one of the reference's Beeston-Barlow assertions would fire
-        (likelihood.py:649,655) raise AssertionError, as the scalar call does -- or, with 'nan', come back as nan so that a
-        line search can step around them."""
-        z, scale, prior, unit = self._batch_terms(points, livetime_days, want_unit=True)
-        P = len(z)
-        ll, gz, gs, st = self.ctx.eval_grad(z if z.shape[1] else None, scale, dataset)
-        if np.any(st & _capi.ST_INTERNAL):
-            raise DeviceError("the device gave up waiting for a partial sum (in-launch reduction): GPU fault")
-        if np.any(st & _BB_FLAGS):
-            if bb_assert != 'nan':
-                raise AssertionError("Beeston-Barlow assertion at %d points" % int(np.count_nonzero(st & _BB_FLAGS)))
-            ll = np.where(st & _BB_FLAGS, np.nan, ll)
-        bad = (st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0
-        if np.any(st & _capi.ST_UNPHYSICAL) and self.config.get('unphysical_behaviour') == 'error':
-            raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(st & _capi.ST_UNPHYSICAL)), P))
-        out = ll + prior
-        out[bad] = -np.inf
-
-        def slope(log_prior, x):               # priors are Python callables: central differences, vectorised
-            if log_prior is None:
-                return 0.0
-            h = 1e-6 * np.maximum(1.0, np.abs(x))
-            return (_prior_of(log_prior, x + h) - _prior_of(log_prior, x - h)) / (2 * h)
-
-        grads = OrderedDict()
-        for s, name in enumerate(self.source_name_list):
-            if name in self.rate_parameters:
-                mult = np.broadcast_to(np.asarray(points.get(name + '_rate_multiplier', 1.0), dtype=float), (P,))
-                grads['%s_rate_multiplier' % name] = gs[:, s] * unit[:, s] + slope(self.rate_parameters[name], mult)
-        for i, (name, (_, log_prior, _)) in enumerate(self.shape_parameters.items()):
-            g = gz[:, i] + slope(log_prior, z[:, i])
-            # a shape parameter that doubles as the efficiency of some sources also scales their rates
-            for s in np.flatnonzero(self.source_apply_efficiency):
-                if self.source_efficiency_names[s] == name:
-                    with np.errstate(all='ignore'):
-                        g = g + np.where(z[:, i] != 0, gs[:, s] * scale[:, s] / np.where(z[:, i] != 0, z[:, i], 1.0), 0.0)
-            grads[name] = g
-        for g in grads.values():
-            g[bad] = np.nan
-        return out, grads
-
-    # -- toy-MC ---------------------------------------------------------------------------------
     @_needs_data
     def eval_toys(self, livetime_days=None, t0=0, t1=None, **kwargs):
         """One parameter point against every uploaded dataset (see `set_binned_data`): ll [T]."""

@@ -210,7 +210,11 @@ int bi_eval_end(bi_ctx* ctx, double* out, int32_t* status);
  * mu_b = U_b + A_b p_b with p_b = r_i P_b / a_b, d mu = dU + p dA + A dp, dA from the root formula's partial derivatives;
  * in bins with U_b == 0 exactly the derivative of the reference's special case A = (n + a) / (1 + p_cal) is taken (on that
  * measure-zero set the two branches of the reference differ, so ll itself is not differentiable across it).  d <= 7 there.
- * status carries the Beeston-Barlow assertion bits of the value, as bi_eval does. */
+ * status carries the Beeston-Barlow assertion bits of the value, as bi_eval does.
+ * Extended unbinned likelihood (bi_set_unbinned / bi_score_events; blueice/likelihood.py:678-690): the same call returns
+ *   d ll = -sum_s d mu_s + sum_events (sum_s d(mu_s p_s(x_e))) / (sum_s mu_s p_s(x_e));
+ * an event that takes the outlier likelihood (density not > 0) is a constant and contributes no slope, a source whose term is
+ * nan at an event is dropped from value and slopes alike (numpy.nansum, likelihood.py:686); `dataset` is ignored. */
 int bi_eval_grad(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
                  double* grad, int32_t* status);
 

@@ -155,20 +155,29 @@ def test_reparam_as_the_reference_tests_it(ns):
 
 
 def test_gradient_fit_falls_back_without_gradient_support(ns):
-    """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (unbinned terms, a sum containing
-    one) must take the numerical route instead of failing mid-fit.  (Beeston-Barlow likelihoods have one since round 3.)"""
-    from blueice_amd import LogLikelihoodSum
+    """bestfit_scipy(use_gradient=True) on likelihoods that have no analytic gradient (a sum containing a term without one:
+    here an ancillary Python function) must take the numerical route instead of failing mid-fit.  Beeston-Barlow likelihoods
+    have one since round 3, unbinned likelihoods since round 4 -- and sums of those do too."""
+    from blueice_amd import LogAncillaryLikelihood, LogLikelihoodSum
     bb, _, _ = model_zoo.bb_two_shape(ns)
     plain, _, _ = model_zoo.c1_like(ns)
     unb, _, _ = model_zoo.unb_shape_2src(ns)
-    assert plain.supports_gradient and bb.supports_gradient and not unb.supports_gradient
-    total = LogLikelihoodSum([plain, unb])
-    assert not total.supports_gradient and LogLikelihoodSum([plain, bb]).supports_gradient
-    with pytest.raises(NotImplementedError):
-        total.value_and_gradient()
+    assert plain.supports_gradient and bb.supports_gradient and unb.supports_gradient
     fixed = dict(sigma=1.2, some_multiplier=0.8, shift=0.2)
+    total = LogLikelihoodSum([plain, unb])
+    assert total.supports_gradient and LogLikelihoodSum([plain, bb]).supports_gradient
+    v, g = total.value_and_gradient(**fixed)
+    assert same(v, total(**fixed), 1e-12) and all(np.isfinite(list(g.values())))
     a = total.bestfit_scipy(use_gradient=True, **fixed)
     b = total.bestfit_scipy(**fixed)
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(b[1]) or a[1] > b[1]
+    anc = LogAncillaryLikelihood(lambda values: -0.5 * (values['shift'] / 0.3) ** 2, ['shift'], config=dict(shift=0.0))
+    mixed = LogLikelihoodSum([plain, anc])
+    assert not mixed.supports_gradient
+    with pytest.raises(NotImplementedError):
+        mixed.value_and_gradient()
+    a = mixed.bestfit_scipy(use_gradient=True)
+    b = mixed.bestfit_scipy()
     assert same(a[1], b[1], 1e-9)
     # a sum with a Beeston-Barlow term: the analytic route and the differencing route reach the same maximum
     both = LogLikelihoodSum([plain, bb])
