@@ -52,6 +52,9 @@ struct bi_plan {
     int share_world = 1;          // come out in sorted order, out[0 .. share_hi - share_lo); sorted_idx [P] maps sorted positions
     int64_t share_lo = 0, share_hi = 0, n_valid = 0;   // back to the caller's point indices
     DevBuf sorted_idx;
+    DevBuf keep_z, keep_rs;       // gradient batches on the matrix cores: the points' z / rate_scale stay on the device for the finish kernel
+    int64_t max_group_items = 0;  // ... the largest number of work items a (cell, dataset) group holds
+    int max_item_tiles = 0;       // ... and the tiles of the longest rows
     bool device_planned = false;  // built by plan_points_device: rejected points are found through the status array
     bool no_reuse = false;     // no anchor model is touched by two items of the plan
     bool sparse = false;       // rows / counts refer to the compacted (non-empty-bin) copies
@@ -141,6 +144,10 @@ struct bi_ctx {
     int64_t n_valid_launches = 0;                // how often the validity pass of a split scan ran
     int64_t n_scan_launches = 0;                 // how often the matrix-core scan kernel ran (observability)
     int64_t last_scan_nslots = 0, last_scan_resident = 0, last_valid_nslots = 0;   // what the planner chose last (read-only parameters)
+    int64_t grad_mfma = 1;                       // bi_eval_grad: large single-dataset batches of plain binned likelihoods on the matrix cores (k_grad_mfma)
+    int64_t grad_mfma_min = 2048;                // ... from this many points on (below, the planning of the batch costs more than the kernel saves)
+    int64_t grad_slices = 0;                     // ... slices a cell's 16-bin blocks are split into (0 = by the batch)
+    int64_t n_grad_mfma_launches = 0;
     int64_t scan_xcd = 1;                        // k_scan_sorted: how the (group, block) pairs are dealt to the 8 XCDs (0 launch order, 1 contiguous ranges, 2 group g -> XCD g mod 8)
     int64_t scan_waves_per_cu = 0;               // scan kernels: 0 = the planner sizes the split by occupancy; > 0 forces that many waves per CU
     int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
@@ -340,7 +347,7 @@ void free_plan_buffers(bi_plan* p) {
         dev_free(k.perm); dev_free(k.slot_lg); dev_free(k.partial); dev_free(k.pflags); dev_free(k.rowoff_full);
     }
     dev_free(p->bad_idx); dev_free(p->nan_idx); dev_free(p->out); dev_free(p->status); dev_free(p->grp_first); dev_free(p->grp_items);
-    dev_free(p->slab); dev_free(p->bad); dev_free(p->sorted_idx);
+    dev_free(p->slab); dev_free(p->bad); dev_free(p->sorted_idx); dev_free(p->keep_z); dev_free(p->keep_rs);
 }
 
 }  // namespace

@@ -1,0 +1,369 @@
+// bi_grad_mfma.h -- value + analytic gradient of large batches on the fp64 matrix cores (bi_eval_grad, plain binned
+// likelihoods; round 4).  Included by blueice_hip.hip after bi_planning_device.h.
+//
+// What it replaces: one work item per point (k_grad_fill + k_morph_reduce<16,...,1>), every point re-reading its cell's
+// compacted rows out of L2 (2.5 MB) and carrying a [streams x 16] coefficient matrix -- 131 072 points in 40 ms, ~20 % of
+// the fp64 rate.  It is the iteration of every batched profile fit (blueice_amd/profile.py; the reference's counterpart is
+// scipy differencing make_objective's f, blueice/inference.py:111-124,153-155, inside the loops of :392-443).
+//
+// The gradient as TWO matrix products.  With mu[p][b] = sum_k coef[p][k] row[k][b] (k = corner x source) and
+// d mu[p][b] / d theta_q = sum_k C_q[p][k] row[k][b]:
+//     d ll / d theta_q = sum_b (n_b / mu_b - 1) d mu_b = sum_k C_q[p][k] ( G[p][k] - rowsum_k ),
+//     G[p][k] = sum_b f[p][b] row[k][b],   f[p][b] = n_b / mu[p][b]   (0 where n_b = 0).
+// So the device needs no derivative columns at all: per 16-bin block and 16-point work item
+//     (1) mu = rows x coef         [16 bins x K] x [K x 16 points]      KG  v_mfma_f64_16x16x4
+//     (2) G += f x rows^T          [16 points x 16 bins] x [16 bins x K]  4 x K/16 of them
+// and the accumulator layout of (1) -- lane (kq, col) holds mu[bin 4r + kq][point col] -- IS the A-operand layout of (2)
+// (row = point = col, k = kq <-> bin 4r + kq of the r-th MFMA): f goes from one product into the other without leaving its
+// registers.  Only the rows are needed in two layouts (bins along the lanes for (1), streams along the lanes for (2)): two
+// loads of the same cache lines.  The contraction with C_q (K x (d + S) numbers per point) is a few hundred flops per
+// point and happens in the finish kernel, which rebuilds the point's geometry the way k_grad_fill does.
+//
+// Work decomposition: a wave owns FOUR work items of a grid cell (64 points: their coefficients and G accumulators stay in
+// registers, 2 x 64 VGPRs) and one slice of the cell's 16-bin blocks; the rows of a block are loaded once for the four
+// items.  Partial sums per (item, slice) are written once at the end and added in slice order by the finish kernel: no
+// atomics, bitwise reproducible.
+#pragma once
+
+namespace {
+
+struct GradMfmaArgs {
+    const double* ps;
+    const double* counts;
+    const int64_t* rowoff;      // [items][NS]   (rows of a group = rows of its first item)
+    const double* coef;         // [items][NS][16]  value coefficients w_corner * r_source (unused slots repeat a point)
+    const int64_t* item_cnt;    // [items]
+    const int32_t* item_tiles;  // [items]
+    const int64_t* grp_first;   // [groups]
+    const int32_t* grp_items;   // [groups]
+    double* part_ll;            // [items][n_slices][16]
+    double* part_g;             // [items][n_slices][NSP][16]   NSP = 16 * NB
+    int NS, n_slices;
+};
+
+template <int KG, bool MASK>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_grad_mfma(GradMfmaArgs a) {
+    constexpr int NB = KG >= 4 ? KG / 4 : 1;       // blocks of 16 streams (product 2's N dimension)
+    constexpr int NSP = 16 * NB;
+    const int grp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, col = lane & 15;
+    // (product 2 reads the rows of streams 0 .. 16 NB - 1 -- more than the 4 KG of product 1 when KG < 4: every index is
+    //  clamped to a valid row here, and the rows of streams beyond NS are zeroed where they are loaded)
+    constexpr int NRO = 4 * KG > NSP ? 4 * KG : NSP;
+    constexpr bool MASK_B2 = MASK || NSP != 4 * KG;
+    __shared__ int64_t s_rowoff[NRO];
+    if (threadIdx.x < NRO) s_rowoff[threadIdx.x] = a.rowoff[a.grp_first[grp] * a.NS + min((int)threadIdx.x, a.NS - 1)];
+    log_table_load();
+    const int wx = blockIdx.x * 4 + wave;
+    const int quad = wx / a.n_slices, slice = wx % a.n_slices;
+    const int64_t item0 = a.grp_first[grp];
+    const int n_items = a.grp_items[grp];
+    const int i0 = quad * 4;
+    if (i0 >= n_items) return;
+    const int NS = a.NS;
+    const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
+    const int n_blocks = a.item_tiles[item0] * (kTile / 16);
+
+    // the four items' value coefficients: B operand of product 1 (k = kq <-> stream 4 kg + kq, column = point)
+    double cf[4][KG];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double* __restrict__ c = a.coef + (item0 + min(i0 + j, n_items - 1)) * NS * 16;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) cf[j][kg] = c[min(kg * 4 + kq, NS - 1) * 16 + col];
+    }
+    // (the group's row offsets are read from LDS block by block: as loop invariants they would hold 2 (KG + NB) registers)
+
+    bi_double4 g[4][NB];
+    double ll[4];
+    bool bad[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ll[j] = 0.0;
+        bad[j] = false;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) g[j][nb] = bi_double4{0.0, 0.0, 0.0, 0.0};
+    }
+
+    for (int blk = slice; blk < n_blocks; blk += a.n_slices) {
+        const int64_t bin0 = (int64_t)blk * 16;
+        double b1[KG], b2[4][NB], n4[4];
+        int kqo = kq, colo = col;
+        asm volatile("" : "+v"(kqo), "+v"(colo));          // (opaque: keeps the LDS reads inside the loop)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const double v = a.ps[s_rowoff[kg * 4 + kqo] + bin0 + col];
+            b1[kg] = (MASK && kg * 4 + kq >= NS) ? 0.0 : v;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int64_t row = s_rowoff[nb * 16 + colo];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = a.ps[row + bin0 + 4 * r + kq];
+                b2[r][nb] = (MASK_B2 && nb * 16 + col >= NS) ? 0.0 : v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n4[r] = cnt[bin0 + 4 * r + kq];
+        // the block's counts, known once for the four items: one count in all 16 bins (the rule in count order) lets a
+        // lane take ONE logarithm of the product of its four expectations; anything unusual is flagged
+        const double n_first = lane_value(n4[0], 0);
+        const bool uniform = __builtin_amdgcn_ballot_w64(n4[0] == n_first && n4[1] == n_first && n4[2] == n_first && n4[3] == n_first) == ~0ull &&
+                             n_first > 0.0 && n_first == floor(n_first);
+        bool odd_lane = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) odd_lane |= n4[r] != n4[r] || n4[r] < 0.0 || n4[r] != floor(n4[r]);
+        const bool odd = __builtin_amdgcn_ballot_w64(odd_lane) != 0ull;
+
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bi_double4 mu = bi_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) mu = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[j][kg], mu, 0, 0, 0);
+            // sum_b n log mu over the lane's four bins of its point (scipy's values for every argument)
+            bool neg = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) neg |= !(mu[r] >= 0.0);
+            bad[j] |= neg;
+            bool done = false;
+            if (uniform) {
+                const bool ok = mu[0] > kProdFloor && mu[1] > kProdFloor && mu[2] > kProdFloor && mu[3] > kProdFloor;
+                const double q = (mu[0] * mu[1]) * (mu[2] * mu[3]);
+                if (__builtin_amdgcn_ballot_w64(ok && pos_normal(q)) == ~0ull) {
+                    ll[j] += n_first * bin_log_fast(q);
+                    done = true;
+                }
+            }
+            if (!done) {
+                bool checked = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) checked |= n4[r] > 0.0 && !pos_normal(mu[r]);
+                if (__builtin_amdgcn_ballot_w64(checked) == 0ull) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double lg = bin_log_fast(mu[r]);
+                        ll[j] += n4[r] > 0.0 ? n4[r] * lg : 0.0;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ll[j] += n4[r] > 0.0 ? n4[r] * bin_log(mu[r]) : 0.0;
+                }
+                if (odd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (n4[r] != n4[r]) bad[j] = true;
+                        else if (n4[r] < 0.0 || n4[r] != floor(n4[r])) ll[j] += -__builtin_inf();
+                    }
+                }
+            }
+            // f = n / mu feeds product 2 straight from these registers: A[m = point = col][k = kq <-> bin 4 r + kq]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double f = n4[r] != 0.0 ? n4[r] / mu[r] : 0.0;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) g[j][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b2[r][nb], g[j][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial sums of this slice: ll per point (the four rows of a wave hold different bins of the same points), G as it lies
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j >= n_items) break;
+        const int64_t slot = (item0 + i0 + j) * a.n_slices + slice;
+        double t = bad[j] ? __builtin_nan("") : ll[j];
+        t = rows4_sum(t);
+        if (kq == 0) a.part_ll[slot * 16 + col] = t;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.part_g[(slot * NSP + nb * 16 + col) * 16 + 4 * r + kq] = g[j][nb][r];
+    }
+}
+
+// One thread per (item, slot): the slices' partial sums in slice order, then the contraction with the derivative
+// coefficients C_q of the point -- d w_c / d z_i = (+-1/delta_i) prod_{j != i} w^(j), d mus_s / d z_i, as k_grad_fill
+// builds them -- without ever writing the [K x (d + S)] matrix:
+//     H_{c,s} = G_{c,s} - rowsum_{c,s};   A_s = sum_c w_c H_{c,s};   B_{i,s} = sum_c (d w_c / d z_i) H_{c,s}
+//     d ll / d rate_scale_s = mus_s A_s;   d ll / d z_i = sum_s ( r_s B_{i,s} + (d mus_s / d z_i) rate_scale_s A_s )
+constexpr int kGradFinThreads = 64;
+constexpr int kGradFinDoubles = 32 + 64 + kMaxDim + kMaxDim;          // H[32], W[64], t[8], 1/delta[8]
+__global__ __launch_bounds__(kGradFinThreads) void k_grad_mfma_finish(PlanMeta m, int64_t n_slots, int n_slices, int NSP,
+                                                                      const int64_t* __restrict__ perm, const double* __restrict__ slot_lg,
+                                                                      const double* __restrict__ part_ll, const double* __restrict__ part_g,
+                                                                      const double* __restrict__ z, const double* __restrict__ rate_scale,
+                                                                      double* __restrict__ ll_out, double* __restrict__ grad_out) {
+    extern __shared__ double s_fin[];
+    const int lane = threadIdx.x;
+#define BI_AT(base, i) s_fin[((base) + (i)) * kGradFinThreads + lane]
+#define H_(k) BI_AT(0, k)
+#define W_(c) BI_AT(32, c)
+#define T_(i) BI_AT(96, i)
+#define ID_(i) BI_AT(96 + kMaxDim, i)
+    const int64_t slot = (int64_t)blockIdx.x * kGradFinThreads + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int64_t p = perm[slot];
+    if (p < 0) return;
+    const int64_t item = slot >> 4;
+    const int gslot = (int)(slot & 15);
+    const int NS = m.nc * m.S;
+    double ll = 0.0;
+    for (int s = 0; s < n_slices; ++s) ll += part_ll[(item * n_slices + s) * 16 + gslot];
+    ll -= slot_lg[slot];
+    ll_out[p] = ll;
+    // the point's cell and corner weights (as k_plan_geometry / k_grad_fill; the point is known to be inside the box)
+    int64_t cell = 0;
+    for (int i = 0; i < m.d; ++i) {
+        const double* g = m.grid + m.grid_off[i];
+        const int n = m.n_anchor[i];
+        const double zi = z[p * m.d + i];
+        int k = 0;
+        double ti = 0.0, id = 0.0;
+        if (n > 1) {
+            if (zi == g[n - 1]) {
+                k = n - 2;
+            } else {
+                while (k + 1 < n && g[k + 1] <= zi) ++k;
+                k = min(k, n - 2);
+            }
+            ti = (zi - g[k]) / (g[k + 1] - g[k]);
+            id = 1.0 / (g[k + 1] - g[k]);
+        }
+        T_(i) = ti;
+        ID_(i) = id;
+        cell += (int64_t)k * m.astride[i];
+    }
+    for (int corner = 0; corner < m.nc; ++corner) {
+        double wc = 1.0;
+        for (int i = 0; i < m.de; ++i) {
+            const double ti = T_(m.eff_axes[i]);
+            wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? ti : (1 - ti));
+        }
+        W_(corner) = wc;
+    }
+    for (int k = 0; k < NS; ++k) {
+        double gk = 0.0;
+        for (int s = 0; s < n_slices; ++s) gk += part_g[((item * n_slices + s) * NSP + k) * 16 + gslot];
+        const int corner = k / m.S, src = k % m.S;
+        H_(k) = gk - m.rowsum[(cell + m.corner_off[corner]) * m.S + src];
+    }
+    auto dw = [&](int corner, int i) {
+        double v = (((corner >> (m.de - 1 - i)) & 1) ? 1.0 : -1.0) * ID_(m.eff_axes[i]);
+        for (int j = 0; j < m.de; ++j) {
+            if (j == i) continue;
+            const double tj = T_(m.eff_axes[j]);
+            v *= ((corner >> (m.de - 1 - j)) & 1) ? tj : (1 - tj);
+        }
+        return v;
+    };
+    double* __restrict__ out = grad_out + p * (m.d + m.S);
+    for (int i = 0; i < m.d; ++i) out[i] = 0.0;
+    const bool fin = ll == ll && ll > -__builtin_inf() && ll < __builtin_inf();
+    for (int src = 0; src < m.S; ++src) {
+        double mus = 0.0, A = 0.0;
+        for (int corner = 0; corner < m.nc; ++corner) {
+            mus = mus + m.mus[(cell + m.corner_off[corner]) * m.S + src] * W_(corner);
+            A += W_(corner) * H_(corner * m.S + src);
+        }
+        const double rs = rate_scale ? rate_scale[p * m.S + src] : 1.0;
+        out[m.d + src] = fin ? mus * A : __builtin_nan("");
+        for (int i = 0; i < m.de; ++i) {
+            double dmus = 0.0, B = 0.0;
+            for (int corner = 0; corner < m.nc; ++corner) {
+                const double v = dw(corner, i);
+                dmus += v * m.mus[(cell + m.corner_off[corner]) * m.S + src];
+                B += v * H_(corner * m.S + src);
+            }
+            out[m.eff_axes[i]] += (mus * rs) * B + dmus * rs * A;
+        }
+    }
+    if (!fin)
+        for (int i = 0; i < m.d; ++i) out[i] = __builtin_nan("");
+#undef BI_AT
+#undef H_
+#undef W_
+#undef T_
+#undef ID_
+}
+
+// bi_eval_grad for large single-dataset batches of a plain binned likelihood: device planner (points grouped by grid cell, 16
+// per work item), k_grad_mfma, k_grad_mfma_finish.  -> ll [P], grad [P][d + S], status [P]
+int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
+                   double* ll, double* grad, int32_t* status) {
+    const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
+    bi_plan* plan = nullptr;
+    int rc = plan_points_device(c, P, z, rate_scale, dataset, sparse, &plan, 0, 1, false, /*grad_mode=*/true);
+    if (rc) return rc;
+    const double ninf = -std::numeric_limits<double>::infinity(), qnan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<int32_t> h_st((size_t)P, 0);
+    DevBuf d_pll, d_pg, d_ll, d_grad;
+    auto cleanup = [&]() { dev_free(d_pll); dev_free(d_pg); dev_free(d_ll); dev_free(d_grad); bi_plan_destroy(c, plan); };
+    hipError_t e = hipSuccess;
+    std::vector<double> h_ll((size_t)P), h_grad((size_t)P * (d + S));
+    if (!plan->classes.empty() && plan->classes[0].n_items > 0) {
+        bi_plan::Class& k = plan->classes[0];
+        const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
+        const int NSP = kg >= 4 ? 4 * kg : 16;
+        // slices: enough waves for two per SIMD over the whole chip; a wave wants at least ~8 blocks of 16 bins
+        const int64_t quads_max = (plan->max_group_items + 3) / 4;
+        const int64_t quads_all = std::max<int64_t>(1, (k.n_items + 3) / 4);
+        const int64_t n_blocks = (int64_t)plan->max_item_tiles * (kTile / 16);
+        const int64_t want = 2 * 4 * (int64_t)c->prop.multiProcessorCount;
+        int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>({(want + quads_all - 1) / quads_all, n_blocks / 8 > 0 ? n_blocks / 8 : 1, 64}));
+        if (c->grad_slices > 0) n_slices = (int)std::min<int64_t>(c->grad_slices, std::max<int64_t>(1, n_blocks));
+        const size_t ni = (size_t)k.n_items;
+        if ((rc = dev_alloc(c, d_pll, ni * n_slices * 16 * 8)) || (rc = dev_alloc(c, d_pg, ni * n_slices * NSP * 16 * 8)) ||
+            (rc = dev_alloc(c, d_ll, (size_t)P * 8)) || (rc = dev_alloc(c, d_grad, (size_t)P * (d + S) * 8))) { cleanup(); return rc; }
+        GradMfmaArgs ga{};
+        ga.ps = sparse ? (const double*)c->ps_c.p : (const double*)c->ps.p;
+        ga.counts = sparse ? (const double*)c->cnt_c.p : (const double*)c->counts.p;
+        ga.rowoff = (const int64_t*)k.rowoff.p; ga.coef = (const double*)k.coef.p;
+        ga.item_cnt = (const int64_t*)k.item_cnt.p; ga.item_tiles = (const int32_t*)k.item_tiles.p;
+        ga.grp_first = (const int64_t*)plan->grp_first.p; ga.grp_items = (const int32_t*)plan->grp_items.p;
+        ga.part_ll = (double*)d_pll.p; ga.part_g = (double*)d_pg.p; ga.NS = NS; ga.n_slices = n_slices;
+        const dim3 grid((unsigned)((quads_max * n_slices + 3) / 4), (unsigned)plan->n_groups);
+        {
+            EventScope ev(c);
+            ++c->n_grad_mfma_launches;
+#define BI_GM(KG)                                                                                                 \
+    do {                                                                                                          \
+        if (NS == 4 * KG) hipLaunchKernelGGL((k_grad_mfma<KG, false>), grid, dim3(kThreads), 0, c->stream, ga);   \
+        else hipLaunchKernelGGL((k_grad_mfma<KG, true>), grid, dim3(kThreads), 0, c->stream, ga);                 \
+    } while (0)
+            if (kg == 1) BI_GM(1); else if (kg == 2) BI_GM(2); else if (kg == 4) BI_GM(4); else BI_GM(8);
+#undef BI_GM
+        }
+        PlanMeta m = plan_meta_of(c, sparse);
+        const int64_t n_slots = (int64_t)k.n_items * 16;
+        const size_t lds = (size_t)kGradFinDoubles * kGradFinThreads * sizeof(double);
+        e = hipFuncSetAttribute((const void*)k_grad_mfma_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_grad_mfma_finish, dim3((unsigned)((n_slots + kGradFinThreads - 1) / kGradFinThreads)), dim3(kGradFinThreads), lds,
+                               c->stream, m, n_slots, n_slices, NSP, (const int64_t*)k.perm.p, (const double*)k.slot_lg.p,
+                               (const double*)d_pll.p, (const double*)d_pg.p, (const double*)plan->keep_z.p,
+                               rate_scale ? (const double*)plan->keep_rs.p : (const double*)nullptr, (double*)d_ll.p, (double*)d_grad.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_ll.data(), d_ll.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_grad.data(), d_grad.p, h_grad.size() * 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_st.data(), plan->status.p, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_grad (matrix-core path): %s", hipGetErrorString(e));
+    for (int64_t p = 0; p < P; ++p) {
+        if (status) status[p] = h_st[(size_t)p];
+        if (h_st[(size_t)p]) {
+            ll[p] = ninf;
+            for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = qnan;
+        } else {
+            ll[p] = h_ll[(size_t)p];
+            for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = h_grad[(size_t)p * (d + S) + j];
+        }
+    }
+    return BI_OK;
+}
+
+}  // namespace

@@ -53,6 +53,9 @@ const ParamDef kParams[] = {
     {"scan_waves_per_cu", kParamRW, BI_P_GET(c->scan_waves_per_cu), BI_P_SET(c->scan_waves_per_cu = v < 0 ? 0 : v)},
     {"host_threads", kParamRW, [](bi_ctx*) -> int64_t { return host_threads(); },
      [](bi_ctx* c, int64_t v) -> int { if (v < 0 || v > 256) return fail(c, BI_ERR_INVALID, "host_threads in [0, 256] (0 = by the process's affinity, at most 16)"); host_threads_setting().store((int)v); return BI_OK; }},
+    {"grad_mfma", kParamRW, BI_P_GET(c->grad_mfma), BI_P_FLAG(grad_mfma)},
+    {"grad_mfma_min", kParamRW, BI_P_GET(c->grad_mfma_min), BI_P_RANGE(1, (int64_t)1 << 40, grad_mfma_min, "grad_mfma_min >= 1")},
+    {"grad_slices", kParamRW, BI_P_GET(c->grad_slices), BI_P_RANGE(0, 4096, grad_slices, "grad_slices in [0, 4096]")},
     {"scan_xcd", kParamRW, BI_P_GET(c->scan_xcd), BI_P_RANGE(0, 2, scan_xcd, "scan_xcd: 0 launch order, 1 contiguous ranges, 2 one XCD per group")},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},
     {"scan_split", kParamRW, BI_P_GET(c->scan_split), BI_P_FLAG(scan_split)},
@@ -77,6 +80,7 @@ const ParamDef kParams[] = {
     BI_P_RO("tile_bins", kTile),
     BI_P_RO("padded_bins", c->Bp),
     BI_P_RO("n_scan_launches", c->n_scan_launches),
+    BI_P_RO("n_grad_mfma_launches", c->n_grad_mfma_launches),
     BI_P_RO("n_valid_launches", c->n_valid_launches),
     BI_P_RO("n_sorted_scans", c->n_sorted_scans),
     BI_P_RO("n_bb_exact", c->n_bb_exact),

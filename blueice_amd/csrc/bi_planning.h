@@ -45,7 +45,7 @@ struct PlanItem {
 constexpr int kClassG[5] = {1, 2, 4, 8, 16};
 
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out, int share_rank, int share_world, bool resident);
+                       bi_plan** out, int share_rank, int share_world, bool resident, bool grad_mode);
 
 // transient: the plan is run once and destroyed inside the calling entry point (bi_eval); small ones then travel in
 // one packed copy and deliver their results to pinned host memory.
@@ -82,13 +82,13 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         if (share_rank < 0 || share_rank >= share_world) return fail(c, BI_ERR_INVALID, "share %d outside [0,%d)", share_rank, share_world);
         if (bb || inf_scale || P > (int64_t)1 << 30)
             return fail(c, BI_ERR_INVALID, "shares of a scan are planned on the device: not available with Beeston-Barlow or infinite rate scales");
-        return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, share_rank, share_world, false);
+        return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, share_rank, share_world, false, false);
     }
     if (!bb && !inf_scale && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
         int64_t cells = 1;
         for (int ax : c->eff_axes) cells *= c->n_anchor[(size_t)ax] - 1;
         const int64_t groups = cells * (dataset ? c->T : 1);
-        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, 0, 1, false);
+        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, 0, 1, false, false);
     }
 
     // ---- phase 1: per point geometry, rates, early exits (parallel) ---------------------------------

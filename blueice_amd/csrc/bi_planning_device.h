@@ -285,9 +285,12 @@ __global__ __launch_bounds__(kThreads) void k_plan_group_first(const int64_t* __
 }
 
 __global__ __launch_bounds__(kThreads) void k_plan_group_items(const int64_t* __restrict__ grp_first, int64_t n_groups, int64_t n_items,
-                                                               int32_t* __restrict__ grp_items) {
+                                                               int32_t* __restrict__ grp_items, unsigned long long* __restrict__ max_items /* or NULL */) {
     const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (g < n_groups) grp_items[g] = (int32_t)((g + 1 < n_groups ? grp_first[g + 1] : n_items) - grp_first[g]);
+    if (g >= n_groups) return;
+    const int64_t n = (g + 1 < n_groups ? grp_first[g + 1] : n_items) - grp_first[g];
+    grp_items[g] = (int32_t)n;
+    if (max_items) atomicMax(max_items, (unsigned long long)n);
 }
 
 __global__ __launch_bounds__(kThreads) void k_fill_bad_by_status(const int32_t* __restrict__ status, int64_t P, double* __restrict__ out) {
@@ -569,8 +572,11 @@ int eval_grad_device(bi_ctx* c, int64_t P, const double* z, const double* rate_s
     return BI_OK;
 }
 
+// grad_mode (eval_grad_mfma): the plan of a gradient batch for the matrix cores -- group tables always, the linear part
+// -sum_b mu_b in the per-point constant, no scan / split decisions, no partial-sum buffers, and the device copies of z and
+// rate_scale stay with the plan (the finish kernel rebuilds every point's derivative coefficients from them)
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
-                       bi_plan** out, int share_rank = 0, int share_world = 1, bool resident = false) {
+                       bi_plan** out, int share_rank, int share_world, bool resident, bool grad_mode) {
     int rc = ensure_plan_tables(c);
     if (rc) return rc;
     const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
@@ -673,18 +679,18 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         // Every bin visited, mostly empty data, several items per cell: split the scan into the non-empty-bin pass (the
         // descriptors below then describe the compacted rows, as for a sparse plan) and a validity pass over all bins on
         // the matrix cores (k_scan_valid).  The two together are exact for templates and rates of either sign.
-        const bool split = !sparse && c->scan_split && scan_shape && c->compact_ready && c->dense_counts &&
+        const bool split = !grad_mode && !sparse && c->scan_split && scan_shape && c->compact_ready && c->dense_counts &&
                            n_items >= c->scan_min_items * n_groups;
         const bool compacted = sparse || split;
         // the matrix-core scan kernel pays when many items share a cell (it streams a cell's rows once per strip and
         // keeps them in registers): measured against k_morph_reduce 1.2x at 2, 1.3x at 8 and 1.7x at 128 items per cell
         // on sparse data; 1.0x at 4, 1.2x at 8 and 1.3x at 128 on dense data (where the per-bin logarithm is the
         // larger part of the work)
-        const bool scan_ok = !split && scan_shape &&
+        const bool scan_ok = !grad_mode && !split && scan_shape &&
                              n_items >= c->scan_min_items * (mostly_empty ? 1 : 2) * n_groups &&
                              !(sparse && n_items > c->scan_sparse_max_items * n_groups);   // compacted rows, very long item lists: see scan_sparse_max_items
         m.sparse = compacted ? 1 : 0;
-        m.linear_outside = scan_ok ? 1 : 0;
+        m.linear_outside = (scan_ok || grad_mode) ? 1 : 0;
         plan->sparse = compacted;
         plan->classes.emplace_back();
         bi_plan::Class& k = plan->classes.back();
@@ -701,8 +707,9 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         const size_t ni = (size_t)n_items;
         if ((rc = dev_alloc(c, k.rowoff, ni * NS * 8)) || (rc = dev_alloc(c, k.coef, ni * NS * kDevG * 8)) || (rc = dev_alloc(c, k.aux, ni * kDevG * 16)) ||
             (rc = dev_alloc(c, k.item_cnt, ni * 8)) || (rc = dev_alloc(c, k.item_tiles, ni * 4)) || (rc = dev_alloc(c, k.perm, ni * kDevG * 8)) ||
-            (rc = dev_alloc(c, k.slot_lg, ni * kDevG * 8)) || (rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||
-            (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))) ||
+            (rc = dev_alloc(c, k.slot_lg, ni * kDevG * 8)) ||
+            (!grad_mode && ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||
+                            (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))))) ||
             (split && (rc = dev_alloc(c, k.rowoff_full, ni * NS * 8))))
             return abort_plan(rc);
         e = hipMemsetAsync(k.coef.p, 0, ni * NS * kDevG * 8, c->stream);
@@ -728,9 +735,20 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             hipLaunchKernelGGL(k_plan_group_first, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, (const int64_t*)d_idx.p,
                                (const int64_t*)d_keys.p, n_valid, (int64_t*)plan->grp_first.p);
             hipLaunchKernelGGL(k_plan_group_items, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
-                               (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p);
+                               (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p,
+                               grad_mode ? (unsigned long long*)(scal + 3) : (unsigned long long*)nullptr);
             return BI_OK;
         };
+        if (grad_mode) {
+            if ((rc = group_tables())) return abort_plan(rc);
+            int64_t h_max = 0;
+            e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+            plan->n_groups = n_groups;
+            plan->max_group_items = h_max;
+            plan->max_item_tiles = (int)max_tiles;
+        }
         // A group's strips are spread over W = 4 b waves (b blocks); a block lasts as long as its busiest wave, ceil(strips / W)
         // strips, and the blocks of all groups run in ceil(b * n_groups / resident blocks) rounds -- the last of which is
         // as long as the others however few blocks it holds.  Choose b for the smallest rounds x strips-per-wave (ties: the
@@ -835,6 +853,10 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     if (shared) {                 // the sorted -> original index map outlives the planning: unsort_share reads it
         plan->sorted_idx = d_idx2;
         d_idx2 = DevBuf{};
+    }
+    if (grad_mode && !resident) {
+        plan->keep_z = d_z; d_z = DevBuf{};
+        plan->keep_rs = d_rs; d_rs = DevBuf{};
     }
     cleanup();
     *out = plan;

@@ -51,6 +51,7 @@
 #include "bi_single.h"
 #include "bi_planning.h"
 #include "bi_planning_device.h"
+#include "bi_grad_mfma.h"
 #include "bi_grad_bb.h"
 #include "bi_params.h"
 
@@ -528,7 +529,7 @@ int bi_plan_points_resident(bi_ctx* c, int64_t P, const double* z_dev, const dou
     if (!sparse && !c->dense_counts)
         return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
                                      "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
-    return plan_points_device(c, P, z_dev, rate_scale_dev, dataset_dev, sparse, out, share_rank, share_world, true);
+    return plan_points_device(c, P, z_dev, rate_scale_dev, dataset_dev, sparse, out, share_rank, share_world, true, false);
 }
 
 int bi_plan_share_info(const bi_plan* p, int64_t* n_valid, int64_t* lo, int64_t* hi) {
@@ -863,8 +864,12 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
     const double qnan = std::numeric_limits<double>::quiet_NaN();
 
     // large batches: the descriptors are built on the device (k_grad_fill), one work item per point
-    if (!unb && c->device_plan_min > 0 && P >= c->device_plan_min && de <= 6 && P <= ((int64_t)1 << 26))
+    if (!unb && c->device_plan_min > 0 && P >= c->device_plan_min && de <= 6 && P <= ((int64_t)1 << 26)) {
+        // one dataset, up to 32 streams: grouped by grid cell, two matrix products per 16-bin block (k_grad_mfma)
+        if (c->grad_mfma && P >= c->grad_mfma_min && c->scan_mfma && c->ps_finite && NS <= 32 && (!dataset || c->T == 1))
+            return eval_grad_mfma(c, P, z, rate_scale, dataset, sparse, ll, grad, status);
         return eval_grad_device(c, P, z, rate_scale, dataset, sparse, G, ll, grad, status);
+    }
 
     // Host half, per point and independent: phase 1 decides which points are evaluated at all (the reference's early
     // exits), phase 2 fills the descriptor arrays of the live ones.  Both run on a few host threads for large batches --

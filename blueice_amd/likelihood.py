@@ -970,7 +970,15 @@ class LogLikelihoodSum:
         total = 0.
         for i, (ll, names, weight) in enumerate(zip(self.likelihood_list, self.likelihood_parameters, self.likelihood_weights)):
             lt = livetime_days[i] if isinstance(livetime_days, list) else livetime_days
-            total = total + weight * ll.eval_points({k: v for k, v in points.items() if k in names}, livetime_days=lt)
+            mine = {k: v for k, v in points.items() if k in names}
+            if hasattr(ll, 'eval_points'):
+                total = total + weight * ll.eval_points(mine, livetime_days=lt)
+                continue
+            # a term that only knows scalar calls (an analytic constraint, LogAncillaryLikelihood): point by point
+            cols = {k: np.atleast_1d(np.asarray(v, dtype=float)) for k, v in mine.items()}
+            P = max([len(c) for c in cols.values()] + [1])
+            vals = np.array([ll(**{k: float(c[j] if len(c) == P else c[0]) for k, c in cols.items()}) for j in range(P)])
+            total = total + weight * (vals if cols else vals[0])
         return total
 
     @property

@@ -329,6 +329,11 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     which it is used (4; x2 for dense data), strip width (0 = by the data), waves per CU the
  *                     strips of all cells are spread over (0 = sized by the kernel's occupancy so that the blocks run in
  *                     full rounds, default)
+ *   grad_mfma, grad_mfma_min, grad_slices   bi_eval_grad: batches of >= grad_mfma_min (2048) points of one dataset (plain binned likelihood, up to 32
+ *                     streams) run on the fp64 matrix cores -- points grouped by grid cell, mu = rows x coefficients and
+ *                     G = (n / mu) x rows^T as two chained matrix products per 16-bin block, the derivative coefficients
+ *                     contracted per point afterwards (k_grad_mfma; 1, default; 0 = one work item per point); grad_slices:
+ *                     slices a cell's 16-bin blocks are split into (0 = by the batch).  Read-only n_grad_mfma_launches
  *   host_threads      host threads the planner may start per call (PROCESS-wide): 0 = what the process may run on (its
  *                     scheduling affinity), at most 16 (default); a launcher of N ranks per node sets its share, so that the ranks
  *                     together never run more planner threads than the node has cores for them
