@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): counter evidence for the 131 072-point scan of C2 over DENSE data (an event in
-# nearly every bin), count-sorted rows (k_scan_mfma<2,8,false,2>, round 3) against rows in bin order (<2,8,false,0>,
+# nearly every bin), count-sorted rows (k_scan_sorted<8,false>, round 4) against rows in bin order (k_scan_mfma<2,8,false,0>,
 # round 2's path) -> gpurun_out/prof_scan_dense/ ; tools/summarize_scan_dense.py turns it into profiles/rNN_scan_dense_data_*.
 # One counter pass per command, never combined with a trace.
 set -e -o pipefail

@@ -19,7 +19,7 @@ def counters(order):
         return None
     with open(os.path.join(SRC, 'pmc_%s' % order, 'pmc_counter_collection.csv')) as f:
         for row in csv.DictReader(f):
-            if 'k_scan_mfma' in row['Kernel_Name']:
+            if 'k_scan_mfma' in row['Kernel_Name'] or 'k_scan_sorted' in row['Kernel_Name']:
                 agg[row['Counter_Name']] += float(row['Counter_Value'])
                 name = row['Kernel_Name']
                 if row['Counter_Name'] == 'SQ_INSTS_MFMA':
@@ -43,7 +43,7 @@ def main(rnd):
     trace = {}
     with open(os.path.join(SRC, 'kt', 'kt_kernel_stats.csv')) as f:
         for row in csv.DictReader(f):
-            if 'k_scan_mfma' in row['Name']:
+            if 'k_scan_mfma' in row['Name'] or 'k_scan_sorted' in row['Name']:
                 trace = dict(name=row['Name'], calls=int(row['Calls']), average_us=float(row['AverageNs']) / 1e3,
                              min_us=float(row['MinNs']) / 1e3, max_us=float(row['MaxNs']) / 1e3)
     out = dict(
@@ -64,17 +64,17 @@ def main(rnd):
         st = {}
         with open(os.path.join(SRC, 'kts', 'kt_kernel_stats.csv')) as f:
             for row in csv.DictReader(f):
-                if 'k_scan_mfma' in row['Name']:
+                if 'k_scan_mfma' in row['Name'] or 'k_scan_sorted' in row['Name']:
                     st = dict(name=row['Name'], calls=int(row['Calls']), average_us=float(row['AverageNs']) / 1e3,
                               min_us=float(row['MinNs']) / 1e3, max_us=float(row['MaxNs']) / 1e3)
         shutil.copy(os.path.join(SRC, 'kts', 'kt_kernel_stats.csv'), os.path.join(dst, tag + '_sparse_scan_kernel_stats.csv'))
         with open(os.path.join(dst, tag + '_sparse_scan_pmc.json'), 'w') as f:
             json.dump(dict(round=rnd, command='tools/profile_scan_dense.sh: rocprofv3 --pmc <8 SQ counters> / --kernel-trace --stats (own run) '
                                               '-- python3 tools/profile/sparse_scan_only.py',
-                           workload='10^6-point scan of C2 on the default path (non-empty-bin form): k_scan_mfma over the compacted rows, '
-                                    'ordered by count (one logarithm per lane, work item and 32-bin strip)',
+                           workload='10^6-point scan of C2 on the default path (non-empty-bin form): k_scan_sorted over the compacted rows, '
+                                    'ordered by count (64-bin strips, one logarithm per four work items)',
                            kernel_trace=st, evaluations_per_s_by_kernel_trace=(1e6 / (st['average_us'] * 1e-6) if st else None),
-                           previous_round='profiles/r02_sparse_scan_pmc.json: k_scan_mfma<2,8,false,true> 14.6 ms, 7.95 vector instructions per MFMA, matrix pipe busy 57.7 %',
+                           previous_round='profiles/r03_sparse_scan_pmc.json: k_scan_mfma<2,8,false,2> 13.76 ms, 3.62 vector instructions per MFMA, matrix pipe busy 63.5 %',
                            **sparse), f, indent=1)
         print('default-path scan: %s' % st, sparse['derived'])
     d1, d0 = out['count_sorted_rows']['derived'], out['rows_in_bin_order']['derived']
