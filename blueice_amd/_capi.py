@@ -49,6 +49,8 @@ SIGNATURES = {
     'bi_download_counts': (C.c_int, [_p, _i64, _p]),
     'bi_eval': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p]),
     'bi_eval_grad': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p]),
+    'bi_minimize_batched': (C.c_int, [_p, _p, _i64, C.c_int, _p, _p, _p, _p, _p, C.c_double, C.c_int, _p, _p, _p, _p]),
+    'bi_fit_batched': (C.c_int, [_p, _i64, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_int, _p, _p, _p, _p]),
     'bi_eval_datasets': (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     'bi_interpolate': (C.c_int, [_p, C.c_int, _p, _p]),
     'bi_eval_full': (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
@@ -83,6 +85,9 @@ SIGNATURES = {
     'bi_get_param': (_i64, [_p, C.c_char_p]),
     'bi_list_params': (C.c_int, [C.c_char_p, C.c_int]),
 }
+
+# the objective callback of bi_minimize_batched
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, _p, _i64, C.c_int, _pd, C.POINTER(_i64), _pd, _pd)
 
 _lib = None
 

@@ -1999,3 +1999,5 @@ int bi_profile_read(bi_ctx* c, int64_t* n_launches, double* total_ms) {
 }
 
 }  // extern "C"
+
+#include "bi_fit.h"

@@ -327,6 +327,14 @@ class DeviceContext:
                                            ptr(status)))
         return ll, grad[:, :self.d], grad[:, self.d:], status
 
+    def fit_batched(self, P, F, kind, index, z0, scale0, unit, dataset, x0, lo, hi, n_kinks, kinks, gtol, max_iter, x, f, flags, counters):
+        """bi_fit_batched: the batched profile-fit engine's loop with this context's likelihood as the objective (all
+        arguments are C-contiguous numpy arrays of the right dtype or None; results are written into x, f, flags, counters)."""
+        self._check(self._lib.bi_fit_batched(self._h, int(P), int(F), ptr(kind), ptr(index), ptr(z0) if self.d else None, ptr(scale0), ptr(unit),
+                                             ptr(dataset), ptr(x0), ptr(lo), ptr(hi), ptr(n_kinks), ptr(kinks), float(gtol), int(max_iter),
+                                             ptr(x), ptr(f), ptr(flags), ptr(counters)))
+        return 0
+
     def eval_datasets(self, z, rate_scale=None, t0=0, t1=None):
         """One parameter point against datasets [t0, t1) -> (ll [t1-t0], status)."""
         t1 = self.T if t1 is None else int(t1)

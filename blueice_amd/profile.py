@@ -15,14 +15,21 @@ get central differences from batched `eval_points` calls instead.
 
     best, ll = bestfit_batched(lf, points={'shift': grid}, s2_rate_multiplier=1.)     # arrays [len(grid)]
 """
+import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
 
-from .exceptions import NoOpimizationNecessary
+from .exceptions import DeviceError, NoOpimizationNecessary
 from .utils import is_numeric
 
-__all__ = ['bestfit_batched', 'batched_minimize', 'BatchObjective', 'supports_batched_fits']
+# The optimiser's inner loop: 'native' = the C++ port inside libblueice_hip.so (bi_minimize_batched / bi_fit_batched,
+# csrc/bi_fit.h: the same algorithm as loops over problems, and with a device likelihood as the objective no Python between
+# the iterations at all), 'numpy' = the array form below (kept as the executable specification: tests hold one against the other)
+ENGINE = os.environ.get('BLUEICE_AMD_ENGINE', 'native')
+
+__all__ = ['bestfit_batched', 'batched_minimize', 'batched_minimize_numpy', 'BatchObjective', 'supports_batched_fits']
 
 
 def supports_batched_fits(lf):
@@ -53,6 +60,44 @@ class BatchObjective:
             except (TypeError, ValueError):
                 pass
         self.calls = self.evaluations = 0
+
+    def native(self):
+        """What bi_fit_batched needs to evaluate this objective without Python: the problems' settings as arrays, and which
+        optimiser variable is which parameter -- or None where a Python callable sits between x and the device call (priors,
+        a shape parameter that doubles as an efficiency, 'unphysical_behaviour': 'error', likelihoods that are not one
+        device context)."""
+        if hasattr(self, '_native'):
+            return self._native
+        self._native = None
+        lf = self.lf
+        ok = self.analytic and hasattr(lf, '_batch_terms') and getattr(lf, 'ctx', None) is not None and \
+            hasattr(lf.ctx, 'fit_batched') and not any(getattr(lf, 'source_apply_efficiency', [])) and \
+            lf.config.get('unphysical_behaviour') != 'error' and \
+            all(v[1] is None for v in lf.shape_parameters.values()) and all(v is None for v in lf.rate_parameters.values())
+        if not ok:
+            return None
+        P = max([len(v) for v in self.points.values()] + ([len(self.datasets)] if self.datasets is not None else []) + [1])
+        pts = {k: np.broadcast_to(v, (P,)) for k, v in self.points.items()}
+        pts.update(self.fixed)
+        z0, scale0, prior, unit = lf._batch_terms(pts, self.livetime_days, want_unit=True)
+        z0, scale0, unit = (np.ascontiguousarray(np.broadcast_to(a, (P,) + a.shape[1:]), dtype=float) for a in (z0, scale0, unit))
+        kind, index = [], []
+        shape_names = list(lf.shape_parameters)
+        for n in self.names:
+            if n in lf.shape_parameters:
+                kind.append(0)
+                index.append(shape_names.index(n))
+            elif n.endswith('_rate_multiplier') and n[:-16] in lf.source_name_list:
+                kind.append(1)
+                index.append(lf.source_name_list.index(n[:-16]))
+            else:
+                return None
+        self._native = dict(P=P, z0=z0, scale0=scale0, unit=unit, kind=np.array(kind, dtype=np.int32), index=np.array(index, dtype=np.int32))
+        return self._native
+
+    def stacked(self, period):
+        """The same objective over several copies of the problem set: row r is problem r % period (multi-start fits)."""
+        return StackedObjective(self, period)
 
     def _points_of(self, x, rows):
         pts = {k: v[rows] for k, v in self.points.items()}
@@ -103,8 +148,81 @@ class BatchObjective:
         return -ll[0], -g
 
 
-def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=20, ftol=1e-15, slow_window=8, slow_tol=1e-11,
-                     kinks=None):
+class StackedObjective:
+    def __init__(self, base, period):
+        self.base, self.period = base, int(period)
+
+    def __call__(self, x, rows):
+        return self.base(x, rows % self.period)
+
+
+def _native_minimize(fun, x0, lo, hi, gtol, max_iter, kinks):
+    """batched_minimize on the C++ loop of libblueice_hip.so.  A BatchObjective (or a stack of one) over a device likelihood
+    without Python-side terms runs entirely inside bi_fit_batched; any other objective is called back from bi_minimize_batched."""
+    from . import _capi
+    lib = _capi.load()
+    x0 = np.ascontiguousarray(x0, dtype=float)
+    P, F = x0.shape
+    lo = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=float), (F,)))
+    hi = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=float), (F,)))
+    if kinks is not None and any(len(k) for k in kinks):
+        n_k = np.array([len(k) for k in kinks], dtype=np.int32)
+        k_flat = np.ascontiguousarray(np.concatenate([np.sort(np.asarray(k, dtype=float)) for k in kinks]))
+    else:
+        n_k = k_flat = None
+    x = np.empty((P, F))
+    f = np.empty(P)
+    flags = np.zeros(P, dtype=np.int32)
+    counters = np.zeros(4, dtype=np.int64)
+    ptr = _capi.ptr
+    base = fun.base if isinstance(fun, StackedObjective) else fun
+    nat = base.native() if isinstance(base, BatchObjective) else None
+    if nat is not None and (isinstance(fun, StackedObjective) or P == nat['P']):
+        reps = P // nat['P'] if isinstance(fun, StackedObjective) else 1
+        tile = (lambda a: np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1)))) if reps > 1 else (lambda a: a)
+        ds = None if base.datasets is None else np.ascontiguousarray(tile(np.broadcast_to(base.datasets, (nat['P'],))), dtype=np.int64)
+        z0, s0, un = tile(nat['z0']), tile(nat['scale0']), tile(nat['unit'])
+        rc = base.lf.ctx.fit_batched(P, F, nat['kind'], nat['index'], z0, s0, un, ds, x0, lo, hi, n_k, k_flat, gtol, max_iter, x, f, flags, counters)
+        base.calls += int(counters[1])
+        base.evaluations += int(counters[3])
+    else:
+        err = []
+
+        def callback(user, n, nf, xp, rp, fp, gp):
+            try:
+                xx = np.ctypeslib.as_array(xp, (n, nf)).copy()
+                rr = np.ctypeslib.as_array(rp, (n,)).copy()
+                ff, gg = fun(xx, rr)
+                np.ctypeslib.as_array(fp, (n,))[:] = ff
+                np.ctypeslib.as_array(gp, (n, nf))[:] = gg
+                return 0
+            except BaseException as e:          # (must not propagate through the C frames)
+                err.append(e)
+                return -1
+
+        cb = _capi.OBJECTIVE_FN(callback)
+        rc = lib.bi_minimize_batched(C.cast(cb, C.c_void_p), None, P, F, ptr(x0), ptr(lo), ptr(hi), ptr(n_k), ptr(k_flat), float(gtol),
+                                     int(max_iter), ptr(x), ptr(f), ptr(flags), ptr(counters))
+        if err:
+            raise err[0]
+        if rc:
+            raise DeviceError("bi_minimize_batched failed (%d)" % rc)
+    info = dict(converged=(flags & 1) != 0, stalled=(flags & 2) != 0, failed=(flags & 4) != 0, iterations=int(counters[0]),
+                calls=int(counters[1]), kink_calls=int(counters[2]))
+    return x, f, info
+
+
+def batched_minimize(fun, x0, lo, hi, gtol=1e-6, max_iter=200, kinks=None, engine=None, **options):
+    """Minimise P independent functions of F variables each (see `batched_minimize_numpy` for the algorithm): on the C++ loop
+    of the library unless engine / BLUEICE_AMD_ENGINE says 'numpy' or non-default tuning options are given."""
+    engine = engine or ENGINE
+    if engine == 'native' and not options and np.ndim(x0) == 2 and np.shape(x0)[0] > 0 and 1 <= np.shape(x0)[1] <= 64:
+        return _native_minimize(fun, x0, lo, hi, gtol, max_iter, kinks)
+    return batched_minimize_numpy(fun, x0, lo, hi, gtol=gtol, max_iter=max_iter, kinks=kinks, **options)
+
+
+def batched_minimize_numpy(fun, x0, lo, hi, gtol=1e-6, max_iter=200, c1=1e-4, max_halvings=20, ftol=1e-15, slow_window=8, slow_tol=1e-11,
+                           kinks=None):
     """Minimise P independent functions of F variables each.  fun(x [n, F], rows [n]) -> (f [n], g [n, F]).
     lo / hi [F]: box (+-inf = none).  kinks: per variable, the interior points at which f has a kink along it (the anchors
     of a shape parameter: the morph is linear between them).  A variable sitting ON one -- every fit starts there, the
@@ -450,7 +568,7 @@ def bestfit_batched(lf, points=None, guess=None, livetime_days=None, gtol=1e-6, 
         x, f, info = batched_minimize(obj, x0, lo, hi, gtol=gtol, max_iter=max_iter, kinks=kinks)
     else:
         rows_of = lambda k: np.tile(np.arange(P), k)
-        scout = lambda xx, rr: obj(xx, rr % P)                       # row r of the stacked problem set is problem r % P
+        scout = obj.stacked(P)                                       # row r of the stacked problem set is problem r % P
         xs, fs, _ = batched_minimize(scout, np.concatenate(starts), lo, hi, gtol=gtol, max_iter=scout_iterations, kinks=kinks)
         fs = np.where(np.isfinite(fs), fs, np.inf).reshape(n_st, P)
         keep = n_st if thorough else min(keep_starts + len(also_from), n_st)      # ('cells': every start runs to convergence)

@@ -218,6 +218,32 @@ int bi_eval_end(bi_ctx* ctx, double* out, int32_t* status);
 int bi_eval_grad(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, double* ll,
                  double* grad, int32_t* status);
 
+/* The batched profile-fit engine's inner loop (host code): P minimisations of F variables each advance in lock-step, every
+ * optimiser iteration ONE evaluation call over the problems still running -- what replaces the reference's loops of sequential
+ * scipy fits (bestfit_scipy, blueice/inference.py:131-178, inside one_parameter_interval / plot_likelihood_ratio, :332-443).
+ * BFGS per problem (Hessian estimate in direct form, exact reduced steps at bounds), Armijo backtracking with a ladder of
+ * three trial steps per call, box constraints lo / hi [F] (+-inf = none); `kinks` (n_kinks [F] counts, values concatenated,
+ * ascending; NULL = none): points along a variable where the function has a kink -- the interior anchors of a shape parameter,
+ * the morph is linear between them (pdf_morphers.py:67-70) -- at which both one-sided slopes are taken and steps end.
+ *   bi_minimize_batched   over a caller's objective: fun(user, n, F, x [n][F], rows [n], f [n], g [n][F]) evaluates f and its
+ *                         gradient for problems `rows` at `x`; non-zero return aborts.  Needs no context and no GPU.
+ *   bi_fit_batched        with the context's likelihood as the objective, f = -ll (bi_eval_grad), no caller code between the
+ *                         iterations: variable j is shape parameter var_index[j] (var_kind 0: z_i = x_j) or the rate
+ *                         multiplier of source var_index[j] (var_kind 1: rate_scale_s = x_j * unit[p][s]); z0 [P][d] and
+ *                         scale0 [P][S] are the problems' other settings, dataset [P] or NULL.  Points at which a
+ *                         Beeston-Barlow assertion would fire count as nan (to be stepped around), rejected points as +inf.
+ * x_out [P][F], f_out [P]; flags_out [P]: 1 converged (projected gradient below gtol, or the rounding floor), 2 stalled (no
+ * descent step / crawling across a kink), 4 failed (the start was not finite); counters [4]: iterations, evaluation calls,
+ * of which one-sided-slope calls, evaluations (bi_fit_batched) -- or NULL. */
+typedef int (*bi_objective_fn)(void* user, int64_t n, int F, const double* x, const int64_t* rows, double* f, double* g);
+int bi_minimize_batched(bi_objective_fn fun, void* user, int64_t P, int F, const double* x0, const double* lo, const double* hi,
+                        const int32_t* n_kinks, const double* kinks, double gtol, int max_iter, double* x_out, double* f_out,
+                        int32_t* flags_out, int64_t* counters);
+int bi_fit_batched(bi_ctx* ctx, int64_t P, int F, const int32_t* var_kind, const int32_t* var_index, const double* z0,
+                   const double* scale0, const double* unit, const int64_t* dataset, const double* x0, const double* lo,
+                   const double* hi, const int32_t* n_kinks, const double* kinks, double gtol, int max_iter, double* x_out,
+                   double* f_out, int32_t* flags_out, int64_t* counters);
+
 /* One parameter point against datasets [t0, t1): the toy-MC form.  mu_b / log mu_b are computed
  * once and every dataset reduces sum_b xlogy(n, mu) against them.  Not available with
  * Beeston-Barlow (mu then depends on the data).  out [t1 - t0]. */

@@ -249,3 +249,85 @@ def test_batched_minimize_starting_on_kinks():
     # without the kinks the one-sided slope at the start looks like a descent direction that is none
     x2, f2, info2 = batched_minimize(fun, np.zeros((7, 2)), lo, hi, gtol=1e-8)
     assert not info2['converged'][:3].all() and np.all(f <= f2 + 1e-12)
+
+
+# ---- the C++ loop (csrc/bi_fit.h) against the numpy form it was ported from ---------------------------------------------
+def _engine_cases():
+    rng = np.random.default_rng(3)
+    P, F = 60, 3
+    A = rng.normal(size=(P, F, F))
+    A = np.einsum('pij,pkj->pik', A, A) + 0.3 * np.eye(F)
+    c = rng.normal(size=(P, F)) * 2
+
+    def quad(x, rows):
+        dx = x - c[rows]
+        Ad = np.einsum('pij,pj->pi', A[rows], dx)
+        return 0.5 * np.sum(dx * Ad, axis=1), Ad
+
+    w = np.linspace(0.2, 3.0, P)
+    m = np.linspace(-1.5, 1.5, P)
+
+    def vee(x, rows):                                    # |x0| kinks at -1, 0, 1 scaled differently per problem
+        x0, x1, x2 = x[:, 0], x[:, 1], x[:, 2]
+        sign = np.where(x0 >= 0, 1.0, -1.0)
+        f = w[rows] * np.abs(x0) + (x0 - m[rows]) ** 2 + (x1 - 1) ** 2 + 0.5 * (x2 + 0.3 * x1) ** 2
+        g = np.stack([w[rows] * sign + 2 * (x0 - m[rows]), 2 * (x1 - 1) + 0.3 * (x2 + 0.3 * x1), x2 + 0.3 * x1], axis=1)
+        dead = rows == 7
+        return np.where(dead, np.nan, f), g
+
+    lo, hi = np.array([-2., -np.inf, 0.]), np.array([2., np.inf, np.inf])
+    return [('quadratics with bounds', quad, np.zeros((P, F)), lo, hi, None),
+            ('kinks', vee, np.zeros((P, F)), lo, hi, [np.array([-1., 0., 1.]), np.zeros(0), np.zeros(0)]),
+            ('kinks, off-kink start', vee, np.tile([0.4, -2.0, 1.0], (P, 1)), lo, hi, [np.array([-1., 0., 1.]), np.zeros(0), np.zeros(0)])]
+
+
+@pytest.mark.parametrize('case', range(3))
+def test_native_loop_equals_the_numpy_form(case):
+    """bi_minimize_batched is the numpy algorithm statement by statement: same iterates, same verdicts, same number of
+    evaluation calls (the linear solves differ in their last bits, so results agree to rounding, not bitwise)."""
+    from blueice_amd.profile import batched_minimize
+    name, fun, x0, lo, hi, kinks = _engine_cases()[case]
+    log = {'native': [], 'numpy': []}
+    out = {}
+    for engine in ('native', 'numpy'):
+        def counted(x, rows, engine=engine):
+            log[engine].append(len(rows))
+            return fun(x, rows)
+        out[engine] = batched_minimize(counted, x0, lo, hi, gtol=1e-8, max_iter=300, kinks=kinks, engine=engine)
+    (xa, fa, ia), (xb, fb, ib) = out['native'], out['numpy']
+    for k in ('converged', 'stalled', 'failed'):
+        np.testing.assert_array_equal(ia[k], ib[k], err_msg='%s: %s' % (name, k))
+    ok = ~ia['failed']
+    np.testing.assert_allclose(fa[ok], fb[ok], rtol=1e-9, atol=1e-12, err_msg=name)
+    np.testing.assert_allclose(xa[ok], xb[ok], rtol=1e-6, atol=1e-7, err_msg=name)
+    assert ia['calls'] == ib['calls'] == len(log['native']) == len(log['numpy'])
+    assert ia['kink_calls'] == ib['kink_calls'] and ia['iterations'] == ib['iterations']
+    assert log['native'] == log['numpy'], 'the two forms asked for different batches'
+
+
+def test_native_loop_carries_exceptions_and_options(d2):
+    from blueice_amd.profile import batched_minimize
+
+    def broken(x, rows):
+        if len(rows) < 5:
+            raise RuntimeError('objective failed')
+        return np.sum(x ** 2, axis=1) + np.where(rows % 2 == 0, 0.0, 1.0) * x[:, 0], 2 * x + np.where(rows % 2 == 0, 0.0, 1.0)[:, None] * np.array([1.0, 0.0])
+
+    with pytest.raises(RuntimeError, match='objective failed'):
+        batched_minimize(lambda x, rows: broken(x, rows[:3]) if False else (_ for _ in ()).throw(RuntimeError('objective failed')),
+                         np.ones((6, 2)), np.full(2, -5.), np.full(2, 5.))
+    # tuning options select the numpy form (the C++ loop has the defaults compiled in)
+    x, f, info = batched_minimize(broken, np.ones((6, 2)), np.full(2, -5.), np.full(2, 5.), c1=1e-3)
+    assert info['converged'].all()
+    # the whole engine on the likelihood stand-in, both forms
+    lf = OracleLikelihood(d2['model'], d2['counts'], ['shift', 'stretch'], analytic=True)
+    from blueice_amd import profile
+    res = {}
+    for engine in ('native', 'numpy'):
+        profile.ENGINE = engine
+        try:
+            res[engine] = profile.bestfit_batched(lf, points={'shift': np.linspace(-0.8, 0.8, 9)}, stretch=1.0, s2_rate_multiplier=1.0, return_info=True)
+        finally:
+            profile.ENGINE = 'native'
+    np.testing.assert_allclose(res['native'][1], res['numpy'][1], rtol=1e-9)
+    assert res['native'][2]['calls'] == res['numpy'][2]['calls']
