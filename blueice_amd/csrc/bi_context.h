@@ -138,7 +138,7 @@ struct bi_ctx {
     int32_t pending_status = 0;
 
     // device mirrors of the small tables the planning kernels read (bi_planning_device.h)
-    DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz, pt_rowsum;
+    DevBuf pt_grid, pt_mus, pt_coff, pt_allow, pt_c_off, pt_cnt_off, pt_c_np, pt_Tz, pt_rowsum, pt_rowmin, pt_nm_tot;
     int64_t plan_tables_epoch = -1;
     bool plan_tables_sparse = false;
     int64_t n_valid_launches = 0;                // how often the validity pass of a split scan ran

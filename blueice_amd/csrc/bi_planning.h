@@ -44,6 +44,8 @@ struct PlanItem {
 
 constexpr int kClassG[5] = {1, 2, 4, 8, 16};
 
+constexpr int kPlanNeedsHost = 1;   // plan_points_device: this batch needs the host planner (exact Beeston-Barlow totals) -- internal, not a code of the ABI
+
 int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset, bool sparse,
                        bi_plan** out, int share_rank, int share_world, bool resident, bool grad_mode);
 
@@ -80,15 +82,23 @@ int plan_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale,
         for (int64_t i = 0; i < P * S && !inf_scale; ++i) inf_scale = std::isinf(rate_scale[i]);
     if (share_world > 1) {       // a share of a dealt scan: the dealing IS the device planner's sort
         if (share_rank < 0 || share_rank >= share_world) return fail(c, BI_ERR_INVALID, "share %d outside [0,%d)", share_rank, share_world);
-        if (bb || inf_scale || P > (int64_t)1 << 30)
-            return fail(c, BI_ERR_INVALID, "shares of a scan are planned on the device: not available with Beeston-Barlow or infinite rate scales");
-        return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, share_rank, share_world, false, false);
+        if (inf_scale || P > (int64_t)1 << 30)
+            return fail(c, BI_ERR_INVALID, "shares of a scan are planned on the device: not available with infinite rate scales");
+        rc = plan_points_device(c, P, z, rate_scale, dataset, sparse, out, share_rank, share_world, false, false);
+        if (rc == kPlanNeedsHost)
+            return fail(c, BI_ERR_INVALID, "shares of a scan are planned on the device: this Beeston-Barlow batch has points at which some bin can "
+                                           "have U_b == 0 (or bb_exact = 1) and needs the host planner's exact totals");
+        return rc;
     }
-    if (!bb && !inf_scale && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
+    if (!inf_scale && c->device_plan_min > 0 && P >= c->device_plan_min && P <= (int64_t)1 << 30) {
         int64_t cells = 1;
         for (int ax : c->eff_axes) cells *= c->n_anchor[(size_t)ax] - 1;
         const int64_t groups = cells * (dataset ? c->T : 1);
-        if (groups <= P / 8) return plan_points_device(c, P, z, rate_scale, dataset, sparse, out, 0, 1, false, false);
+        // (Beeston-Barlow work items hold bb_max_group points: the device planner from 4 expected points per group on)
+        if (groups <= P / (bb ? 4 : 8)) {
+            rc = plan_points_device(c, P, z, rate_scale, dataset, sparse, out, 0, 1, false, false);
+            if (rc != kPlanNeedsHost) return rc;         // (else: exact Beeston-Barlow totals wanted -- the host planner below)
+        }
     }
 
     // ---- phase 1: per point geometry, rates, early exits (parallel) ---------------------------------

@@ -101,7 +101,7 @@ bool ensure_sorted_rows(bi_ctx* c) {
     return true;
 }
 
-constexpr int kDevG = 16;   // every device-planned work item has 16 slots (the last of a group is padded)
+constexpr int kDevG = 16;   // a device-planned work item has 16 slots (the last of a group is padded); Beeston-Barlow: bb_max_group
 
 struct PlanMeta {
     int d, S, de, nc, unbinned, sparse;
@@ -124,6 +124,10 @@ struct PlanMeta {
     int share_order;           // results in sorted order (perm = position in the share) instead of the caller's point order
     int linear_outside;        // the batch goes to k_scan_mfma: sum_b mu_b = sum_k coef_k * rowsum_k joins the per-point constant,
                                // and the kernel adds only the n log mu terms
+    int G;                     // slots per work item: 16, or bb_max_group for Beeston-Barlow models
+    int bb_source;             // -1, or the Beeston-Barlow source: streams [corner][s != bb], then its ps rows, then the n_model rows
+    const double* nm_tot;      // Beeston-Barlow: [A] per-anchor totals of the Monte-Carlo counts (N(z) is linear in the weights)
+    const double* rowmin;      // [n_rows] smallest entry of every template row (can some bin have U_b == 0 at a point?)
 };
 
 constexpr uint64_t kBadKey = ~0ull;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
                                                             const int64_t* __restrict__ dataset,
                                                             double* __restrict__ wts, double* __restrict__ rates,
                                                             uint64_t* __restrict__ keys, int64_t* __restrict__ idx,
-                                                            int32_t* __restrict__ status) {
+                                                            int32_t* __restrict__ status, unsigned long long* __restrict__ n_inf) {
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (p >= P) return;
     idx[p] = p;
@@ -192,6 +196,11 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
         }
         if (m.any_allow_neg && (!any_fin || tot < 0)) phys = false;
         if (!phys) st = BI_ST_UNPHYSICAL;
+        // an infinite rate that passes (a source may go negative: likelihood.py:403-415) is answered on the host, the way
+        // the reference evaluates it (inf_rate_value): such a batch is not for this planner
+        if (phys && m.any_allow_neg && n_inf)
+            for (int s = 0; s < m.S; ++s)
+                if (r[s] == __builtin_inf() || r[s] == -__builtin_inf()) { atomicAdd(n_inf, 1ull); break; }
     }
     status[p] = st;
     keys[p] = st ? kBadKey : (uint64_t)(cell * m.T + ds);
@@ -213,9 +222,9 @@ __global__ __launch_bounds__(kThreads) void k_plan_heads(const uint64_t* __restr
     if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? i : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_plan_item_heads(const int64_t* __restrict__ gstart, int64_t n, int64_t* __restrict__ ihead) {
+__global__ __launch_bounds__(kThreads) void k_plan_item_heads(const int64_t* __restrict__ gstart, int64_t n, int G, int64_t* __restrict__ ihead) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i < n) ihead[i] = ((i - gstart[i]) % kDevG == 0) ? 1 : 0;
+    if (i < n) ihead[i] = ((i - gstart[i]) % G == 0) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ keys,
@@ -225,41 +234,81 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
                                                         double* __restrict__ coef, int64_t* __restrict__ cnt_off,
                                                         int32_t* __restrict__ tiles, int64_t* __restrict__ perm,
                                                         double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum,
-                                                        int64_t* __restrict__ rowoff_full /* split scans, else NULL */) {
+                                                        int64_t* __restrict__ rowoff_full /* split scans, else NULL */,
+                                                        double* __restrict__ aux /* Beeston-Barlow: [items][G][2], else NULL */,
+                                                        unsigned long long* __restrict__ n_zero_u /* Beeston-Barlow, else NULL */) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const int64_t p = idx[i];
-    const int g = (int)((i - gstart[i]) % kDevG);
+    const int G = m.G;
+    const int g = (int)((i - gstart[i]) % G);
     const int64_t item = item_incl[i] - 1;
     const bool last_of_group = i + 1 == n || gstart[i + 1] == i + 1;
     const int64_t ds = (int64_t)(keys[i] % (uint64_t)m.T), cell = (int64_t)(keys[i] / (uint64_t)m.T);
-    const int NS = m.nc * m.S;
+    const bool bb = m.bb_source >= 0;
+    const int n0 = bb ? m.nc * (m.S - 1) : m.nc * m.S;
+    const int NS = bb ? n0 + 2 * m.nc : n0;
     const int64_t row_stride = m.sparse ? m.c_np[ds] : m.Bp;
     const int64_t row_base = m.sparse ? m.c_off[ds] : 0;
     const double* w = wts + p * m.nc;
     const double* r = rates + p * m.S;
     double zsum = 0.0, rsum = 0.0;
+    // the unused slots of a group's last work item repeat its last point (their results are dropped: perm = -1): with
+    // coefficients of zero their expectations would be zero, and the product forms of the scan kernels would have to leave
+    // their fast path for the whole item
+    const int g_end = last_of_group ? G : g + 1;
     int k = 0;
     for (int corner = 0; corner < m.nc; ++corner) {
         const int64_t a = cell + m.corner_off[corner];
         const double wc = w[corner];
 #pragma unroll 4
         for (int s = 0; s < m.S; ++s) {                     // (unrolled: the Tz loads of a corner go out together)
+            if (bb && s == m.bb_source) continue;
             const double cf = wc * r[s];
             const double tz = m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0);
-            coef[(item * NS + k + s) * kDevG + g] = cf;
-            // the unused slots of a group's last work item repeat its last point (their results are dropped: perm = -1):
-            // with coefficients of zero their expectations would be zero, and the product forms of the scan kernels
-            // would have to leave their fast path for the whole item
-            if (last_of_group)
-                for (int gg = g + 1; gg < kDevG; ++gg) coef[(item * NS + k + s) * kDevG + gg] = cf;
+            for (int gg = g; gg < g_end; ++gg) coef[(item * NS + k) * G + gg] = cf;
             if (m.sparse || m.linear_outside) zsum += cf * tz;
             if (g == 0) {
-                rowoff[item * NS + k + s] = row_base + (a * m.S + s) * row_stride;
-                if (rowoff_full) rowoff_full[item * NS + k + s] = (a * m.S + s) * m.Bp;
+                rowoff[item * NS + k] = row_base + (a * m.S + s) * row_stride;
+                if (rowoff_full) rowoff_full[item * NS + k] = (a * m.S + s) * m.Bp;
             }
+            ++k;
         }
-        k += m.S;
+    }
+    if (bb) {
+        // the Beeston-Barlow source's own template rows and its Monte-Carlo counts: coefficient = the corner weight
+        // (blueice/likelihood.py:643-646); N(z) = sum_c w_c N_c and p_cal = r_i / N travel per point (aux)
+        double Ntot = 0.0;
+        for (int corner = 0; corner < m.nc; ++corner) {
+            const int64_t a = cell + m.corner_off[corner];
+            for (int gg = g; gg < g_end; ++gg) {
+                coef[(item * NS + n0 + corner) * G + gg] = w[corner];
+                coef[(item * NS + n0 + m.nc + corner) * G + gg] = w[corner];
+            }
+            if (g == 0) {
+                rowoff[item * NS + n0 + corner] = (a * m.S + m.bb_source) * m.Bp;
+                rowoff[item * NS + n0 + m.nc + corner] = a * m.Bp;
+            }
+            const double term = m.nm_tot[a] * w[corner];
+            Ntot = Ntot + term;
+        }
+        for (int gg = g; gg < g_end; ++gg) {
+            aux[(item * G + gg) * 2 + 0] = r[m.bb_source] / Ntot;
+            aux[(item * G + gg) * 2 + 1] = Ntot;
+        }
+        // can some bin have U_b == 0 at this point (bb_zero_u_possible, bi_single.h)?  Then the reference's first-root
+        // assertion hangs on the last bits of N, which only the host planner's extra pass reproduces (bb_exact_totals)
+        bool zero_u = true;
+        for (int s = 0; s < m.S && zero_u; ++s) {
+            if (s == m.bb_source || !(r[s] > 0.0)) continue;
+            bool positive = true;
+            for (int corner = 0; corner < m.nc && positive; ++corner) {
+                if (!(w[corner] > 0.0)) continue;
+                positive = m.rowmin[(cell + m.corner_off[corner]) * m.S + s] > 0.0;
+            }
+            if (positive) zero_u = false;
+        }
+        if (zero_u && n_zero_u) atomicAdd(n_zero_u, 1ull);
     }
     for (int s = 0; s < m.S; ++s) rsum += r[s];
     if (g == 0) {
@@ -267,8 +316,8 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
         tiles[item] = (int32_t)(row_stride / kTile);
         atomicAdd(tile_sum, (unsigned long long)(row_stride / kTile));
     }
-    slot_lg[item * kDevG + g] = m.unbinned ? rsum : m.lgsum[ds] + zsum;
-    perm[item * kDevG + g] = m.share_order ? i : p;
+    slot_lg[item * G + g] = m.unbinned ? rsum : m.lgsum[ds] + zsum;
+    perm[item * G + g] = m.share_order ? i : p;
 }
 
 // group bookkeeping for the scan kernel: flag[i] = 1 at the first sorted position of every (cell, dataset) group
@@ -309,7 +358,8 @@ int ensure_plan_tables(bi_ctx* c) {
     for (int k = 0; k < nc; ++k) coff[(size_t)k] = corner_offset(c, k);
     if ((rc = dev_upload(c, c->pt_grid, grid)) || (rc = dev_upload(c, c->pt_mus, c->h_mus)) ||
         (rc = dev_upload(c, c->pt_coff, coff)) || (rc = dev_upload(c, c->pt_allow, c->allow_neg)) ||
-        (rc = dev_upload(c, c->pt_rowsum, c->h_rowsum)))
+        (rc = dev_upload(c, c->pt_rowsum, c->h_rowsum)) || (rc = dev_upload(c, c->pt_rowmin, c->h_rowmin)) ||
+        (c->bb_source >= 0 && (rc = dev_upload(c, c->pt_nm_tot, c->h_nm_tot))))
         return rc;
     if (c->compact_ready && ((rc = dev_upload(c, c->pt_c_off, c->h_c_off)) || (rc = dev_upload(c, c->pt_cnt_off, c->h_cnt_off)) ||
                              (rc = dev_upload(c, c->pt_c_np, c->h_c_np)) || (rc = dev_upload(c, c->pt_Tz, c->h_Tz))))
@@ -338,6 +388,10 @@ PlanMeta plan_meta_of(const bi_ctx* c, bool sparse) {
     m.c_off = (const int64_t*)c->pt_c_off.p; m.cnt_off = (const int64_t*)c->pt_cnt_off.p; m.c_np = (const int64_t*)c->pt_c_np.p;
     m.Tz = (const double*)c->pt_Tz.p;
     m.rowsum = (const double*)c->pt_rowsum.p;
+    m.rowmin = (const double*)c->pt_rowmin.p;
+    m.nm_tot = (const double*)c->pt_nm_tot.p;
+    m.bb_source = c->bb_source;
+    m.G = c->bb_source >= 0 ? (int)std::min<int64_t>(c->max_group, c->bb_max_group) : kDevG;
     return m;
 }
 
@@ -579,8 +633,13 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                        bi_plan** out, int share_rank, int share_world, bool resident, bool grad_mode) {
     int rc = ensure_plan_tables(c);
     if (rc) return rc;
-    const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de, NS = nc * S;
+    const int S = c->S, d = c->d, de = (int)c->eff_axes.size(), nc = 1 << de;
+    const bool bb = c->bb_source >= 0;
+    const int NS = bb ? nc * (S - 1) + 2 * nc : nc * S;      // Beeston-Barlow: the other sources' rows, its own template rows, its Monte-Carlo counts
+    // Beeston-Barlow with `bb_exact = 1` wants N(z) in numpy's summation order for every point: the host planner's extra pass
+    if (bb && c->bb_exact == 1) return kPlanNeedsHost;
     PlanMeta m = plan_meta_of(c, sparse);                    // (split scans switch m.sparse on below)
+    const int G = m.G;
 
     bi_plan* plan = new bi_plan();
     plan->P = P; plan->sparse = sparse; plan->epoch = c->epoch; plan->device_planned = true; plan->no_reuse = false;
@@ -613,8 +672,13 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     }
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning upload: %s", hipGetErrorString(e)));
     const unsigned nblk = (unsigned)((P + kThreads - 1) / kThreads);
+    // [0] n_valid  [1] n_items  [2] sum of tiles  [3] largest group (gradient batches)  [4] Beeston-Barlow points at which some
+    // bin can have U_b == 0  [5] points with an infinite rate that the reference evaluates (sources that may go negative)
+    int64_t* scal = (int64_t*)d_scal.p;
+    HIP_TRY(c, hipMemsetAsync(scal, 0, 64, c->stream));
     hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
-                       (double*)d_wts.p, (double*)d_rates.p, (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p);
+                       (double*)d_wts.p, (double*)d_rates.p, (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p,
+                       (unsigned long long*)(scal + 5));
     // sort (key, point) pairs: keys are cell * T + dataset, rejected points carry the largest key
     size_t tmp_bytes = 0;
     int end_bit = 64;
@@ -628,13 +692,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                   (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
-    int64_t* scal = (int64_t*)d_scal.p;   // [0] n_valid  [1] n_items  [2] sum of tiles
-    HIP_TRY(c, hipMemsetAsync(scal, 0, 64, c->stream));
     hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, scal);
-    int64_t h_scal[3] = {0, 0, 0};
+    int64_t h_scal[3] = {0, 0, 0}, h_inf = 0;
     e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_inf, scal + 5, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
+    if (h_inf > 0)
+        return abort_plan(fail(c, BI_ERR_INVALID, "%lld points carry an infinite rate of a source that may go negative: those are answered on "
+                                                  "the host (bi_plan_points / bi_eval with host arrays)", (long long)h_inf));
     const int64_t n_valid_all = h_scal[0];
     plan->n_bad = P - n_valid_all;
     // the share of this context: everything, or a contiguous range of the sorted list (the arrays below are windows on it)
@@ -659,7 +725,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, keys_s, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, rocprim::maximum<int64_t>(), c->stream);  // d_b = group start
-        hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
+        hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, G, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);               // d_keys = item index + 1
         e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
@@ -675,7 +741,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
         const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
-        const bool scan_shape = c->scan_mfma && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535;
+        const bool scan_shape = c->scan_mfma && !bb && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535;
         // Every bin visited, mostly empty data, several items per cell: split the scan into the non-empty-bin pass (the
         // descriptors below then describe the compacted rows, as for a sparse plan) and a validity pass over all bins on
         // the matrix cores (k_scan_valid).  The two together are exact for templates and rates of either sign.
@@ -694,7 +760,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         plan->sparse = compacted;
         plan->classes.emplace_back();
         bi_plan::Class& k = plan->classes.back();
-        k.G = kDevG;
+        k.G = G;
         k.n_items = n_items;
         const int n_tiles = n_tiles_of(c);
         const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
@@ -705,26 +771,33 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if (c->xcd_affine && n_items > 1 && nbx > 4 && nbx < max_tiles) nbx = std::min<int64_t>(max_tiles, (nbx + 7) / 8 * 8);
         k.nbx = (int)nbx;
         const size_t ni = (size_t)n_items;
-        if ((rc = dev_alloc(c, k.rowoff, ni * NS * 8)) || (rc = dev_alloc(c, k.coef, ni * NS * kDevG * 8)) || (rc = dev_alloc(c, k.aux, ni * kDevG * 16)) ||
-            (rc = dev_alloc(c, k.item_cnt, ni * 8)) || (rc = dev_alloc(c, k.item_tiles, ni * 4)) || (rc = dev_alloc(c, k.perm, ni * kDevG * 8)) ||
-            (rc = dev_alloc(c, k.slot_lg, ni * kDevG * 8)) ||
-            (!grad_mode && ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double))) ||
-                            (rc = dev_alloc(c, k.pflags, ni * k.nbx * kDevG * sizeof(unsigned))))) ||
+        if ((rc = dev_alloc(c, k.rowoff, ni * NS * 8)) || (rc = dev_alloc(c, k.coef, ni * NS * G * 8)) || (rc = dev_alloc(c, k.aux, ni * G * 16)) ||
+            (rc = dev_alloc(c, k.item_cnt, ni * 8)) || (rc = dev_alloc(c, k.item_tiles, ni * 4)) || (rc = dev_alloc(c, k.perm, ni * G * 8)) ||
+            (rc = dev_alloc(c, k.slot_lg, ni * G * 8)) ||
+            (!grad_mode && ((rc = dev_alloc(c, k.partial, ni * k.nbx * G * sizeof(double))) ||
+                            (rc = dev_alloc(c, k.pflags, ni * k.nbx * G * sizeof(unsigned))))) ||
             (split && (rc = dev_alloc(c, k.rowoff_full, ni * NS * 8))))
             return abort_plan(rc);
-        e = hipMemsetAsync(k.coef.p, 0, ni * NS * kDevG * 8, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(k.perm.p, 0xFF, ni * kDevG * 8, c->stream);     // -1: padding slots
-        if (e == hipSuccess) e = hipMemsetAsync(k.slot_lg.p, 0, ni * kDevG * 8, c->stream);
+        e = hipMemsetAsync(k.coef.p, 0, ni * NS * G * 8, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(k.perm.p, 0xFF, ni * G * 8, c->stream);     // -1: padding slots
+        if (e == hipSuccess) e = hipMemsetAsync(k.slot_lg.p, 0, ni * G * 8, c->stream);
+        if (e == hipSuccess && bb) e = hipMemsetAsync(k.aux.p, 0, ni * G * 16, c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
         hipLaunchKernelGGL(k_plan_fill, dim3(vblk), dim3(kThreads), 0, c->stream, m, n_valid, keys_s,
                            idx_s, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, (const double*)d_wts.p,
                            (const double*)d_rates.p, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
                            (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
-                           split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr);
+                           split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr, bb ? (double*)k.aux.p : (double*)nullptr,
+                           bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr);
         e = hipGetLastError();
+        int64_t h_zero_u = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
+        // Beeston-Barlow points at which some bin can have U_b == 0: the reference's first-root assertion then hangs on the
+        // last bits of N(z), which only the host planner's pass in numpy's summation order reproduces (bb_exact_totals)
+        if (bb && c->bb_exact && h_zero_u > 0) return abort_plan(kPlanNeedsHost);
         plan->bytes = (int64_t)sizeof(double) * ((int64_t)NS + 1) * (compacted ? h_scal[2] * kTile : n_items * c->B);
         plan->launches = (n_items + 65534) / 65535;
 

@@ -128,7 +128,7 @@ void bi_destroy(bi_ctx* c) {
     dev_free(c->pack_dev);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
-    dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum);
+    dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum); dev_free(c->pt_rowmin); dev_free(c->pt_nm_tot);
     for (void* q : c->user_allocs) (void)hipFree(q);   // bi_device_alloc buffers nobody freed
     c->user_allocs.clear();
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
@@ -508,10 +508,8 @@ int bi_plan_points_resident(bi_ctx* c, int64_t P, const double* z_dev, const dou
     if (share_world < 1 || share_rank < 0 || share_rank >= share_world)
         return fail(c, BI_ERR_INVALID, "share %d outside [0,%d)", share_rank, share_world);
     if (c->d > 0 && P > 0 && !z_dev) return fail(c, BI_ERR_INVALID, "z_dev is NULL");
-    if (c->bb_source >= 0) return fail(c, BI_ERR_INVALID, "resident points are planned on the device: not available with Beeston-Barlow");
     bool any_neg = false;
     for (int q = 0; q < c->S; ++q) any_neg |= (c->allow_neg[(size_t)q] != 0);
-    if (any_neg) return fail(c, BI_ERR_INVALID, "resident points are planned on the device: not available with sources that may have negative rates");
     HIP_TRY(c, hipSetDevice(c->device));
     if (P == 0) return plan_points(c, 0, nullptr, nullptr, nullptr, out);
     const void* ptrs[3] = {c->d > 0 ? (const void*)z_dev : nullptr, rate_scale_dev, dataset_dev};
@@ -525,11 +523,17 @@ int bi_plan_points_resident(bi_ctx* c, int64_t P, const double* z_dev, const dou
             return fail(c, BI_ERR_INVALID, "%s is not device memory of GPU %d", names[i], c->device);
         }
     }
-    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !c->unbinned;
+    const bool sparse = c->sparse && c->compact_ready && c->ps_nonneg && !c->unbinned && c->bb_source < 0 && !any_neg;
     if (!sparse && !c->dense_counts)
         return fail(c, BI_ERR_STATE, "the datasets exist only as non-empty-bin lists (device-generated toys): point "
                                      "evaluations need the compacted templates (sparse mode, budget) or bi_eval_datasets");
-    return plan_points_device(c, P, z_dev, rate_scale_dev, dataset_dev, sparse, out, share_rank, share_world, true, false);
+    // (sources that may go negative: an infinite rate among the points is found by the planner itself and refused;
+    //  Beeston-Barlow: refused when some point needs the host planner's exact totals)
+    rc = plan_points_device(c, P, z_dev, rate_scale_dev, dataset_dev, sparse, out, share_rank, share_world, true, false);
+    if (rc == kPlanNeedsHost)
+        return fail(c, BI_ERR_INVALID, "resident points are planned on the device: this Beeston-Barlow batch has points at which some bin can "
+                                       "have U_b == 0 (or bb_exact = 1) and needs the host planner's exact totals (bi_plan_points)");
+    return rc;
 }
 
 int bi_plan_share_info(const bi_plan* p, int64_t* n_valid, int64_t* lo, int64_t* hi) {

@@ -402,7 +402,8 @@ class DeviceContext:
     def plan_resident(self, P, z, rate_scale=None, dataset=None, rank=0, world=1):
         """plan() / plan_share() for points that are already in HBM: `z` [P][d] (and `rate_scale` [P][S], `dataset`
         [P] int64) are DeviceBuffers (or device addresses) on this GPU, read where they lie.  world > 1: this rank's
-        share of a dealt scan, as plan_share.  Plain likelihoods only (no Beeston-Barlow, no negative-rate sources)."""
+        share of a dealt scan, as plan_share.  Always planned on the device: a batch with infinite rates of a source that may go
+        negative, or with Beeston-Barlow points that need the host planner's exact totals, is refused (ValueError)."""
         def addr(b, item_bytes, what):
             if b is None:
                 return None

@@ -114,7 +114,9 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
     host pass over the points.  The ranks' result vectors (sorted order) are gathered -- RCCL on the context's stream
     between device buffers when `comm` offers all_gather_device, else through the host communicator -- and one kernel
     scatters them into the caller's point order (`EvalPlan.unsort`); the [P] vector crosses PCIe once.
-    Beeston-Barlow models are planned on the host: their points are dealt there (deal_points_by_cell)."""
+    Batches the device planner refuses -- infinite rate scales of a source that may go negative, Beeston-Barlow points that
+    need the host planner's exact totals (bins with U_b == 0 possible) -- are dealt on the host instead
+    (deal_points_by_cell), on every rank alike."""
     z = np.atleast_2d(np.asarray(z, dtype=float))
     rate_scale = np.atleast_2d(np.asarray(rate_scale, dtype=float))
     rank, world = _world(comm)
@@ -142,7 +144,7 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
             return ST_INTERNAL
 
     plan = None
-    if world > 1 and ctx.bb_source < 0 and P > 0:
+    if world > 1 and P > 0:
         # The device planner may refuse the batch (infinite rate scales of a source that may go negative are answered on
         # the host: BI_ERR_INVALID) or fail on one rank only (memory): the ranks agree before anybody takes a route, and
         # if any of them has no plan ALL take the host-dealt route below, which answers such points

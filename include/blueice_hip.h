@@ -280,7 +280,10 @@ int bi_run_plan(bi_ctx* ctx, bi_plan* plan, double* out_dev /* NULL: internal bu
  * most two neighbouring ranks) and no host pass over the points is needed.  bi_run_plan then writes hi - lo results in
  * SORTED order to out_dev[0 .. hi - lo); after the ranks' vectors have been gathered into [share_world][stride]
  * (stride >= ceil(n_valid / share_world)), bi_plan_unsort scatters them into the caller's point order, full_dev [P]
- * (rejected points: -inf), on the context's stream.  Plain binned / unbinned likelihoods (no Beeston-Barlow). */
+ * (rejected points: -inf), on the context's stream.  Beeston-Barlow models too (blueice/likelihood.py:618-660: work items of
+ * bb_max_group points, N(z) from the per-anchor totals), unless some point of the batch can have a bin with U_b == 0 -- there
+ * the reference's first-root assertion hangs on the last bits of N, which only the host planner's pass in numpy's summation
+ * order reproduces: BI_ERR_INVALID then, as for infinite rate scales (the caller deals such a scan on the host). */
 int bi_plan_points_share(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, const int64_t* dataset,
                          int share_rank, int share_world, bi_plan** out);
 int bi_plan_share_info(const bi_plan* plan, int64_t* n_valid, int64_t* lo, int64_t* hi);
@@ -289,8 +292,9 @@ int bi_plan_share_info(const bi_plan* plan, int64_t* n_valid, int64_t* lo, int64
  * read where they lie -- no host pass, no copy; they may be freed or overwritten as soon as the call returns.
  * share_world = 1: the whole batch (bi_plan_points); > 1: this rank's share of a dealt scan (bi_plan_points_share).
  * Always planned on the device, so the restrictions of the device planner apply as errors instead of a silent host path:
- * no Beeston-Barlow model, no source that may have a negative rate (likelihood.py:403-415: their infinite rate scales
- * are answered on the host), P <= 2^30; BI_ERR_INVALID as well for a pointer that is not device memory of this GPU.
+ * no point with an infinite rate of a source that may go negative (likelihood.py:403-415: those are answered on the host),
+ * no Beeston-Barlow point that needs exact totals (see bi_plan_points_share), P <= 2^30; BI_ERR_INVALID as well for a
+ * pointer that is not device memory of this GPU.
  * The batched callers of the reference hold their points in numpy arrays (inference.py:424-432), so this entry has no
  * counterpart there: it is for drivers that produce hypotheses on the device or reuse one grid for many datasets. */
 int bi_plan_points_resident(bi_ctx* ctx, int64_t P, const double* z_dev, const double* rate_scale_dev,

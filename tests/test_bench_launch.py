@@ -96,7 +96,7 @@ def test_two_ranks_on_one_gpu_end_to_end():
     assert set(legs) >= {'C4', 'C4-dense', 'C3', 'C5-BB', 'C5-BB-scan'}
     assert legs['C4']['dealing'].startswith('device planner') and legs['C4']['points'] == 10 ** 6
     assert sum(legs['C4']['points_per_rank_min_max']) == 10 ** 6
-    assert legs['C5-BB-scan']['dealing'].startswith('host') and sum(legs['C5-BB-scan']['points_per_rank_min_max']) == 256
+    assert legs['C5-BB-scan']['dealing'].startswith('device planner') and sum(legs['C5-BB-scan']['points_per_rank_min_max']) == 256
     assert legs['C3']['datasets'] == 10000
     for leg in ('C4', 'C4-dense', 'C5-BB-scan'):
         assert legs[leg]['sample_max_rel_diff_vs_single_point_kernel'] <= 1e-11

@@ -344,22 +344,135 @@ def test_points_resident_in_hbm_equal_host_points(sparse):
     assert np.isfinite(b.read()[0]).all()
     a.close(); b.close()
     cu.close()
-    # Beeston-Barlow models and sources with negative rates are planned on the host: refused, not rerouted
-    bb = SyntheticModel.named('mini3', bb_source=0)
-    c2 = DeviceContext(0)
-    bb.upload(c2)
-    c2.upload_counts(bb.counts(dense=True))
-    zz, rr = bb.random_points(600, seed=1)
-    bz, br = c2.device_alloc(zz.nbytes), c2.device_alloc(rr.nbytes)
-    bz.from_host(zz); br.from_host(rr)
-    with pytest.raises(ValueError, match='Beeston-Barlow'):
-        c2.plan_resident(600, bz, br)
-    c2.close()
-    c3 = DeviceContext(0)
-    m.upload(c3)
-    c3.set_allow_negative(np.array([1] + [0] * (m.S - 1)))
-    c3.upload_counts(m.counts(dense=True))
-    bz, br = c3.device_alloc(zz.nbytes), c3.device_alloc(rr.nbytes)
-    with pytest.raises(ValueError, match='negative rates'):
-        c3.plan_resident(600, bz, br)
-    c3.close()
+    # (Beeston-Barlow models and sources that may go negative are planned on the device as well since round 4: the tests
+    #  below; what is still refused -- with a reason -- are batches that need the host: exact Beeston-Barlow totals,
+    #  infinite rates)
+
+
+# ---- the device planner takes Beeston-Barlow and negative-rate models ("Next round" 7) -------------------
+def _bb_context(zero_u=False):
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini4bb', bb_source=0)
+    ctx = DeviceContext(0)
+    if zero_u:
+        # exact zeros in the other sources' templates: bins with U_b == 0 become possible, the reference's first-root
+        # assertion then hangs on the last bits of N(z)
+        dense = m.dense_model()
+        ps = dense['ps'].copy()
+        ps[..., 1:, 3] = 0.0
+        ps[..., 1:, 7] = 0.0
+        ctx.upload_model(dense['anchor_z'], ps, dense['mus'], dense['n_model'], bb_source=0)
+    else:
+        m.upload(ctx)
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(m.counts(dense=True))
+    return m, ctx
+
+
+def test_beeston_barlow_scan_dealt_on_the_device_equals_one_plan():
+    """bi_plan_points_share / bi_plan_points_resident on a Beeston-Barlow model (blueice/likelihood.py:618-660): work items of
+    bb_max_group points, N(z) and p_cal per point from the per-anchor totals -- against the host planner (small batches) and
+    the single-point kernel, assertion status bits included."""
+    m, ctx = _bb_context()
+    z, r = m.random_points(1500, seed=5)
+    z[11, 0] = 9.0                         # outside the box
+    r[12, 1] = -2.0                        # unphysical
+    P = len(z)
+    ctx.set_param('device_plan_min', 0)    # the host planner (8 points per work item, exact totals where needed)
+    want, want_st = ctx.eval(z, r)
+    ctx.set_param('device_plan_min', 512)
+    got, got_st = ctx.eval(z, r)           # the same batch, now planned on the device
+    np.testing.assert_array_equal(got_st, want_st)
+    keep = np.isfinite(want)
+    assert keep.sum() == P - 2 and np.isneginf(got[[11, 12]]).all()
+    np.testing.assert_allclose(got[keep], want[keep], rtol=1e-12)
+    for i in (0, 500, 1499):
+        one, st1 = ctx.eval(z[i], r[i])
+        assert st1[0] == got_st[i] and abs(one[0] - got[i]) <= 1e-12 * abs(one[0])
+    for world in (2, 3):
+        stride = -(-P // world)
+        send, recv, full = ctx.device_alloc(8 * stride), ctx.device_alloc(8 * stride * world), ctx.device_alloc(8 * P)
+        recv.from_host(np.full(stride * world, np.nan))
+        spans = []
+        for rank in range(world):
+            plan = ctx.plan_share(z, r, None, rank, world)
+            assert plan.n_valid == P - 2
+            spans.append(plan.share)
+            plan.run(send.ptr)
+            assert plan.status() & ~(3 | 4 | 8) == 0
+            recv.from_host(send.to_host(np.float64, plan.share[1] - plan.share[0]), offset_bytes=8 * stride * rank)
+            last = plan
+        assert spans[0][0] == 0 and spans[-1][1] == P - 2 and max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+        last.unsort(recv.ptr, stride, full.ptr)
+        shared = full.to_host(np.float64, P)
+        np.testing.assert_allclose(shared[keep], want[keep], rtol=1e-12)
+        assert np.isneginf(shared[[11, 12]]).all()
+    # points already in HBM
+    bz, br = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes)
+    bz.from_host(z); br.from_host(r)
+    plan = ctx.plan_resident(P, bz, br)
+    plan.run()
+    res, res_st = plan.read()
+    np.testing.assert_allclose(res[keep], want[keep], rtol=1e-12)
+    np.testing.assert_array_equal(res_st, want_st)
+    ctx.close()
+
+
+def test_device_planner_leaves_exact_totals_to_the_host():
+    """Where some bin can have U_b == 0 the device planner steps back: large host-array batches silently take the host
+    planner (same values, same assertion bits as small ones), shares and resident points are refused with a reason -- and
+    sharded_scan_device then deals on the host (tests/test_sharding.py scripts that agreement)."""
+    m, ctx = _bb_context(zero_u=True)
+    z, r = m.random_points(1200, seed=6)
+    ctx.set_param('device_plan_min', 0)
+    want, want_st = ctx.eval(z, r)
+    ctx.set_param('device_plan_min', 512)
+    got, got_st = ctx.eval(z, r)
+    np.testing.assert_array_equal(got_st, want_st)
+    ok = np.isfinite(want)
+    np.testing.assert_array_equal(got[ok], want[ok])              # the same planner in the end: the same bits
+    with pytest.raises(ValueError, match='exact totals'):
+        ctx.plan_share(z, r, None, 0, 2)
+    bz, br = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes)
+    bz.from_host(z); br.from_host(r)
+    with pytest.raises(ValueError, match='exact totals'):
+        ctx.plan_resident(len(z), bz, br)
+    ctx.close()
+
+
+def test_device_planner_takes_sources_that_may_go_negative():
+    """allow_negative sources (blueice/likelihood.py:403-415): finite rates of either sign are planned on the device, shares and
+    resident points included; an INFINITE rate is the host's to answer, and the planner says so."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel.named('mini3')
+    ctx = DeviceContext(0)
+    m.upload(ctx)
+    ctx.set_allow_negative([0, 1, 0, 0])
+    ctx.set_param('sparse', 0)
+    ctx.upload_counts(m.counts(dense=True))
+    z, r = m.random_points(1400, seed=8)
+    r[::7, 1] = -0.05                       # a little negative: legal for source 1
+    ctx.set_param('device_plan_min', 0)
+    want, want_st = ctx.eval(z, r)
+    ctx.set_param('device_plan_min', 512)
+    bz, br = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes)
+    bz.from_host(z); br.from_host(r)
+    plan = ctx.plan_resident(len(z), bz, br)
+    plan.run()
+    got, got_st = plan.read()
+    np.testing.assert_array_equal(got_st, want_st)
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-12)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    r2 = r.copy()
+    r2[3, 1] = np.inf
+    br.from_host(r2)
+    with pytest.raises(ValueError, match='infinite rate'):
+        ctx.plan_resident(len(z), bz, br)
+    with pytest.raises(ValueError, match='infinite rate'):
+        ctx.plan_share(z, r2, None, 0, 2)
+    both, _ = ctx.eval(z, r2)               # host arrays: answered on the host the reference's way
+    assert np.array_equal(np.isfinite(both[ok & (np.arange(len(z)) != 3)]), np.ones((ok & (np.arange(len(z)) != 3)).sum(), bool))
+    ctx.close()
