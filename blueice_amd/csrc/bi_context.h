@@ -113,6 +113,7 @@ struct bi_ctx {
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
     bool tm_ok = false;                       // ... and whether every count fits its 19 bits
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
+    int64_t dot_lanes = 8;                    // parameter: lanes per (dataset, tile) run of the tiled kernel: 8 (96 entry slots) or 16 (128)
     int64_t toy_events = 1;                   // parameter: toys of sparse expectations are drawn event by event (0 = always one draw per bin)
     int64_t last_toy_method = 0;              // read-only: 1 = the last bi_generate_toys drew event by event, 0 = bin by bin
     std::vector<int64_t> h_nz_off;            // [T+1]

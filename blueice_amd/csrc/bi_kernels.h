@@ -1365,17 +1365,48 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
 // order with fma: a fixed order, independent of the launch geometry.
 typedef uint32_t bi_uint4 __attribute__((ext_vector_type(4)));
 constexpr int kDotThreads = 1024;
-constexpr int kDotAhead = 2;                   // 16-byte loads per lane requested up front: 2 x 64 = 128 entries per run
-constexpr int kDotPad = 64 * kDotAhead + 16;   // entries behind the lists that the read-ahead may touch (read, masked, never used)
+constexpr int kDotPad = 64 * 2 + 16;           // entries behind the lists that the read-ahead may touch (read, masked, never used): the largest of the variants below
 
+// sum over the L lanes of a group inside a 16-lane DPP row (L = 16, or 8: groups start at lanes 0 and 8) on the cross-lane
+// data path; every lane of the group ends up with the total.  L = 16: four rotate-and-add steps; L = 8: the mirror image
+// within the half row (lane i <-> 7 - i), then the two exchanges within quads -- three steps, in a fixed order.
+template <int L>
+__device__ __forceinline__ double row_group_sum(double v) {
+#define BI_DPP_ADD(CTRL)                                                                                           \
+    do {                                                                                                           \
+        const unsigned long long u = __double_as_longlong(v);                                                      \
+        const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);                \
+        const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);        \
+        v += __longlong_as_double(((unsigned long long)hi << 32) | lo);                                            \
+    } while (0)
+    if constexpr (L == 16) {
+        BI_DPP_ADD(0x120 + 8);        // row_ror:8
+        BI_DPP_ADD(0x120 + 4);
+        BI_DPP_ADD(0x120 + 2);
+        BI_DPP_ADD(0x120 + 1);
+    } else {
+        static_assert(L == 8, "groups of 8 or 16 lanes");
+        BI_DPP_ADD(0x141);            // row_half_mirror
+        BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
+        BI_DPP_ADD(0x4E);             // quad_perm:[2,3,0,1]
+    }
+#undef BI_DPP_ADD
+    return v;
+}
+
+// L lanes per (dataset, tile) run, AHEAD 16-byte loads per lane requested up front: 4 L AHEAD entry slots per run.
+// <16, 2>: 128 slots, 64 runs in flight per block (round 3).  <8, 3>: 96 slots -- a run at C2 is ~76 entries, so 79 % of the
+// slots carry an entry instead of 59 % --, 128 runs in flight per block, three rotate-and-add steps instead of four (round 4).
+template <int L, int AHEAD>
 __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_t* __restrict__ tm_entries,
                                                                    const int64_t* __restrict__ tm_off, int64_t T, int n_tl,
                                                                    const double* __restrict__ logmu, int64_t B, int64_t t0,
                                                                    int64_t n, double* __restrict__ partial /*[n_tl][n]*/) {
+    static_assert(4 * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
     __shared__ double s_mu[kDotTile];
     const int tl = blockIdx.x;
     const int64_t bin0 = (int64_t)tl * kDotTile;
-    const int row = threadIdx.x >> 4, gl = threadIdx.x & 15;           // 64 rows of 16 lanes
+    const int row = threadIdx.x / L, gl = threadIdx.x % L;             // kDotThreads / L rows of L lanes
     const int per = (int)((n + gridDim.y - 1) / gridDim.y);
     const int c0u = (int)blockIdx.y * per, c1 = min((int)n, c0u + per);
     const int c0 = min(c0u, (int)n - 1);                               // (clamped: a block without datasets still loads validly)
@@ -1384,7 +1415,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
     const uint32_t* __restrict__ ent = tm_entries + base;
     const uint32_t* __restrict__ off32 = reinterpret_cast<const uint32_t*>(off);   // low words: all a block-relative index needs
     const uint32_t base32 = (uint32_t)base;
-    constexpr int kStep = kDotThreads / 16, kAhead = kDotAhead, kRing = 6;
+    constexpr int kStep = kDotThreads / L, kAhead = AHEAD, kRing = 6;
     const int q_last = max(c0, c1 - 1);
     // (a step only ISSUES loads into the rings; whatever touches a loaded value -- the subtraction of the base, the mask
     //  of the entries past the run's end -- happens in the step that consumes it, two or four steps later: the compiler
@@ -1394,11 +1425,11 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
         ra = off32[2 * qc];
         rb = off32[2 * qc + 2];
     };
-    // (a lane takes four consecutive entries per load: a row's load covers 256 contiguous bytes of its run)
+    // (a lane takes four consecutive entries per load: a group's load covers 16 L contiguous bytes of its run)
     auto load_entries = [&](uint32_t ra, bi_uint4 (&e)[kAhead]) {
         const uint32_t* __restrict__ p = ent + (int)(ra - base32) + 4 * gl;
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + 64 * k, 16);     // (4-byte aligned 16-byte load)
+        for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + 4 * L * k, 16);     // (4-byte aligned 16-byte load)
     };
     bi_uint4 E[3][kAhead];
     uint32_t RA[kRing], RB[kRing];
@@ -1435,12 +1466,12 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
                 for (int k = 0; k < 4 * kAhead; ++k) lm[k] = s_mu[e[k >> 2][k & 3] & (kDotTile - 1)];      // LDS reads in flight together
 #pragma unroll
                 for (int k = 0; k < 4 * kAhead; ++k)
-                    s = __builtin_fma((double)(64 * (k >> 2) + (k & 3) < len ? e[k >> 2][k & 3] >> 13 : 0u), lm[k], s);
-                for (int j = a + gl + 64 * kAhead; j < b; j += 16) {                        // (runs beyond 128 entries)
+                    s = __builtin_fma((double)(4 * L * (k >> 2) + (k & 3) < len ? e[k >> 2][k & 3] >> 13 : 0u), lm[k], s);
+                for (int j = a + gl + 4 * L * kAhead; j < b; j += L) {                      // (runs beyond 4 L AHEAD entries)
                     const uint32_t x = ent[j];
                     s = __builtin_fma((double)(x >> 13), s_mu[x & (kDotTile - 1)], s);
                 }
-                s = row16_sum(s);
+                s = row_group_sum<L>(s);
                 if (gl == 0 && q < c1) partial[(int64_t)tl * n + q] = s;
             }
         }

@@ -63,6 +63,7 @@ const ParamDef kParams[] = {
     {"bb_exact", kParamRW, BI_P_GET(c->bb_exact), BI_P_RANGE(0, 2, bb_exact, "bb_exact: 0 never, 1 always, 2 auto")},
     {"toy_events", kParamRW, BI_P_GET(c->toy_events), BI_P_FLAG(toy_events)},
     {"dot_tiled", kParamRW, BI_P_GET(c->dot_tiled), BI_P_FLAG(dot_tiled)},
+    {"dot_lanes", kParamRW, BI_P_GET(c->dot_lanes), BI_P_SET(c->dot_lanes = v == 16 ? 16 : 8)},
     {"compact_budget", kParamRW, BI_P_GET(c->compact_budget), BI_P_SET(c->compact_budget = v)},
     {"toy_offset", kParamRW, BI_P_GET(c->toy_offset), BI_P_RANGE(0, INT64_MAX, toy_offset, "toy_offset >= 0")},
     {"mail_timeout_ms", kParamRW, BI_P_GET(c->mail_timeout_ms),

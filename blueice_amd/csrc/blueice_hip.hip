@@ -1170,9 +1170,14 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
                 // (and few enough datasets per block for its 32-bit entry indices: datasets x kDotTile < 2^31)
                 const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((ni + 255) / 256, 2 * (int64_t)c->prop.multiProcessorCount / n_tl),      // two resident blocks per CU (64 KB of LDS each): ONE round, every block's start-up paid once
                                                                  (ni + 262143) / 262144});
-                hipLaunchKernelGGL(k_dataset_dot_tiled, dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
-                                   (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
-                                   (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
+                if (c->dot_lanes == 8)
+                    hipLaunchKernelGGL((k_dataset_dot_tiled<8, 3>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
+                                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
+                                       (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
+                else
+                    hipLaunchKernelGGL((k_dataset_dot_tiled<16, 2>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
+                                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
+                                       (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
             } else if (csr)
                 hipLaunchKernelGGL(k_dataset_dot_csr, dim3((unsigned)ni), dim3(kThreads), 0, c->stream,
                                    (const int32_t*)c->nz_idx.p, (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p,

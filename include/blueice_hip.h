@@ -378,6 +378,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     default); 0 = always one Poisson draw per bin.  Read-only `last_toy_method`: 1 / 0 for the last call.
  *   dot_tiled         bi_eval_datasets over non-empty-bin lists: batches of >= 64 datasets take the kernel that stages bin tiles
  *                     of log mu in LDS over tile-major lists (1, default); 0 = always one block per dataset
+ *   dot_lanes         ... lanes per (dataset, tile) run of that kernel: 8 (96 entry slots per run, 128 runs in flight per block;
+ *                     default) or 16 (128 slots, 64 runs in flight: round 3)
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows
  *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
  *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)

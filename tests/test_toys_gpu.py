@@ -176,6 +176,11 @@ def test_tiled_dataset_kernel_random_shapes(seed):
         rows, _ = ctx.eval_datasets(None, [1.3])
         ctx.set_param('dot_tiled', 1)
         np.testing.assert_allclose(tiled, rows, rtol=1e-13, atol=0)
+        assert ctx.get_param('dot_lanes') == 8                        # (the default: 8 lanes per run, 96 entry slots)
+        ctx.set_param('dot_lanes', 16)                                # round 3's shape: 16 lanes, 128 slots
+        wide, _ = ctx.eval_datasets(None, [1.3])
+        ctx.set_param('dot_lanes', 8)
+        np.testing.assert_allclose(wide, rows, rtol=1e-13, atol=0)
         lo, hi = sorted(rng.choice(T - 64, 2, replace=False))
         part, _ = ctx.eval_datasets(None, [1.3], int(lo), int(hi) + 64)
         np.testing.assert_array_equal(part, tiled[lo:hi + 64])

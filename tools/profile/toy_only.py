@@ -14,6 +14,8 @@ z, r = m.default_point()
 ctx.set_param('sparse', 1)
 if len(sys.argv) > 2:
     ctx.set_param('toy_events', int(sys.argv[2]))      # 0: the bin-by-bin generator
+if len(sys.argv) > 3:
+    ctx.set_param('dot_lanes', int(sys.argv[3]))       # 8 (default) or 16 lanes per (dataset, tile) run
 ctx.generate_toys(z, r, 10000, seed=4242)
 out = ctx.device_alloc(8 * 10000)
 for k in range(3):
@@ -27,6 +29,6 @@ ctx.sync()
 dt = (time.perf_counter() - t) / n
 launches, ms = ctx.profile_read(); ctx.profile(False)
 res = out.to_host(np.float64, 10000)
-print('10^4 toys per call: %.3f ms per call wall (%.1f M evaluations/s), kernels %.3f ms per call by HIP events (%d launches); checksum %.6f' % (
-    dt * 1e3, 1e4 / dt / 1e6, ms / n, launches, float(res.sum())))
+print('dot_lanes %d; 10^4 toys per call: %.3f ms per call wall (%.1f M evaluations/s), kernels %.3f ms per call by HIP events (%d launches); checksum %.6f' % (
+    ctx.get_param('dot_lanes'), dt * 1e3, 1e4 / dt / 1e6, ms / n, launches, float(res.sum())))
 out.free(); ctx.close()
