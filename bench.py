@@ -739,7 +739,7 @@ def main():
     # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from the
     # committed summary of the same command (profiles/), corrected as MI355X_MICROARCH.md prescribes
     traffic = traffic_src = None
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 pm = json.load(f)

@@ -1829,6 +1829,8 @@ __global__ __launch_bounds__(kThreads) void k_histogram(const double* __restrict
 //             -ffp-contract=off), so the bits are scipy's.
 struct ScoreArgs {
     int k, method;
+    int clip;                    // 'linear': clip the coordinates to [first centre, last centre] HERE, as HistogramPdfSource.pdf does
+                                 // (blueice/source.py:231-239) -- events simulated on the device keep their true coordinates
     int n_grid[kMaxDim];
     int grid_off[kMaxDim];
     int64_t stride[kMaxDim];     // bins (C order) per step along the axis
@@ -1843,9 +1845,10 @@ __global__ __launch_bounds__(kThreads) void k_score_events(const double* __restr
     int64_t base = 0;
     double t[kMaxDim];
     for (int ax = 0; ax < a.k; ++ax) {
-        const double x = coords[(int64_t)ax * N + e];
+        double x = coords[(int64_t)ax * N + e];
         const double* __restrict__ g = grid + a.grid_off[ax];
         const int n = a.n_grid[ax];
+        if (a.clip && a.method == 1) x = fmin(fmax(x, g[0]), g[n - 1]);
         int lo = 0, hi = n;
         if (a.method == 0) {                       // first index with g[idx] >= x  (side = 'left')
             while (lo < hi) {
@@ -1898,7 +1901,6 @@ struct SimArgs {
     int n_edges[kMaxDim];
     int edge_off[kMaxDim];
     int64_t stride[kMaxDim];     // bins (C order) per step along the axis
-    int clip_to_centres;         // 'linear' pdfs: coordinates clipped to [first centre, last centre] (source.py:232-241)
 };
 constexpr uint32_t kSimTag = 0x53494D45u;
 
@@ -1954,13 +1956,9 @@ __global__ __launch_bounds__(kThreads) void k_sim_events(const double* __restric
         const int64_t i = rem / a.stride[ax];
         rem -= i * a.stride[ax];
         const double* __restrict__ ed = edges + a.edge_off[ax];
-        double x = ed[i] + u * (ed[i + 1] - ed[i]);
-        if (a.clip_to_centres) {
-            const int n = a.n_edges[ax];
-            const double c0 = 0.5 * (ed[0] + ed[1]), c1 = 0.5 * (ed[n - 2] + ed[n - 1]);
-            x = fmin(fmax(x, c0), c1);
-        }
-        coords[(int64_t)ax * N + e] = x;
+        // (uniform inside the bin, as Histdd.get_random draws it, source.py:248-264; a 'linear' pdf clips to the outer bin
+        //  centres only when it is EVALUATED, source.py:231-239: k_score_events does that, the stored events stay as drawn)
+        coords[(int64_t)ax * N + e] = ed[i] + u * (ed[i + 1] - ed[i]);
     }
     source[e] = s;
 }

@@ -1496,6 +1496,7 @@ int score_events_impl(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n
     ScoreArgs a{};
     a.k = k;
     a.method = method;
+    a.clip = coords_dev ? 1 : 0;          // events simulated on the device arrive unclipped; a caller's events are clipped already
     int64_t bins = 1;
     int off = 0;
     for (int i = 0; i < k; ++i) {
@@ -1565,7 +1566,7 @@ int bi_simulate_events(bi_ctx* tp, bi_ctx* c, const double* z, const double* rat
     if (k < 1 || k > kMaxDim || !n_edges || !edges) return fail(c, BI_ERR_INVALID, "need 1..%d axes with bin edges", kMaxDim);
     if (tp->d > 0 && !z) return fail(c, BI_ERR_INVALID, "z is NULL");
     SimArgs a{};
-    a.k = k; a.S = tp->S; a.clip_to_centres = method == 1 ? 1 : 0;
+    a.k = k; a.S = tp->S;
     int64_t bins = 1;
     int off = 0;
     for (int i = 0; i < k; ++i) {

@@ -254,7 +254,7 @@ def test_event_level_toys_drawn_on_the_device(ns, dims, method):
     counts = np.zeros(3)
     edges = [np.asarray(e, dtype=float) for _, e in space]
     occ = np.zeros([len(e) - 1 for e in edges])
-    frac = []
+    frac, edge_frac = [], []
     n_toys = 400
     for seed in range(n_toys):
         counts += lf.simulate_toy(seed=1000 + seed, **kw)
@@ -264,6 +264,8 @@ def test_event_level_toys_drawn_on_the_device(ns, dims, method):
         x, e0 = sel[space[0][0]], edges[0]
         i = np.clip(np.searchsorted(e0, x, side='right') - 1, 0, len(e0) - 2)
         frac.append((x - e0[i]) / (e0[i + 1] - e0[i]))
+        outer = (i == 0) | (i == len(e0) - 2)
+        edge_frac.append(frac[-1][outer])
     assert np.all(np.abs(counts - n_toys * mus) < 5 * np.sqrt(n_toys * mus))
     tp, _, _ = lf._templates
     dens = tp.interpolate('ps', np.array([0.35]))[0].reshape(occ.shape)          # source 0's density at shift = 0.35
@@ -279,9 +281,13 @@ def test_event_level_toys_drawn_on_the_device(ns, dims, method):
     pulls = (occ[big] - expected[big]) / np.sqrt(expected[big])
     assert abs(pulls.mean()) < 0.25 and 0.7 < pulls.std() < 1.3, (pulls.mean(), pulls.std())
     assert occ[pmf == 0].sum() == 0                                               # no event where the pdf is zero
-    if method == 'piecewise':                                                     # uniform inside the bin (unclipped coordinates)
-        f = np.concatenate(frac)
-        assert abs(f.mean() - 0.5) < 0.01 and abs(f.var() - 1 / 12) < 0.005
+    # uniform inside the bin -- for 'linear' pdfs too: the reference clips to the outer bin centres only when it EVALUATES the
+    # pdf (source.py:231-239), the events Model.simulate returns are as drawn (source.py:248-264)
+    f = np.concatenate(frac)
+    assert abs(f.mean() - 0.5) < 0.01 and abs(f.var() - 1 / 12) < 0.005
+    fe = np.concatenate(edge_frac)                                                # ... in the OUTER bins of the first axis as well
+    if len(fe) > 200:
+        assert abs(fe.mean() - 0.5) < 0.08 and np.mean(fe == 0.5) < 0.05 and fe.min() < 0.1 and fe.max() > 0.9
     # outside the anchor box there is nothing to draw from; analytic pdfs have no device route
     with pytest.raises(ValueError):
         lf.simulate_toy(shift=3.0)
