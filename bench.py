@@ -55,12 +55,15 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+HOST_THREADS_MAX = 16        # the library's own limit (csrc/bi_planning.h: host_threads), and a one-GPU box's CPU share
+
+
 def host_thread_share(world):
     """Host threads ONE rank may use: the cores this process may run on, divided among the ranks of the node (every rank
     uploads its replica and plans its batches with a few threads; eight ranks x 16 threads would be a worker pool the GPU
     pool kills)."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    return max(1, cores // max(1, int(world)))
+    return max(1, min(HOST_THREADS_MAX, cores // max(1, int(world))))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -612,7 +615,7 @@ def main():
     ctx = DeviceContext(default_device())
     info = ctx.info()
     threads = host_thread_share(world)              # per rank: upload threads and the library's planner threads
-    ctx.set_param('host_threads', min(16, threads))
+    ctx.set_param('host_threads', threads)
     ranks = Ranks(ctx, args.backend)
 
     def emit(result):

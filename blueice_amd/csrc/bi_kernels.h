@@ -2188,12 +2188,9 @@ __device__ __forceinline__ double rows4_sum(double v) {
 // instructions per item, a fifth of the kernel's vector work when every bin has data.
 // PROD = 1: the rows are the compacted non-empty bins of sparse data -- blocks whose counts are all 1 or 2 take one logarithm of
 // the product mu^n over a lane's four bins (a separate instantiation, so that the dense-data kernel keeps its code).
-// PROD = 2: the rows are a copy of ALL bins ordered by their count (ensure_sorted_rows: dense data, ~10 events per bin).
-// A sum over bins does not care about their order, and in that order the four bins of a lane -- almost always the
-// whole 32-bin strip -- carry the SAME count n, so  sum_b n log mu_b = n log prod_b mu_b : seven multiplications and ONE
-// logarithm per lane, item and strip instead of eight logarithms (24 instructions each, on a chip where no vector
-// instruction executes beside an fp64 MFMA).  Factors and intermediate products are checked to be positive normal
-// numbers; anything else takes the bin-wise form, which has scipy's values for every argument.
+// (Rows ordered by their count -- dense data, or the count-sorted compacted copy -- are k_scan_sorted's, bi_scan_sorted.h.)
+// MASK: the ROWS of the padding streams are zeroed once per strip; their coefficient reads are steered to a valid element
+// of the item's last stream group (one select on a scalar condition per group, no per-group offset registers).
 template <int CB, int KG, bool MASK, int PROD = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
     constexpr int STRIP = CB * 16;
@@ -2205,24 +2202,35 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
     const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
     const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
     const int n_strips = a.item_tiles[item0] * (kTile / STRIP);
+    // (the group's row offsets: in LDS, read again for every strip -- as loop invariants they would hold 2 KG registers)
+    __shared__ int64_t s_rowoff[4 * KG];
+    if (threadIdx.x < 4 * KG) s_rowoff[threadIdx.x] = rowoff[min((int)threadIdx.x, a.NS - 1)];
     log_table_load();
     const int kq = lane >> 4, col = lane & 15;
-    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // coefficient of K group kg sits at aoff0 + kg * 64 (clamped)
+    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // coefficient of K group kg sits at aoff0 + kg * 64 ...
+    const int kg_last = (a.NS - 1) >> 2;                     // ... up to the group that holds stream NS - 1: from there on
+    const int alast = min(kg_last * 4 + kq, a.NS - 1) * 16 + col;   // the lane reads this (valid) element instead
+#define BI_COEF_AT(kg) ((MASK && (kg) >= kg_last) ? alast : aoff0 + (kg) * 64)
 
     for (int strip = slot; strip < n_strips; strip += a.nslots) {
         const int64_t bin0 = (int64_t)strip * STRIP;
         double b[KG][CB], n[CB][4];
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));           // (opaque: keeps the LDS reads inside the strip loop)
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-            const int64_t row = rowoff[min(kg * 4 + kq, a.NS - 1)];   // streams beyond NS: a valid row times a zero coefficient
+            const int64_t row = s_rowoff[kg * 4 + kqo];               // streams beyond NS: a valid row, zeroed
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16 + col];
+            for (int cb = 0; cb < CB; ++cb) {
+                const double v = a.ps[row + bin0 + cb * 16 + col];
+                b[kg][cb] = (MASK && kg * 4 + kq >= a.NS) ? 0.0 : v;
+            }
         }
         // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
         // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
         // (the four kinds of a lane's bins packed into one register, 2 bits each: registers decide the occupancy here)
         int kinds[CB];
-        bool special[CB], alldata[CB], ones_twos[CB], uniform[CB];
+        bool special[CB], alldata[CB], ones_twos[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             kinds[cb] = 0;
@@ -2241,25 +2249,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
 #pragma unroll
             for (int r = 0; r < 4; ++r) small &= n[cb][r] == 1.0 || n[cb][r] == 2.0;
             ones_twos[cb] = PROD == 1 && __ballot(small) == ~0ull;
-            // count-sorted rows: the four bins of every lane of this block carry one count
-            uniform[cb] = PROD == 2 && alldata[cb] &&
-                          __ballot(n[cb][0] == n[cb][1] && n[cb][1] == n[cb][2] && n[cb][2] == n[cb][3]) == ~0ull;
         }
-        // ... and both blocks of the strip the same one, lane by lane: one logarithm per lane and item for the whole strip
-        bool strip_uniform = false;
-        if constexpr (PROD == 2 && CB == 2) strip_uniform = uniform[0] && uniform[1] && __ballot(n[0][0] == n[1][0]) == ~0ull;
 #define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
 
-        // coefficient operands: coef[k][point]; streams beyond NS read a valid element and are masked to zero
+        // coefficient operands: coef[k][point]; streams beyond NS read a valid element (their rows are zero)
         double av[KG];
         {
             const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = kg * 4 + kq;
-                av[kg] = coef[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) av[kg] = 0.0;
-            }
+            for (int kg = 0; kg < KG; ++kg) av[kg] = coef[BI_COEF_AT(kg)];
         }
         // (the item's coefficient block and its partial slot advance by fixed steps: pointers, not products per item)
         const double* __restrict__ coef_next = a.coef + item0 * a.NS * 16;
@@ -2283,19 +2281,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
 #define BI_EPILOGUE(cb)                                                                                            \
     do {                                                                                                           \
         if (alldata[cb]) { /* dense data: n log mu in every bin; mu <= 0 / nan comes out of the checked logarithm */ \
-            if ((PROD == 2 && uniform[cb]) || (PROD == 1 && ones_twos[cb])) { /* (wave-uniform) product forms */       \
+            if (PROD == 1 && ones_twos[cb]) { /* (wave-uniform) product form */                                    \
                 bool low = false;                                                                                  \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) low |= !(acc[cb][r] > kProdFloor);                   \
                 if (__ballot(low) == 0ull) {                                                                       \
-                    /* PROD 2: one count per lane, n log of the product over the lane's four bins; PROD 1: counts  */ \
-                    /* of 1 and 2 only, ONE logarithm of the product of mu^n.  At most eight factors above         */ \
+                    /* counts of 1 and 2 only: ONE logarithm of the product of mu^n.  At most eight factors above  */ \
                     /* kProdFloor: no partial product can be subnormal, one that overflows stays +inf to the end   */ \
                     double f[4];                                                                                   \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
                         f[r] = (PROD == 1 && n[cb][r] == 2.0) ? acc[cb][r] * acc[cb][r] : acc[cb][r];              \
                     const double prod = (f[0] * f[1]) * (f[2] * f[3]);                                             \
                     if (__ballot(!pos_normal(prod)) == 0ull) {                                                     \
-                        s[cb & 3] = fma(PROD == 2 ? n[cb][0] : 1.0, bin_log_fast(prod), s[cb & 3]);                \
+                        s[cb & 3] += bin_log_fast(prod);                                                           \
                         break;                                                                                     \
                     }                                                                                              \
                 }                                                                                                  \
@@ -2329,39 +2326,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) BI_CHAIN(cb);
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = kg * 4 + kq;
-                av[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) av[kg] = 0.0;
-            }
-            bool strip_done = false;
+            for (int kg = 0; kg < KG; ++kg) av[kg] = coef_next[BI_COEF_AT(kg)];
             double tot = 0.0;
-            if constexpr (PROD == 2 && CB == 2) {
-                if (strip_uniform) {          // (wave-uniform) the whole strip: eight factors, seven products, one logarithm
-                    const double a01 = acc[0][0] * acc[0][1], a23 = acc[0][2] * acc[0][3];
-                    const double b01 = acc[1][0] * acc[1][1], b23 = acc[1][2] * acc[1][3];
-                    const double pa = a01 * a23, pb = b01 * b23;
-                    const double pp = pa * pb;
-                    // eight factors above kProdFloor: no partial product can be subnormal, and one that overflows stays
-                    // +inf through the remaining (positive) factors -- eight compares and ONE class test, no branches
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
-                    const bool ok = (acc[0][0] > kProdFloor) & (acc[0][1] > kProdFloor) & (acc[0][2] > kProdFloor) &
-                                    (acc[0][3] > kProdFloor) & (acc[1][0] > kProdFloor) & (acc[1][1] > kProdFloor) &
-                                    (acc[1][2] > kProdFloor) & (acc[1][3] > kProdFloor) & pos_normal(pp);
-#pragma clang diagnostic pop
-                    if (__ballot(!ok) == 0ull) {
-                        tot = n[0][0] * bin_log_fast(pp);
-                        strip_done = true;
-                    }
-                }
-            }
-            if (!strip_done) {
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
-                tot = (s[0] + s[1]) + (s[2] + s[3]);
-                if (mn < 0.0) tot = __builtin_nan("");
-            }
+            for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
+            tot = (s[0] + s[1]) + (s[2] + s[3]);
+            if (mn < 0.0) tot = __builtin_nan("");
 #undef BI_CHAIN
 #undef BI_EPILOGUE
 #undef BI_KIND
@@ -2370,6 +2340,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             dst += dst_step;
         }
     }
+#undef BI_COEF_AT
 }
 
 // The finish of a scan plan: partial is [items][nslots][16] (point fastest), one wave per item.  Lane l takes point

@@ -13,10 +13,27 @@ namespace {
 // Blocks of a matrix-core scan kernel variant that one CU holds at a time (registers decide it), asked from the runtime
 // once per variant: the planner sizes the split of a cell's strips so that the blocks run in full rounds.
 int scan_resident_blocks(bool valid, int cb, int NS, bool by_count = false) {
-    static std::atomic<int> cache[3][2][4][2];
+    if (by_count) {                      // k_scan_sorted: one variant per number of 4-stream groups (1..8), masked or not
+        static std::atomic<int> sorted_cache[8][2];
+        const int KG = std::max(1, std::min(8, (NS + 3) / 4)), mask = NS == 4 * KG ? 0 : 1;
+        std::atomic<int>& slot = sorted_cache[KG - 1][mask];
+        int v = slot.load();
+        if (v > 0) return v;
+        const void* f = nullptr;
+        switch ((KG - 1) * 2 + mask) {
+#define BI_CASE(K) case ((K) - 1) * 2: f = (const void*)k_scan_sorted<K, false>; break; case ((K) - 1) * 2 + 1: f = (const void*)k_scan_sorted<K, true>; break;
+            BI_CASE(1) BI_CASE(2) BI_CASE(3) BI_CASE(4) BI_CASE(5) BI_CASE(6) BI_CASE(7) BI_CASE(8)
+#undef BI_CASE
+        }
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, kThreads, 0) != hipSuccess || blocks < 1) blocks = 2;
+        slot.store(blocks);
+        return blocks;
+    }
+    static std::atomic<int> cache[2][2][4][2];
     const int kg = NS <= 4 ? 0 : (NS <= 8 ? 1 : (NS <= 16 ? 2 : 3));
     const int mask = NS == (4 << kg) ? 0 : 1;
-    std::atomic<int>& slot = cache[by_count ? 2 : (valid ? 1 : 0)][cb == 2 ? 0 : 1][kg][mask];
+    std::atomic<int>& slot = cache[valid ? 1 : 0][cb == 2 ? 0 : 1][kg][mask];
     int v = slot.load();
     if (v > 0) return v;
     const void* f = nullptr;
@@ -33,18 +50,7 @@ int scan_resident_blocks(bool valid, int cb, int NS, bool by_count = false) {
             default: f = (const void*)KERNEL<CB, 8, true>; break;                                                  \
         }                                                                                                          \
     } while (0)
-    if (by_count) {
-        switch (kg * 2 + mask) {
-            case 0: f = (const void*)k_scan_sorted<1, false>; break;
-            case 1: f = (const void*)k_scan_sorted<1, true>; break;
-            case 2: f = (const void*)k_scan_sorted<2, false>; break;
-            case 3: f = (const void*)k_scan_sorted<2, true>; break;
-            case 4: f = (const void*)k_scan_sorted<4, false>; break;
-            case 5: f = (const void*)k_scan_sorted<4, true>; break;
-            case 6: f = (const void*)k_scan_sorted<8, false>; break;
-            default: f = (const void*)k_scan_sorted<8, true>; break;
-        }
-    } else if (valid) BI_PICK(k_scan_valid, 4);
+    if (valid) BI_PICK(k_scan_valid, 4);
     else if (cb == 2) BI_PICK(k_scan_mfma, 2);
     else BI_PICK(k_scan_mfma, 4);
 #undef BI_PICK

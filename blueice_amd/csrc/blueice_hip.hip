@@ -620,7 +620,10 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
                 sa.xcd_mode = (int)c->scan_xcd;
                 const int64_t scan_blocks = (int64_t)(k.nbx / 4) * (c->scan_xcd == 2 ? (plan->n_groups + 7) / 8 * 8 : plan->n_groups);
                 const dim3 sgrid((unsigned)((scan_blocks + 7) / 8 * 8));
-                if (kg == 1) BI_SORTED(1); else if (kg == 2) BI_SORTED(2); else if (kg == 4) BI_SORTED(4); else BI_SORTED(8);
+                switch ((NS + 3) / 4) {           // the exact number of 4-stream groups: no matrix work on padding
+                    case 1: BI_SORTED(1); break; case 2: BI_SORTED(2); break; case 3: BI_SORTED(3); break; case 4: BI_SORTED(4); break;
+                    case 5: BI_SORTED(5); break; case 6: BI_SORTED(6); break; case 7: BI_SORTED(7); break; default: BI_SORTED(8); break;
+                }
             } else if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
 #undef BI_SORTED
 #undef BI_SCAN_KG

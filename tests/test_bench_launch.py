@@ -56,11 +56,11 @@ def test_host_threads_are_shared_among_the_ranks():
     assert res.returncode == 0, res.stderr[-2000:]
     line = _json_line(res.stdout)
     assert line['n_gpus'] == 8 and len(line['legs']['C4']['ranks']) == 8
-    assert line['config']['host_threads_per_rank'] == max(1, cores // 8)
+    assert line['config']['host_threads_per_rank'] == max(1, min(16, cores // 8))
     assert line['config']['host_threads_per_rank'] * 8 <= max(8, cores)
     sys.path.insert(0, ROOT)
     import bench
-    assert bench.host_thread_share(1) == cores and bench.host_thread_share(10 ** 6) == 1
+    assert bench.host_thread_share(1) == min(16, cores) and bench.host_thread_share(10 ** 6) == 1
     # the strong-scaling legs print what N ranks can reach from one run's own split of a step
     pc = bench.predicted_ceiling(10 ** 6, step_ms=12.0, kernel_ms=9.0, world=1)
     assert pc['fixed_ms_per_rank'] == 3.0 and abs(pc['evals_per_s']['8'] - 1e6 / ((3.0 + 9.0 / 8) * 1e-3)) < 1e-3

@@ -191,3 +191,44 @@ def test_sorted_rows_random_models_match_oracle(seed):
                 (seed, rep, d, S, B, i, g, w, st[i])
     assert used >= 1 or _COUNT
     ctx.close()
+
+
+def test_every_stream_count_from_1_to_32():
+    """The count-ordered scan kernel has one variant per number of 4-stream groups (1..8), with or without padding streams
+    in the last group: every NS = sources x corners from 1 to 32 (no shape axis: NS = sources; one axis: NS = 2 sources),
+    dense data and the compacted non-empty bins of sparse data, against the oracle."""
+    from test_fuzz_gpu import random_case, random_points
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(4321)
+    ctx = DeviceContext(0)
+    seen = set()
+    for NS in range(1, 33):
+        d = 1 if (NS % 2 == 0 and NS % 3 == 0) else 0           # (some of the even counts as two corners x NS / 2 sources)
+        S = NS // 2 if d else NS
+        B = int(rng.choice([192, 512, 700]))
+        model, _ = random_case(rng, d, S, B, -1)
+        if d:                                                   # at least two anchors on the axis: two corners per source
+            while len(model['anchor_z'][0]) < 2:
+                model, _ = random_case(rng, d, S, B, -1)
+        lam = (model['mus'].reshape(-1, S)[0][:, None] * model['ps'].reshape(-1, S, B)[0]).sum(axis=0)
+        P = 900
+        z, r = random_points(rng, model, P, S)
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        for sparse in (0, 1):
+            ctx.set_param('sparse', sparse)
+            scale = 12.0 if not sparse else 0.4
+            counts = rng.poisson(np.maximum(lam, 0.02) * (scale / max(lam.mean(), 1e-9))).astype(float)
+            ctx.upload_counts(counts)
+            before = ctx.get_param('n_scan_launches')
+            got, st = ctx.eval(z if d else None, r)
+            if ctx.get_param('n_scan_launches') > before:
+                seen.add((NS, sparse))
+            for i in range(0, P, 11):
+                w = orc.loglikelihood(model, counts, z[i], r[i])
+                g = got[i]
+                assert (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= 1e-10 * max(1, abs(w))), \
+                    (NS, sparse, i, g, w, st[i])
+    ctx.close()
+    # the matrix-core scan ran for every stream count in at least one data form
+    assert {ns for ns, _ in seen} == set(range(1, 33)), sorted(set(range(1, 33)) - {ns for ns, _ in seen})
