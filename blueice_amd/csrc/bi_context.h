@@ -113,6 +113,12 @@ struct bi_ctx {
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
     bool tm_ok = false;                       // ... and whether every count fits its 19 bits
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
+    int64_t toy_fast_call = 7;                // parameter, bits: 1 descriptors in the kernel arguments, 2 parallel finish (k_dataset_finish_tiled), 4 poll the completion word
+    DevBuf toy_blocks_done;                   // the finish kernel's block counter (zero between calls)
+    bool toy_blocks_done_zeroed = false;
+    unsigned long long toy_seq = 0;
+    int64_t n_toy_polled = 0;                 // calls that returned on the completion word
+    int64_t dot_blocks_per_cu = 0;            // parameter: blocks of the tiled kernel per CU the dataset split aims at (0 = as many as are resident)
     int64_t dot_lanes = 8;                    // parameter: lanes per (dataset, tile) run of the tiled kernel: 8 (96 entry slots) or 16 (128)
     int64_t toy_events = 1;                   // parameter: toys of sparse expectations are drawn event by event (0 = always one draw per bin)
     int64_t last_toy_method = 0;              // read-only: 1 = the last bi_generate_toys drew event by event, 0 = bin by bin

@@ -1323,15 +1323,20 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 // Tile-major copy of the non-empty-bin lists: all entries of bin tile 0 (dataset 0, 1, ...), then tile 1, ... -- the
 // block that owns a tile reads ONE contiguous stream instead of a sub-kilobyte run per dataset scattered over the
-// dataset-major lists (which held the first tiled version at 2.6 TB/s).  An entry is 4 bytes: bin within the tile
-// (13 bits) and the count (19 bits); data whose counts do not fit (or are not positive integers) keep the row kernel.
+// dataset-major lists (which held the first tiled version at 2.6 TB/s).  An entry is 4 bytes: the byte offset of the bin
+// within the staged tile (bits 3..16: bin * 8) and the count (15 bits, from bit 17), so that the kernel gets the LDS
+// address with one AND and the count with one shift; data whose counts do not fit (or are not positive integers) keep
+// the row kernel.  Every (dataset, tile) run is padded to a multiple of FOUR entries with kTmPadEntry -- count 0, and the
+// offset of an extra LDS slot behind the tile that holds 0.0, never log mu = -inf -- so that a lane's 16-byte load is
+// wholly inside its run or wholly outside it (one test per load, not per entry) and every load is 16-byte aligned.
+constexpr uint32_t kTmPadEntry = (uint32_t)kDotTile << 3;
 __global__ void k_tm_counts(const int32_t* __restrict__ tile_off, int64_t T, int n_tl, int64_t* __restrict__ cnt /*[n_tl * T + 1]*/) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > (int64_t)n_tl * T) return;
     if (i == (int64_t)n_tl * T) { cnt[i] = 0; return; }
     const int64_t tl = i / T, t = i % T;
     const int32_t* __restrict__ o = tile_off + t * (n_tl + 1) + tl;
-    cnt[i] = o[1] - o[0];
+    cnt[i] = (o[1] - o[0] + 3) & ~3;                // (the run's padded length: the list is pre-filled with kTmPadEntry)
 }
 
 __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restrict__ nz_idx, const double* __restrict__ nz_n,
@@ -1346,8 +1351,8 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
         const int idx = nz_idx[j];
         const double n = nz_n[j];
         const int tl = idx / kDotTile;
-        if (!(n >= 1.0 && n < 524288.0 && n == floor(n))) any_bad = true;
-        tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = (uint32_t)(idx - tl * kDotTile) | ((uint32_t)n << 13);
+        if (!(n >= 1.0 && n < 32768.0 && n == floor(n))) any_bad = true;
+        tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = ((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n << 17);
     }
     if (any_bad) atomicOr(bad, 1);
 }
@@ -1359,12 +1364,17 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
 // runs in flight (ring buffers in registers, the loop unrolled over the ring so that nothing is copied and nothing
 // newer than what it needs is waited for): offsets four runs ahead, entries two runs ahead.  Every load is
 // unconditional -- a run behind the row's last one is the last one again (requested, never stored), an entry load
-// reads up to kDotPad entries past its run (the lists are padded by that much) and is masked afterwards -- because a
-// branch around a load makes the compiler wait for ALL outstanding loads.  Index arithmetic is 32-bit, relative to the
+// reads up to kDotPad entries past its run (the lists are padded by that much) and its 4-entry sum is dropped afterwards
+// (runs are whole 16-byte groups: round 4) -- because a branch around a load makes the compiler wait for ALL outstanding
+// loads.  Index arithmetic is 32-bit, relative to the
 // block's first entry (the launch keeps a block below 2^31 entries).  Per lane the entries are added in ascending
-// order with fma: a fixed order, independent of the launch geometry.
+// order with fma, four at a time (one 16-byte load), the groups' sums then in ascending order: a fixed order, independent of
+// the launch geometry.
 typedef uint32_t bi_uint4 __attribute__((ext_vector_type(4)));
 constexpr int kDotThreads = 1024;
+#ifndef BI_DOT_DEPTH
+#define BI_DOT_DEPTH 2
+#endif
 constexpr int kDotPad = 64 * 2 + 16;           // entries behind the lists that the read-ahead may touch (read, masked, never used): the largest of the variants below
 
 // sum over the L lanes of a group inside a 16-lane DPP row (L = 16, or 8: groups start at lanes 0 and 8) on the cross-lane
@@ -1403,7 +1413,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
                                                                    const double* __restrict__ logmu, int64_t B, int64_t t0,
                                                                    int64_t n, double* __restrict__ partial /*[n_tl][n]*/) {
     static_assert(4 * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
-    __shared__ double s_mu[kDotTile];
+    __shared__ double s_mu[kDotTile + 1];                              // (+ the slot of the padding entries: 0.0)
     const int tl = blockIdx.x;
     const int64_t bin0 = (int64_t)tl * kDotTile;
     const int row = threadIdx.x / L, gl = threadIdx.x % L;             // kDotThreads / L rows of L lanes
@@ -1415,7 +1425,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
     const uint32_t* __restrict__ ent = tm_entries + base;
     const uint32_t* __restrict__ off32 = reinterpret_cast<const uint32_t*>(off);   // low words: all a block-relative index needs
     const uint32_t base32 = (uint32_t)base;
-    constexpr int kStep = kDotThreads / L, kAhead = AHEAD, kRing = 6;
+    constexpr int kStep = kDotThreads / L, kAhead = AHEAD, kDepth = BI_DOT_DEPTH, kRing = 2 * (kDepth + 1);   // entries kDepth runs ahead, offsets 2 kDepth; the ring a multiple of the entry buffers
     const int q_last = max(c0, c1 - 1);
     // (a step only ISSUES loads into the rings; whatever touches a loaded value -- the subtraction of the base, the mask
     //  of the entries past the run's end -- happens in the step that consumes it, two or four steps later: the compiler
@@ -1431,12 +1441,12 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + 4 * L * k, 16);     // (4-byte aligned 16-byte load)
     };
-    bi_uint4 E[3][kAhead];
+    bi_uint4 E[kDepth + 1][kAhead];
     uint32_t RA[kRing], RB[kRing];
     const int q0 = c0 + row;
     // the pipeline's first requests go out before the tile is staged: their latency passes under the staging
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_offsets(q0 + u * kStep, RA[u], RB[u]);
+    for (int u = 0; u < 2 * kDepth; ++u) load_offsets(q0 + u * kStep, RA[u], RB[u]);
     {   // (all loads first, addresses clamped instead of predicated: eight loads in flight per thread, not one at a time)
         double v[kDotTile / kDotThreads];
 #pragma unroll
@@ -1444,9 +1454,10 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
 #pragma unroll
         for (int k = 0; k < kDotTile / kDotThreads; ++k)
             s_mu[threadIdx.x + k * kDotThreads] = bin0 + threadIdx.x + k * kDotThreads < B ? v[k] : 0.0;
+        if (threadIdx.x == 0) s_mu[kDotTile] = 0.0;
     }
-    load_entries(RA[0], E[0]);
-    load_entries(RA[1], E[1]);
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) load_entries(RA[u], E[u]);
     __syncthreads();
     if (c0u >= c1) return;
     const int n_iter = (c1 - c0 + kStep - 1) / kStep;             // block-uniform: rows past their last run idle along
@@ -1455,22 +1466,28 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
         for (int u = 0; u < kRing; ++u) {
             if (it + u < n_iter) {                               // (scalar condition)
                 const int q = q0 + (it + u) * kStep;
-                load_offsets(q + 4 * kStep, RA[(u + 4) % kRing], RB[(u + 4) % kRing]);
-                load_entries(RA[(u + 2) % kRing], E[(u + 2) % 3]);
+                load_offsets(q + 2 * kDepth * kStep, RA[(u + 2 * kDepth) % kRing], RB[(u + 2 * kDepth) % kRing]);
+                load_entries(RA[(u + kDepth) % kRing], E[(u + kDepth) % (kDepth + 1)]);
                 __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this step's arithmetic, not after it
-                const bi_uint4 (&e)[kAhead] = E[u % 3];
+                const bi_uint4 (&e)[kAhead] = E[u % (kDepth + 1)];
                 const int a = (int)(RA[u % kRing] - base32), b = (int)(RB[u % kRing] - base32);
-                const int len = b - a - 4 * gl;                  // entries of the run from this lane's first on
+                const int len = b - a - 4 * gl;                  // (padded) entries of the run from this lane's first on
                 double s = 0.0, lm[4 * kAhead];
+#define BI_TM_LOG(x) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_mu) + ((x) & 0x1FFF8u)))
 #pragma unroll
-                for (int k = 0; k < 4 * kAhead; ++k) lm[k] = s_mu[e[k >> 2][k & 3] & (kDotTile - 1)];      // LDS reads in flight together
+                for (int k = 0; k < 4 * kAhead; ++k) lm[k] = BI_TM_LOG(e[k >> 2][k & 3]);      // LDS reads in flight together
 #pragma unroll
-                for (int k = 0; k < 4 * kAhead; ++k)
-                    s = __builtin_fma((double)(4 * L * (k >> 2) + (k & 3) < len ? e[k >> 2][k & 3] >> 13 : 0u), lm[k], s);
+                for (int g = 0; g < kAhead; ++g) {
+                    double sg = (double)(e[g][0] >> 17) * lm[4 * g];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) sg = __builtin_fma((double)(e[g][k] >> 17), lm[4 * g + k], sg);
+                    s += 4 * L * g < len ? sg : 0.0;             // (a load behind the run's end read other runs' entries: dropped whole)
+                }
                 for (int j = a + gl + 4 * L * kAhead; j < b; j += L) {                      // (runs beyond 4 L AHEAD entries)
                     const uint32_t x = ent[j];
-                    s = __builtin_fma((double)(x >> 13), s_mu[x & (kDotTile - 1)], s);
+                    s = __builtin_fma((double)(x >> 17), BI_TM_LOG(x), s);
                 }
+#undef BI_TM_LOG
                 s = row_group_sum<L>(s);
                 if (gl == 0 && q < c1) partial[(int64_t)tl * n + q] = s;
             }
@@ -1978,9 +1995,8 @@ __global__ void k_csr_to_dense(const int32_t* __restrict__ idx, const double* __
 
 // ---- toy-MC form: one parameter point, many datasets --------------------------------------
 // pass 1: mu_b -> logmu[b] (log mu, or -inf for mu == 0, or nan for invalid mu), partial sum mu
-__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu, int store_mu) {
-    const int64_t* __restrict__ rowoff = a.rowoff;
-    const double* __restrict__ coef = a.coef;
+__device__ __forceinline__ void morph_logmu_body(const LaunchArgs& a, const int64_t* __restrict__ rowoff, const double* __restrict__ coef,
+                                                 double* __restrict__ logmu, int store_mu) {
     double sum = 0.0;
     unsigned bad = 0u;
     log_table_load();
@@ -2019,6 +2035,21 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* 
         a.partial[blockIdx.x] = t;
         a.pflags[blockIdx.x] = f;
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_morph_logmu(LaunchArgs a, double* __restrict__ logmu, int store_mu) {
+    morph_logmu_body(a, a.rowoff, a.coef, logmu, store_mu);
+}
+
+// The point's descriptors in the kernel arguments (up to kMaxSingleStreams streams): a toy-MC call is ONE point, and a
+// host-to-device copy of its 512 bytes ahead of the launch costs more than the launch (10 ... 15 us on this runtime).
+struct PointDesc {
+    int64_t rowoff[kMaxSingleStreams];
+    double coef[kMaxSingleStreams];
+};
+
+__global__ __launch_bounds__(kThreads) void k_morph_logmu_desc(LaunchArgs a, PointDesc d, double* __restrict__ logmu, int store_mu) {
+    morph_logmu_body(a, d.rowoff, d.coef, logmu, store_mu);
 }
 
 // pass 2: for dataset t: sum_b xlogy(n_tb, mu_b).  blockIdx.y = group of kDotGroup datasets, x strides tiles: the
@@ -2124,6 +2155,85 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish(const double* __res
     double r = (s - m) - lgsum[t0 + t];
     if (f) r = __builtin_nan("");
     out[t] = r;
+}
+
+// The finish of the tiled toy-MC pass, partial[tile][dataset] (block-major): 64 datasets per block, the tiles of a
+// dataset split over the block's four waves (k_dataset_finish has one thread walk all ~123 tiles of its dataset, 16 trips
+// to L2 one after the other on 40 blocks: 10 ... 15 us for 10^4 datasets; here 157 blocks and four trips).  Fixed order:
+// a wave's range in steps of eight with eight running sums, then the four waves' sums ((0 + 1) + (2 + 3)).
+// done != NULL: out is pinned host memory; the block that finishes last publishes `seq` there with a system-scope
+// release once every block's results are on their way (the host polls the word instead of synchronising the stream).
+__global__ __launch_bounds__(kThreads) void k_dataset_finish_tiled(const double* __restrict__ partial, int nbx,
+                                                                   const double* __restrict__ mu_partial,
+                                                                   const unsigned* __restrict__ mu_flags, int nmu,
+                                                                   const double* __restrict__ lgsum, int64_t t0, int64_t n,
+                                                                   double* __restrict__ out, unsigned* __restrict__ blocks_done,
+                                                                   unsigned long long* done, unsigned long long seq) {
+    static_assert(kThreads == 256, "four waves per block");
+    __shared__ double sh[kThreads / 64];
+    __shared__ unsigned shf[kThreads / 64];
+    __shared__ double part[kThreads / 64][64];
+    double m = 0.0;
+    unsigned f = 0u;
+    {
+        double m4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = threadIdx.x;
+        for (; b + 3 * kThreads < nmu; b += 4 * kThreads) {
+            double v[4];
+            unsigned g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = mu_partial[b + k * kThreads]; g[k] = mu_flags[b + k * kThreads]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m4[k] += v[k]; f |= g[k]; }
+        }
+        for (; b < nmu; b += kThreads) { m4[0] += mu_partial[b]; f |= mu_flags[b]; }
+        m = (m4[0] + m4[1]) + (m4[2] + m4[3]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+    const int per = (nbx + 3) / 4;
+    const int b0 = wave * per, b1 = min(nbx, b0 + per);
+    double s = 0.0;
+    if (t < n) {
+        const double* __restrict__ p = partial + t;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int b = b0;
+        for (; b + 7 < b1; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(int64_t)(b + k) * n];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+        for (; b < b1; ++b) acc[0] += p[(int64_t)b * n];
+        s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+    part[wave][lane] = s;
+    m = wave_sum(m);
+    f = wave_or(f);
+    if (lane == 0) { sh[wave] = m; shf[wave] = f; }
+    __syncthreads();
+    if (wave == 0 && t < n) {
+        double mm = sh[0];
+        unsigned ff = shf[0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) { mm += sh[w]; ff |= shf[w]; }
+        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        double r = (tot - mm) - lgsum[t0 + t];
+        if (ff) r = __builtin_nan("");
+        out[t] = r;
+    }
+    if (!done) return;
+    if (wave == 0) {
+        __threadfence_system();                        // this wave's results have left before the block is counted
+        if (lane == 0) {
+            const unsigned before = __hip_atomic_fetch_add(blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == gridDim.x - 1) {
+                __hip_atomic_store(blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (ready for the next call)
+                __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 }  // namespace

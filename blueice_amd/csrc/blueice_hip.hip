@@ -117,7 +117,7 @@ void bi_destroy(bi_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
-    dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu);
+    dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu); dev_free(c->toy_blocks_done);
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     dev_free(c->mail); dev_free(c->mail_flags);
     dev_free(c->ps_sorted); dev_free(c->cnt_sorted);
@@ -1110,12 +1110,13 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
         if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
             (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
             (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t))) ||
-            (rc = dev_alloc(c, c->tm_entries, (size_t)(nnz + kDotPad) * sizeof(uint32_t)))) {     // (+ pad: the kernel's unconditional read-ahead)
+            // (every run padded to whole 16-byte groups: at most 3 entries each; + pad: the kernel's unconditional read-ahead)
+            (rc = dev_alloc(c, c->tm_entries, (size_t)(nnz + 3 * cells + kDotPad) * sizeof(uint32_t)))) {
             drop();
             return rc;
         }
         hipError_t e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync((uint32_t*)c->tm_entries.p + nnz, 0, (size_t)kDotPad * sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)c->tm_entries.p, (int)kTmPadEntry, (size_t)(nnz + 3 * cells + kDotPad), c->stream);
         hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
                            (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p);
         hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
@@ -1142,9 +1143,12 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     const int nbx = tiled ? n_tl : csr ? 1 : (int)std::min<int64_t>(n_tiles, std::max<int64_t>(1, 4 * slots / std::max<int64_t>(1, (std::min(n, chunk) + kDotGroup - 1) / kDotGroup)));
     // descriptors in one packed copy; up to 4 MB of results are written straight into pinned host memory
     const bool host_out = !out_dev && (size_t)n * sizeof(double) <= ((size_t)4 << 20);
+    // (up to kMaxSingleStreams streams the point's descriptors ride in the kernel arguments: no copy ahead of the launch)
+    const bool by_value = NS <= kMaxSingleStreams && (c->toy_fast_call & 1);
     PackedUpload pu;
-    if ((rc = packed_upload(c, {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)}},
-                            host_out ? (size_t)n * sizeof(double) : 0, pu)) ||
+    std::vector<std::pair<const void*, size_t>> parts;
+    if (!by_value) parts = {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)}};
+    if ((rc = packed_upload(c, parts, host_out ? (size_t)n * sizeof(double) : 0, pu)) ||
         (rc = dev_alloc(c, c->logmu, (size_t)c->Bp * sizeof(double))) ||
         (rc = dev_alloc(c, c->scratch, (size_t)nmu * sizeof(double) + (size_t)nmu * sizeof(unsigned) + 64)) ||
         (rc = dev_alloc(c, c->scratch2, (size_t)std::min(n, chunk) * nbx * sizeof(double))) ||
@@ -1155,15 +1159,36 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     double* res = out_dev ? out_dev : (host_out ? (double*)pu.host_out() : (double*)d_out.p);
     LaunchArgs a{};
     a.ps = (const double*)c->ps.p;
-    a.rowoff = pu.dev<int64_t>(0);
-    a.coef = pu.dev<double>(1);
+    a.rowoff = by_value ? nullptr : pu.dev<int64_t>(0);
+    a.coef = by_value ? nullptr : pu.dev<double>(1);
     a.partial = (double*)c->scratch.p;
     a.pflags = (unsigned*)((char*)c->scratch.p + (((size_t)nmu * sizeof(double) + 63) / 64) * 64);
     a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles;
-    {
-        EventScope ev(c);
-        hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p, 0);
+    // One chunk of tiled partials whose results go to pinned host memory: the finish kernel's last block publishes a
+    // sequence number behind them, and the call polls that word (as single evaluations do) instead of synchronising
+    unsigned long long* done_word = nullptr;
+    unsigned long long seq = 0;
+    if (tiled && host_out && n <= chunk && c->poll_result && !c->profiling && (c->toy_fast_call & 6) == 6) {
+        if ((rc = dev_alloc(c, c->toy_blocks_done, 64))) { cleanup(); return rc; }
+        if (!c->toy_blocks_done_zeroed) {
+            HIP_TRY(c, hipMemsetAsync(c->toy_blocks_done.p, 0, 64, c->stream));
+            c->toy_blocks_done_zeroed = true;
+        }
+        done_word = (unsigned long long*)((char*)pu.host_out() + ((size_t)n * sizeof(double) + 63) / 64 * 64);   // (packed_upload keeps 64 spare bytes behind the results)
+        seq = ++c->toy_seq;
+        *(volatile unsigned long long*)done_word = 0ull;
     }
+    auto launch_logmu = [&]() {
+        EventScope ev(c);
+        if (by_value) {
+            PointDesc pd;
+            memcpy(pd.rowoff, rowoff.data(), rowoff.size() * sizeof(int64_t));
+            memcpy(pd.coef, coef.data(), coef.size() * sizeof(double));
+            hipLaunchKernelGGL(k_morph_logmu_desc, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, pd, (double*)c->logmu.p, 0);
+        } else
+            hipLaunchKernelGGL(k_morph_logmu, dim3((unsigned)nmu), dim3(kThreads), 0, c->stream, a, (double*)c->logmu.p, 0);
+    };
+    launch_logmu();
     for (int64_t s0 = 0; s0 < n; s0 += chunk) {
         const int64_t ni = std::min(chunk, n - s0);
         {
@@ -1171,16 +1196,26 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
             if (tiled) {
                 // datasets split over blockIdx.y so that ~4 blocks per CU exist; every block stages its tile once
                 // (and few enough datasets per block for its 32-bit entry indices: datasets x kDotTile < 2^31)
-                const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((ni + 255) / 256, 2 * (int64_t)c->prop.multiProcessorCount / n_tl),      // two resident blocks per CU (64 KB of LDS each): ONE round, every block's start-up paid once
+                // as many blocks as are resident at once (the 8-lane variant's registers allow one per CU, the 16-lane
+                // variant's two; asked from the runtime once): ONE round, every block's start-up paid once
+                static std::atomic<int> resident_cache[2];
+                std::atomic<int>& rslot = resident_cache[c->dot_lanes == 8 ? 0 : 1];
+                int resident = c->dot_blocks_per_cu > 0 ? (int)c->dot_blocks_per_cu : rslot.load();
+                if (resident <= 0) {
+                    int r = 0;
+                    const void* f = c->dot_lanes == 8 ? (const void*)k_dataset_dot_tiled<8, 3> : (const void*)k_dataset_dot_tiled<16, 2>;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, f, kDotThreads, 0) != hipSuccess || r < 1) r = 1;
+                    rslot.store(r);
+                    resident = r;
+                }
+                const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((ni + 255) / 256, (int64_t)resident * c->prop.multiProcessorCount / n_tl),
                                                                  (ni + 262143) / 262144});
-                if (c->dot_lanes == 8)
-                    hipLaunchKernelGGL((k_dataset_dot_tiled<8, 3>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
-                                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
-                                       (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
-                else
-                    hipLaunchKernelGGL((k_dataset_dot_tiled<16, 2>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream,
-                                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,
-                                       (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p);
+#define BI_DOT(L, AHEAD)                                                                                           \
+    hipLaunchKernelGGL((k_dataset_dot_tiled<L, AHEAD>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream, \
+                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,                  \
+                       (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p)
+                if (c->dot_lanes == 8) BI_DOT(8, 3); else BI_DOT(16, 2);
+#undef BI_DOT
             } else if (csr)
                 hipLaunchKernelGGL(k_dataset_dot_csr, dim3((unsigned)ni), dim3(kThreads), 0, c->stream,
                                    (const int32_t*)c->nz_idx.p, (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p,
@@ -1190,14 +1225,34 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
                                    c->stream, (const double*)c->counts.p, (const double*)c->logmu.p, c->Bp, n_tiles, t0 + s0, ni,
                                    (double*)c->scratch2.p);
         }
-        hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double*)c->scratch2.p, nbx, tiled ? (int64_t)1 : (int64_t)nbx, tiled ? ni : (int64_t)1,
-                           (const double*)a.partial, (const unsigned*)a.pflags, nmu,
-                           (const double*)c->lgsum.p, t0 + s0, ni, res + s0);
+        if (tiled && (c->toy_fast_call & 2))
+            hipLaunchKernelGGL(k_dataset_finish_tiled, dim3((unsigned)((ni + 63) / 64)), dim3(kThreads), 0, c->stream,
+                               (const double*)c->scratch2.p, nbx, (const double*)a.partial, (const unsigned*)a.pflags, nmu,
+                               (const double*)c->lgsum.p, t0 + s0, ni, res + s0, (unsigned*)c->toy_blocks_done.p, done_word, seq);
+        else
+            hipLaunchKernelGGL(k_dataset_finish, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, c->stream,
+                               (const double*)c->scratch2.p, nbx, tiled ? (int64_t)1 : (int64_t)nbx, tiled ? ni : (int64_t)1,
+                               (const double*)a.partial, (const unsigned*)a.pflags, nmu,
+                               (const double*)c->lgsum.p, t0 + s0, ni, res + s0);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && n && !host_out && !out_dev) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    bool arrived = false;
+    if (e == hipSuccess && done_word) {
+        const volatile unsigned long long* dw = done_word;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+        for (unsigned spin = 0; !(arrived = (*dw == seq)); ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        ++c->n_toy_polled;
+    }
+    // (falls back to the stream sync, which also reports a faulted kernel; every 256th call synchronises anyway, so the
+    //  runtime retires its completed commands at a steady pace)
+    if (e == hipSuccess && (!arrived || (seq & 255ull) == 0)) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && n && host_out) memcpy(out, res, (size_t)n * sizeof(double));
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets: %s", hipGetErrorString(e));

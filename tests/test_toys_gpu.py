@@ -181,6 +181,29 @@ def test_tiled_dataset_kernel_random_shapes(seed):
         wide, _ = ctx.eval_datasets(None, [1.3])
         ctx.set_param('dot_lanes', 8)
         np.testing.assert_allclose(wide, rows, rtol=1e-13, atol=0)
+        # round 4's short call: descriptors in the kernel arguments (bit 1), the finish with 64 datasets per block (2), the
+        # completion word polled instead of a stream synchronise (4) -- the same numbers whichever way the call travels;
+        # only the finish changes the order of a dataset's ~n_tiles additions
+        assert ctx.get_param('toy_fast_call') == 7
+        polled = ctx.get_param('n_toy_polled')
+        again, _ = ctx.eval_datasets(None, [1.3])
+        np.testing.assert_array_equal(again, tiled)
+        assert ctx.get_param('n_toy_polled') == polled + 1
+        by_bits = {}
+        for bits in (0, 1, 2, 3, 6):
+            ctx.set_param('toy_fast_call', bits)
+            by_bits[bits], st_b = ctx.eval_datasets(None, [1.3])
+            assert st_b == 0
+        ctx.set_param('toy_fast_call', 7)
+        np.testing.assert_array_equal(by_bits[1], by_bits[0])
+        np.testing.assert_array_equal(by_bits[3], by_bits[2])
+        np.testing.assert_array_equal(by_bits[6], by_bits[2])
+        np.testing.assert_array_equal(tiled, by_bits[2])
+        np.testing.assert_allclose(by_bits[2], by_bits[0], rtol=1e-13, atol=0)
+        for k in range(300):                                          # (past a 256th call: those synchronise the stream as well)
+            more, _ = ctx.eval_datasets(None, [1.3 + 0.001 * (k % 3)])
+        more, _ = ctx.eval_datasets(None, [1.3])
+        np.testing.assert_array_equal(more, tiled)
         lo, hi = sorted(rng.choice(T - 64, 2, replace=False))
         part, _ = ctx.eval_datasets(None, [1.3], int(lo), int(hi) + 64)
         np.testing.assert_array_equal(part, tiled[lo:hi + 64])
