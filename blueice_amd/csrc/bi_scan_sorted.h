@@ -275,33 +275,31 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                 for (int kg = 0; kg < KG; ++kg) sv[kg] = cf[loff[kg]];
             }
             for (int i = lo; i < hi; ++i) {
-                // the next item's coefficients are asked for before this item's chains and taken over after its last block:
-                // block by block (one chain, one accumulator at a time) the path stays within the fast loop's registers
-                double sn[KG];
-                {
-                    const double* __restrict__ cf = coef0 + (int64_t)min(i + 1, hi - 1) * coef_step;
+                bi_double4 acc[CB];
 #pragma unroll
-                    for (int kg = 0; kg < KG; ++kg) sn[kg] = cf[loff[kg]];
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};
+                // (the next item's coefficients behind the chains, as in the fast loop)
+                const double* __restrict__ cf = coef0 + (int64_t)min(i + 1, hi - 1) * coef_step;
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[kg][cb], sv[kg], acc[cb], 0, 0, 0);
+                    sv[kg] = cf[loff[kg]];
+                    __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 double tot = 0.0;
                 bool invalid = false;
-#pragma unroll 1
+#pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    bi_double4 acc1 = bi_double4{0.0, 0.0, 0.0, 0.0};
-                    {
-                        double bb[KG];                       // (cb is a run-time index here: pick the block's rows by selects)
 #pragma unroll
-                        for (int kg = 0; kg < KG; ++kg) bb[kg] = cb == 0 ? b[kg][0] : (cb == 1 ? b[kg][1] : (cb == 2 ? b[kg][2] : b[kg][3]));
-#pragma unroll
-                        for (int kg = 0; kg < KG; ++kg) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[kg], sv[kg], acc1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) invalid |= !(acc1[r] >= 0.0);
+                    for (int r = 0; r < 4; ++r) invalid |= !(acc[cb][r] >= 0.0);
                     if (blk_uniform & (1u << cb)) {          // (wave-uniform) one count in the block: n log of the lane's product
-                        const bool ok = acc1[0] > kProdFloor && acc1[1] > kProdFloor && acc1[2] > kProdFloor && acc1[3] > kProdFloor;
-                        const double q = (acc1[0] * acc1[1]) * (acc1[2] * acc1[3]);
+                        const bool ok = acc[cb][0] > kProdFloor && acc[cb][1] > kProdFloor && acc[cb][2] > kProdFloor && acc[cb][3] > kProdFloor;
+                        const double q = (acc[cb][0] * acc[cb][1]) * (acc[cb][2] * acc[cb][3]);
                         if (__builtin_amdgcn_ballot_w64(ok && pos_normal(q)) == ~0ull) {
-                            tot += lane_value(c_lane, cb * 16) * bin_log_fast(q);
+                            tot += n_blk[cb] * bin_log_fast(q);
                             continue;
                         }
                     }
@@ -310,17 +308,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         n[r] = s_cnt[wave][cb * 16 + 4 * r + kq];
-                        checked |= n[r] > 0.0 && !pos_normal(acc1[r]);
+                        checked |= n[r] > 0.0 && !pos_normal(acc[cb][r]);
                     }
                     if (__builtin_amdgcn_ballot_w64(checked) == 0ull) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const double lg = bin_log_fast(acc1[r]);
+                            const double lg = bin_log_fast(acc[cb][r]);
                             tot += n[r] > 0.0 ? n[r] * lg : 0.0;
                         }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tot += n[r] > 0.0 ? n[r] * bin_log(acc1[r]) : 0.0;
+                        for (int r = 0; r < 4; ++r) tot += n[r] > 0.0 ? n[r] * bin_log(acc[cb][r]) : 0.0;
                     }
                     if (strip_odd) {                         // (wave-uniform) negative / non-integer / nan counts in this strip
 #pragma unroll
@@ -334,8 +332,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                 tot = rows4_sum(tot);
                 if (kq == 0) unsafeAtomicAdd(part0 + (int64_t)i * dst_step + col, tot);
                 if (i == lo) first = tot;
-#pragma unroll
-                for (int kg = 0; kg < KG; ++kg) sv[kg] = sn[kg];
             }
             if (!fast) break;
             // A quad left the window of the product form: centre the window on this strip's own terms (the first point of
