@@ -401,7 +401,8 @@ def toy_leg(ctx, ranks, model, T, steps):
     kernel_ms = ranks.max_over_ranks(kernel_ms)
     ctx.set_param('toy_offset', 0)
     # algorithmic bytes of a call on this rank: the 2^d*S template rows once (log mu of every bin) + 4 bytes per list entry
-    # (13 bits of bin, 19 bits of count) of every dataset; the entries are gathered against a tile of log mu held in LDS
+    # (the bin's byte offset within its tile and 15 bits of count) of every dataset; the entries are gathered against a tile of
+    # log mu held in LDS (runs are padded to 16-byte groups: at most 3 more entries per dataset and tile, not counted here)
     NS = 2 ** model.d * model.S
     nbytes = 8.0 * NS * model.B + 4.0 * nnz
     step_ms = elapsed / steps * 1e3
