@@ -7,9 +7,10 @@ import numpy as np
 _P = C.c_void_p
 
 
-def load():
+def load(path=None):
+    """path = None: the host build; tests/test_minimal_abi_gpu.py passes libblueice_hip.so -- the SAME signatures, the product."""
     from blueice_amd import build
-    lib = C.CDLL(build.build_host())
+    lib = C.CDLL(path or build.build_host())
     lib.bi_create.argtypes = [C.c_int, C.POINTER(_P)]
     lib.bi_destroy.argtypes = [_P]
     lib.bi_destroy.restype = None
