@@ -525,7 +525,7 @@ def unbinned_leg(ctx, model, n_events=1000000, steps=24):
                     bound='hbm', events=n_events, bytes_per_launch=nbytes, avg_launch_us=ms / n * 1e3, achieved=gbs,
                     peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, evals_per_s=PPS * n / (ms * 1e-3),
                     set_data_on_device_s=score_s,
-                    set_data_note='k_score_events fills the [125 anchors][4 sources][%d events] tensor (%.1f GB) from the 3 x N '
+                    set_data_note='k_score_locate + k_score_rows fill the [125 anchors][4 sources][%d events] tensor (%.1f GB) from the 3 x N '
                                   'coordinates: %.1f M pdf values per second' % (n_events, 8e-9 * model.A * model.S * n_events,
                                                                                model.A * model.S * n_events / score_s / 1e6))
     finally:

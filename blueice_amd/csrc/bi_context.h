@@ -113,6 +113,9 @@ struct bi_ctx {
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
     bool tm_ok = false;                       // ... and whether every count fits its 19 bits
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
+    int64_t score_sorted = 1;                 // parameter: bi_score_events / bi_simulate_events order the events by cell before the gathers
+    DevBuf ev_perm;                           // [events] sorted position -> the caller's event (valid while ev_sorted)
+    bool ev_sorted = false;                   // the unbinned tensor's columns are in sorted order
     int64_t toy_fast_call = 7;                // parameter, bits: 1 descriptors in the kernel arguments, 2 parallel finish (k_dataset_finish_tiled), 4 poll the completion word
     DevBuf toy_blocks_done;                   // the finish kernel's block counter (zero between calls)
     bool toy_blocks_done_zeroed = false;

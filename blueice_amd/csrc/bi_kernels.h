@@ -1019,7 +1019,8 @@ __global__ void k_rows_sum(const double* __restrict__ partial, int nblk, double*
 __global__ __launch_bounds__(kThreads) void k_morph_store(const double* __restrict__ src,
                                                           const int64_t* __restrict__ rowoff,  // [R][nc]
                                                           const double* __restrict__ w,        // [nc]
-                                                          int nc, int64_t B, double* __restrict__ out) {
+                                                          int nc, int64_t B, double* __restrict__ out,
+                                                          const int32_t* __restrict__ place = nullptr) {
     const int r = blockIdx.y;
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
@@ -1028,7 +1029,8 @@ __global__ __launch_bounds__(kThreads) void k_morph_store(const double* __restri
         const double term = __dmul_rn(src[rowoff[(int64_t)r * nc + c] + b], w[c]);
         v = __dadd_rn(v, term);
     }
-    out[(int64_t)r * B + b] = v;
+    // place: column b of the tensor is the caller's column place[b] (unbinned data whose events were ordered by cell)
+    out[(int64_t)r * B + (place ? (int64_t)place[b] : b)] = v;
 }
 
 // sum over bins of one padded row -> out[row]  (used for the Beeston-Barlow N table)
@@ -1853,14 +1855,24 @@ struct ScoreArgs {
     int64_t stride[kMaxDim];     // bins (C order) per step along the axis
 };
 
-__global__ __launch_bounds__(kThreads) void k_score_events(const double* __restrict__ coords /*[k][N]*/, int64_t N, ScoreArgs a,
-                                                           const double* __restrict__ grid, const double* __restrict__ rows,
-                                                           int64_t row_stride, int n_rows, double* __restrict__ out,
-                                                           int64_t out_stride) {
+// Two passes (round 4).  Round 3's single kernel -- one thread per event looping over all anchors x sources rows -- let its
+// blocks drift apart over the rows, so the 10^9-byte-scale gathers of 10^6 events came from a working set of gigabytes:
+// every 8-byte value cost a whole memory transaction (10.6 ms for the 4 GB tensor of the C2 shape = 0.05 of the HBM peak).
+// Now (1) k_score_locate finds every event's cell and interpolation weights ONCE, and (2) k_score_rows has the ROW as the
+// slow grid dimension: blocks are dispatched row by row, so at any time the gathers of the whole chip fall into one or two
+// 8 MB histograms that stay in L2 / Infinity Cache, and each histogram is read from HBM once (6.1 ms).  And (3) between the
+// two the events are ORDERED BY CELL (radix sort of the cell indices, stable): the events of a block then fall into a few
+// consecutive cache lines of the histogram, every line is fetched once per block instead of once per event, and the
+// kernel becomes the stream it should be -- 4 GB in, 4 GB out.  The tensor's columns are then in sorted order; `perm`
+// (sorted position -> the caller's event) stays with the context and bi_interpolate / bi_eval_full hand per-event values
+// back in the caller's order, so the order is visible only to sums over events (1e-10, not bitwise, against a host-scored
+// tensor).  Same arithmetic per value in the same order as before: bit-identical values.
+__global__ __launch_bounds__(kThreads) void k_score_locate(const double* __restrict__ coords /*[k][N]*/, int64_t N, ScoreArgs a,
+                                                           const double* __restrict__ grid, int64_t* __restrict__ base_out,
+                                                           double* __restrict__ t_out /*[k][N], method 1 only*/) {
     const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (e >= N) return;
     int64_t base = 0;
-    double t[kMaxDim];
     for (int ax = 0; ax < a.k; ++ax) {
         double x = coords[(int64_t)ax * N + e];
         const double* __restrict__ g = grid + a.grid_off[ax];
@@ -1880,28 +1892,70 @@ __global__ __launch_bounds__(kThreads) void k_score_events(const double* __restr
             }
         }
         const int i = min(max(lo - 1, 0), n - 2);
-        t[ax] = a.method == 1 ? (x - g[i]) / (g[i + 1] - g[i]) : 0.0;
+        if (a.method == 1) t_out[(int64_t)ax * N + e] = (x - g[i]) / (g[i + 1] - g[i]);
         base += i * a.stride[ax];
     }
+    base_out[e] = base;
+}
+
+// events per thread of k_score_rows (their gathers are in flight together; one event where 2^K corners are many already)
+constexpr int score_events_per_thread(int K) { return K <= 3 ? 4 : 1; }
+
+// K: analysis dimensions of the 'linear' method (0 = 'piecewise': one value per event and row)
+template <int K>
+__global__ __launch_bounds__(kThreads) void k_score_rows(const int64_t* __restrict__ base_in, const double* __restrict__ t_in, int64_t N,
+                                                         ScoreArgs a, const double* __restrict__ rows, int64_t row_stride, int n_rows,
+                                                         double* __restrict__ out, int64_t out_stride,
+                                                         const int32_t* __restrict__ perm /*NULL: base_in in event order*/) {
+    constexpr int kScoreEvents = score_events_per_thread(K);
+    const int64_t e0 = (int64_t)blockIdx.x * (kThreads * kScoreEvents) + threadIdx.x;
+    int64_t base[kScoreEvents];
+    double t[kScoreEvents][K > 0 ? K : 1];
+#pragma unroll
+    for (int j = 0; j < kScoreEvents; ++j) {
+        const int64_t e = min(e0 + (int64_t)j * kThreads, N - 1);
+        base[j] = base_in[e];                        // (sorted keys when perm is given)
+        const int64_t ev = perm ? (int64_t)perm[e] : e;
+#pragma unroll
+        for (int ax = 0; ax < K; ++ax) t[j][ax] = t_in[(int64_t)ax * N + ev];
+    }
     for (int r = blockIdx.y; r < n_rows; r += gridDim.y) {
-        const double* __restrict__ src = rows + (int64_t)r * row_stride + base;
-        double value;
-        if (a.method == 0) {
-            value = src[0];
+        const double* __restrict__ row = rows + (int64_t)r * row_stride;
+        double value[kScoreEvents];
+        if constexpr (K == 0) {
+#pragma unroll
+            for (int j = 0; j < kScoreEvents; ++j) value[j] = row[base[j]];
         } else {
-            value = 0.0;
-            for (int corner = 0; corner < (1 << a.k); ++corner) {
-                double weight = 1.0;
-                int64_t off = 0;
-                for (int ax = 0; ax < a.k; ++ax) {
-                    const bool up = (corner >> (a.k - 1 - ax)) & 1;
-                    weight = weight * (up ? t[ax] : 1.0 - t[ax]);
-                    if (up) off += a.stride[ax];
+#pragma unroll
+            for (int j = 0; j < kScoreEvents; ++j) {
+                const double* __restrict__ src = row + base[j];
+                double v = 0.0;
+                auto add_corner = [&](int corner) {
+                    double weight = 1.0;
+                    int64_t off = 0;
+#pragma unroll
+                    for (int ax = 0; ax < K; ++ax) {
+                        const bool up = (corner >> (K - 1 - ax)) & 1;
+                        weight = weight * (up ? t[j][ax] : 1.0 - t[j][ax]);
+                        if (up) off += a.stride[ax];
+                    }
+                    v = v + src[off] * weight;
+                };
+                if constexpr (K <= 3) {
+#pragma unroll
+                    for (int corner = 0; corner < (1 << K); ++corner) add_corner(corner);
+                } else {
+#pragma unroll 1
+                    for (int corner = 0; corner < (1 << K); ++corner) add_corner(corner);
                 }
-                value = value + src[off] * weight;
+                value[j] = v;
             }
         }
-        out[(int64_t)r * out_stride + e] = value;
+#pragma unroll
+        for (int j = 0; j < kScoreEvents; ++j) {
+            const int64_t e = e0 + (int64_t)j * kThreads;
+            if (e < N) out[(int64_t)r * out_stride + e] = value[j];
+        }
     }
 }
 
@@ -1974,7 +2028,7 @@ __global__ __launch_bounds__(kThreads) void k_sim_events(const double* __restric
         rem -= i * a.stride[ax];
         const double* __restrict__ ed = edges + a.edge_off[ax];
         // (uniform inside the bin, as Histdd.get_random draws it, source.py:248-264; a 'linear' pdf clips to the outer bin
-        //  centres only when it is EVALUATED, source.py:231-239: k_score_events does that, the stored events stay as drawn)
+        //  centres only when it is EVALUATED, source.py:231-239: k_score_locate does that, the stored events stay as drawn)
         coords[(int64_t)ax * N + e] = ed[i] + u * (ed[i + 1] - ed[i]);
     }
     source[e] = s;

@@ -63,6 +63,7 @@ const ParamDef kParams[] = {
     {"bb_exact", kParamRW, BI_P_GET(c->bb_exact), BI_P_RANGE(0, 2, bb_exact, "bb_exact: 0 never, 1 always, 2 auto")},
     {"toy_events", kParamRW, BI_P_GET(c->toy_events), BI_P_FLAG(toy_events)},
     {"dot_tiled", kParamRW, BI_P_GET(c->dot_tiled), BI_P_FLAG(dot_tiled)},
+    {"score_sorted", kParamRW, BI_P_GET(c->score_sorted), BI_P_FLAG(score_sorted)},
     {"toy_fast_call", kParamRW, BI_P_GET(c->toy_fast_call), BI_P_RANGE(0, 7, toy_fast_call, "toy_fast_call: bits 1 | 2 | 4")},
     {"dot_blocks_per_cu", kParamRW, BI_P_GET(c->dot_blocks_per_cu), BI_P_RANGE(0, 16, dot_blocks_per_cu, "dot_blocks_per_cu in [0, 16]")},
     {"dot_lanes", kParamRW, BI_P_GET(c->dot_lanes), BI_P_SET(c->dot_lanes = v == 16 ? 16 : 8)},
@@ -84,6 +85,7 @@ const ParamDef kParams[] = {
     BI_P_RO("padded_bins", c->Bp),
     BI_P_RO("n_scan_launches", c->n_scan_launches),
     BI_P_RO("n_toy_polled", c->n_toy_polled),
+    BI_P_RO("events_sorted", c->ev_sorted ? 1 : 0),
     BI_P_RO("n_grad_mfma_launches", c->n_grad_mfma_launches),
     BI_P_RO("n_valid_launches", c->n_valid_launches),
     BI_P_RO("n_sorted_scans", c->n_sorted_scans),

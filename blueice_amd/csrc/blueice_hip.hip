@@ -117,7 +117,7 @@ void bi_destroy(bi_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->ps); dev_free(c->nm); dev_free(c->nm_tot); dev_free(c->counts); dev_free(c->lgsum);
-    dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu); dev_free(c->toy_blocks_done);
+    dev_free(c->scratch); dev_free(c->scratch2); dev_free(c->logmu); dev_free(c->toy_blocks_done); dev_free(c->ev_perm);
     dev_free(c->slot_dev); dev_free(c->slot_partial); dev_free(c->slot_pflags); dev_free(c->slot_counter); dev_free(c->space_edges);
     dev_free(c->mail); dev_free(c->mail_flags);
     dev_free(c->ps_sorted); dev_free(c->cnt_sorted);
@@ -203,6 +203,7 @@ int bi_model_begin(bi_ctx* c, int d, const int32_t* n_anchor, const double* anch
     c->d = d; c->S = S; c->B = B; c->bb_source = bb_source;
     c->Bp = std::max<int64_t>(kTile, (B + kTile - 1) / kTile * kTile);
     c->unbinned = false;
+    c->ev_sorted = false;
     c->n_anchor.assign(d, 0);
     c->grid.assign(d, {});
     c->A = 1;
@@ -1576,25 +1577,58 @@ int score_events_impl(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n
     int rc = bi_model_begin(c, tp->d, na.data(), az.data(), tp->S, N, -1);
     if (rc) return rc;
     if (N > 0) {
-        DevBuf d_ev, d_grid;
-        if ((!coords_dev && (rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double)))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double)))) {
-            dev_free(d_ev); dev_free(d_grid);
+        DevBuf d_ev, d_grid, d_base, d_t, d_keys, d_iota, d_tmp;
+        auto drop = [&]() { dev_free(d_ev); dev_free(d_grid); dev_free(d_base); dev_free(d_t); dev_free(d_keys); dev_free(d_iota); dev_free(d_tmp); };
+        // events ordered by cell (see k_score_rows): from a few thousand events on, and while 32-bit positions do
+        const bool sorted = c->score_sorted && N >= 4096 && N < ((int64_t)1 << 31);
+        size_t sort_bytes = 0;
+        if (sorted) (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr,
+                                                    (int32_t*)nullptr, (size_t)N, 0u, 64u, c->stream);
+        if ((!coords_dev && (rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double)))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double))) ||
+            (rc = dev_alloc(c, d_base, (size_t)N * sizeof(int64_t))) || (method == 1 && (rc = dev_alloc(c, d_t, (size_t)N * k * sizeof(double)))) ||
+            (sorted && ((rc = dev_alloc(c, d_keys, (size_t)N * sizeof(int64_t))) || (rc = dev_alloc(c, d_iota, (size_t)N * sizeof(int32_t))) ||
+                        (rc = dev_alloc(c, d_tmp, std::max<size_t>(sort_bytes, 256))) || (rc = dev_alloc(c, c->ev_perm, (size_t)N * sizeof(int32_t)))))) {
+            drop();
             return rc;
         }
         hipError_t e = coords_dev ? hipSuccess : hipMemcpyAsync(d_ev.p, coords, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_grid.p, grid, (size_t)off * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(tp->stream);            // whatever filled the templates is complete
         if (e == hipSuccess) {
+            // every event's cell and weights once, then the gathers row by row: the row is the slow dimension of the grid, so
+            // the chip works on one or two 8 MB histograms at a time (see k_score_rows)
             const int n_rows = (int)(tp->A * tp->S);
-            const unsigned bx = (unsigned)((N + kThreads - 1) / kThreads);
-            const unsigned by = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)c->prop.multiProcessorCount * 8 / bx));
-            hipLaunchKernelGGL(k_score_events, dim3(bx, by), dim3(kThreads), 0, c->stream, coords_dev ? coords_dev : (const double*)d_ev.p, N, a,
-                               (const double*)d_grid.p, (const double*)tp->ps.p, tp->Bp, n_rows, (double*)c->ps.p, c->Bp);
-            e = hipGetLastError();
+            hipLaunchKernelGGL(k_score_locate, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                               coords_dev ? coords_dev : (const double*)d_ev.p, N, a, (const double*)d_grid.p, (int64_t*)d_base.p, (double*)d_t.p);
+            const int64_t* base_used = (const int64_t*)d_base.p;
+            if (sorted) {
+                hipLaunchKernelGGL(k_iota32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int32_t*)d_iota.p, N);
+                size_t tb = d_tmp.bytes;
+                // (the cell index needs ceil(log2 B) bits: fewer radix passes than 64)
+                unsigned bits = 1;
+                while (bits < 63 && ((int64_t)1 << bits) < tp->B) ++bits;
+                e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const int64_t*)d_base.p, (int64_t*)d_keys.p, (const int32_t*)d_iota.p,
+                                              (int32_t*)c->ev_perm.p, (size_t)N, 0u, bits, c->stream);
+                base_used = (const int64_t*)d_keys.p;
+            }
+            const int per_block = kThreads * score_events_per_thread(method == 0 ? 0 : k);
+            const unsigned bx = (unsigned)((N + per_block - 1) / per_block);
+#define BI_ROWS(K)                                                                                                 \
+    hipLaunchKernelGGL((k_score_rows<K>), dim3(bx, (unsigned)std::min(n_rows, 65535)), dim3(kThreads), 0, c->stream, \
+                       base_used, (const double*)d_t.p, N, a, (const double*)tp->ps.p, tp->Bp, n_rows, (double*)c->ps.p, c->Bp,        \
+                       sorted ? (const int32_t*)c->ev_perm.p : (const int32_t*)nullptr)
+            if (e == hipSuccess) switch (method == 0 ? 0 : k) {
+                case 0: BI_ROWS(0); break; case 1: BI_ROWS(1); break; case 2: BI_ROWS(2); break; case 3: BI_ROWS(3); break;
+                case 4: BI_ROWS(4); break; case 5: BI_ROWS(5); break; case 6: BI_ROWS(6); break; case 7: BI_ROWS(7); break;
+                default: BI_ROWS(8); break;
+            }
+#undef BI_ROWS
+            if (e == hipSuccess) e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);              // coords are borrowed for the call only
         else (void)hipStreamSynchronize(c->stream);
-        dev_free(d_ev); dev_free(d_grid);
+        drop();
+        c->ev_sorted = e == hipSuccess && sorted;
         if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_score_events: %s", hipGetErrorString(e));
     }
     c->h_mus = tp->h_mus;
@@ -1765,7 +1799,9 @@ int bi_interpolate(bi_ctx* c, int which, const double* z, double* out) {
         (rc = dev_alloc(c, d_out, (size_t)R * c->B * sizeof(double)))) { cleanup(); return rc; }
     hipLaunchKernelGGL(k_morph_store, dim3((unsigned)((c->B + kThreads - 1) / kThreads), (unsigned)R), dim3(kThreads), 0,
                        c->stream, which == 0 ? (const double*)c->ps.p : (const double*)c->nm.p,
-                       (const int64_t*)d_row.p, (const double*)d_w.p, nc, c->B, (double*)d_out.p);
+                       (const int64_t*)d_row.p, (const double*)d_w.p, nc, c->B, (double*)d_out.p,
+                       // (an unbinned tensor scored on the device holds its events ordered by cell: back to the caller's order)
+                       which == 0 && c->ev_sorted ? (const int32_t*)c->ev_perm.p : (const int32_t*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out.p, (size_t)R * c->B * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

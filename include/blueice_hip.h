@@ -382,6 +382,10 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     default) or 16 (128 slots, 64 runs in flight: round 3)
  *   dot_blocks_per_cu ... blocks of that kernel per CU its split of the datasets aims at: 0 = as many as are resident at once (one
  *                     round of blocks; default), n = n per CU
+ *   score_sorted      bi_score_events / bi_simulate_events (set on the TARGET context): from 4096 events on, the events are ordered
+ *                     by histogram cell before their densities are gathered, so the gathers stream through the histograms; the
+ *                     tensor's columns are then in that order, which only sums over events can see -- bi_interpolate and
+ *                     bi_eval_full return per-event values in the caller's order (1, default; read-only `events_sorted`)
  *   toy_fast_call     bi_eval_datasets, bits: 1 = the point's descriptors travel in the kernel arguments (no copy ahead of the launch),
  *                     2 = the tiled kernel's partial sums are finished 64 datasets per block, tiles split over its four waves,
  *                     4 = results of up to 4 MB: the call polls a completion word behind them instead of synchronising the
@@ -407,7 +411,7 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     fails does the same before it gives up
  *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
  *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
- * read-only: tile_bins, padded_bins, n_scan_launches, n_toy_polled (bi_eval_datasets calls that returned on the completion word), n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_toy_polled (bi_eval_datasets calls that returned on the completion word), events_sorted, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
  *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
  *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of

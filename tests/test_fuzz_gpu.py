@@ -519,7 +519,7 @@ def test_fuzz_event_scoring(seed):
     from blueice_amd.device import DeviceContext
     from blueice_amd.histdd import Histdd
     rng = np.random.default_rng(9000 + seed)
-    k = int(rng.integers(1, 4))
+    k = int(rng.integers(1, 6))            # (up to 3 axes: four events per thread, corners unrolled; 4, 5: one event, a corner loop)
     S = int(rng.integers(1, 4))
     d = int(rng.integers(0, 3))
     method = 'linear' if rng.random() < 0.6 else 'piecewise'
@@ -535,7 +535,7 @@ def test_fuzz_event_scoring(seed):
     dens = rng.random((A, S) + shape) ** 2
     dens[rng.random(dens.shape) < 0.1] = 0.0
     mus = rng.uniform(1, 30, (A, S))
-    N = int(rng.integers(1, 300))
+    N = int(rng.integers(1, 300)) if rng.random() < 0.7 else int(rng.integers(1000, 5000))     # (several blocks of 1024 events)
     cols = [rng.uniform(e[0], e[-1], N) for e in edges]
     for ax, e in enumerate(edges):                                             # limits, an inner edge, a bin centre
         special = np.array([e[0], e[-1], e[1], 0.5 * (e[0] + e[1]), 0.5 * (e[-2] + e[-1])])[:N]

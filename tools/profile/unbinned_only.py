@@ -1,4 +1,4 @@
-"""The extended unbinned likelihood on the C2 shape with 10^6 events: k_score_events (set_data on the device), then
+"""The extended unbinned likelihood on the C2 shape with 10^6 events: k_score_locate + k_score_rows (set_data on the device), then
 k_morph_reduce<1,false,true,2>, 8 evaluations per launch in disjoint grid cells -- the command the rocprofv3 passes of
 profiles/rNN_unbinned_* wrap (bench.py's `unbinned` leg as a stand-alone).  usage: python tools/profile/unbinned_only.py [launches]"""
 import sys, time

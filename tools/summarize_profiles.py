@@ -119,7 +119,7 @@ def summarize_unbinned(tag, dst):
     shutil.copy(kt, os.path.join(dst, tag + '_unbinned_kernel_stats.csv'))
     needle = 'k_morph_reduce<1, false, true, 2>'
     st = _kernel_stats(kt, needle)
-    score = _kernel_stats(kt, 'k_score_events')
+    score = _kernel_stats(kt, 'k_score_rows') or _kernel_stats(kt, 'k_score_events')     # (k_score_events: round 3's single kernel)
     fetch, n = _kernel_counters(os.path.join(SRC, 'unbfetch', 'unb_counter_collection.csv'), needle)
     algo = 8 * 8 * 32 * 10 ** 6
     rd = fetch['FETCH_SIZE'] * 1024 * 2
@@ -132,7 +132,7 @@ def summarize_unbinned(tag, dst):
            'traffic_over_algorithmic': rd / algo, 'hip_event_line': open(os.path.join(SRC, 'unb_plain.txt')).read().strip()}
     with open(os.path.join(dst, tag + '_unbinned.json'), 'w') as f:
         json.dump(out, f, indent=1)
-    print('unbinned kernel: %.1f us -> %.0f GB/s (%.3f of 8 TB/s), traffic / algorithmic %.4f; k_score_events %.1f us' % (
+    print('unbinned kernel: %.1f us -> %.0f GB/s (%.3f of 8 TB/s), traffic / algorithmic %.4f; event scoring kernel %.1f us' % (
         st['average_us'], out['achieved_GBps'], out['frac_of_8TBps'], out['traffic_over_algorithmic'], score['average_us'] if score else -1))
 
 
