@@ -159,6 +159,7 @@ struct bi_ctx {
     int64_t grad_slices = 0;                     // ... slices a cell's 16-bin blocks are split into (0 = by the batch)
     int64_t n_grad_mfma_launches = 0;
     int64_t scan_xcd = 1;                        // k_scan_sorted: how the (group, block) pairs are dealt to the 8 XCDs (0 launch order, 1 contiguous ranges, 2 group g -> XCD g mod 8)
+    int64_t scan_share_slow = 1;                 // parameter: k_scan_sorted deals the items of mixed-count strips over all waves of the cell
     int64_t scan_waves_per_cu = 0;               // scan kernels: 0 = the planner sizes the split by occupancy; > 0 forces that many waves per CU
     int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
     int64_t last_single_cell = -1, last_single_ds = -1;

@@ -2323,6 +2323,7 @@ struct ScanArgs {
     int nslots;                 // waves per group = gridDim.x * 4
     int n_groups;               // k_scan_sorted (one-dimensional grid, dealt to the XCDs in contiguous ranges of blocks)
     int xcd_mode;               // 0 launch order, 1 contiguous ranges (default), 2 group g -> XCD g mod 8
+    int share_slow;             // k_scan_sorted: strips of mixed counts are worked by all waves of the cell together
 };
 
 // sum of a double over the 4 DPP rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): one half-row exchange and one half-wave

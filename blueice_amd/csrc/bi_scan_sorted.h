@@ -123,7 +123,42 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     int sc = 0;                                                         // the rows in registers are the templates * 2^sc
     int sc_learnt = 0;                                                  // the scale this wave's last slow quad asked for
 
-    for (int strip = slot; strip < n_strips; strip += a.nslots) {
+    // A strip that is worked item by item costs about 25 strips of the product form, and the wave that owns it would still
+    // be at it long after the cell's other waves have finished (ONE such strip -- the end of the data next to the padding --
+    // was 14 % of a 10^6-point scan of C2's 9930 non-empty bins).  So a wave does all items only of its own UNIFORM strips
+    // (first count == last count: in count order that is what uniform means); the others are done afterwards by ALL waves of
+    // the cell together, wave w taking items w, w + nslots, ... of each -- into its own partial slot, as always.  Both passes
+    // use the same predicate, so every strip is worked exactly once whatever its counts are.
+    const bool share = a.nslots > 1 && a.share_slow;
+    int own_strip = slot, batch0 = -64;
+    unsigned long long batch = 0ull;
+    bool shared = false;
+    while (true) {
+        int strip;
+        if (!shared) {
+            if (own_strip >= n_strips) {
+                if (!share) break;
+                shared = true;
+                continue;
+            }
+            strip = own_strip;
+            own_strip += a.nslots;
+            if (share && !(cnt[(int64_t)strip * STRIP] == cnt[(int64_t)strip * STRIP + STRIP - 1])) continue;
+        } else {
+            if (batch == 0ull) {                             // the next 64 strips, one per lane
+                batch0 += 64;
+                if (batch0 >= n_strips) break;
+                const int s = min(batch0 + lane, n_strips - 1);
+                const bool mixed = !(cnt[(int64_t)s * STRIP] == cnt[(int64_t)s * STRIP + STRIP - 1]);
+                batch = __builtin_amdgcn_ballot_w64(mixed && batch0 + lane < n_strips);
+                continue;
+            }
+            const int bit = __builtin_ctzll(batch);
+            batch &= batch - 1;
+            strip = batch0 + bit;
+        }
+        // items of this strip that this wave works: all of them, or its share
+        const int i_first = shared ? slot : 0, i_step = shared ? a.nslots : 1;
         const int64_t bin0 = (int64_t)strip * STRIP;
         double b[KG][CB];
 #define BI_LOAD_ROWS()                                                                                             \
@@ -191,7 +226,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 
         int it = 0;
         while (true) {
-            int lo = 0, hi = n_items;
+            int lo = i_first, hi = n_items;
+            if (lo >= hi) break;
             if (fast) {
                 // one loop per class (compile-time Z): the class test stays out of the item loop
                 auto quads = [&](auto ztag) -> int {
@@ -274,12 +310,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg) sv[kg] = cf[loff[kg]];
             }
-            for (int i = lo; i < hi; ++i) {
+            const int step = fast ? 1 : i_step;              // (a quad that left the product form: its four items; a mixed strip: this wave's share)
+            for (int i = lo; i < hi; i += step) {
                 bi_double4 acc[CB];
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};
                 // (the next item's coefficients behind the chains, as in the fast loop)
-                const double* __restrict__ cf = coef0 + (int64_t)min(i + 1, hi - 1) * coef_step;
+                const double* __restrict__ cf = coef0 + (int64_t)(i + step < hi ? i + step : i) * coef_step;
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg) {
 #pragma unroll

@@ -619,6 +619,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             if (plan->by_count) {
                 sa.n_groups = (int)plan->n_groups;
                 sa.xcd_mode = (int)c->scan_xcd;
+                sa.share_slow = (int)c->scan_share_slow;
                 const int64_t scan_blocks = (int64_t)(k.nbx / 4) * (c->scan_xcd == 2 ? (plan->n_groups + 7) / 8 * 8 : plan->n_groups);
                 const dim3 sgrid((unsigned)((scan_blocks + 7) / 8 * 8));
                 switch ((NS + 3) / 4) {           // the exact number of 4-stream groups: no matrix work on padding

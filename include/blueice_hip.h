@@ -390,6 +390,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     2 = the tiled kernel's partial sums are finished 64 datasets per block, tiles split over its four waves,
  *                     4 = results of up to 4 MB: the call polls a completion word behind them instead of synchronising the
  *                     stream (needs 2 and poll_result; every 256th call synchronises anyway).  7 (default)
+ *   scan_share_slow   k_scan_sorted: a strip whose 64 bins do not carry one count (two runs meet, the end of the data) is worked item by
+ *                     item, ~25 times the cost of a uniform strip; with 1 (default) the items of such strips are dealt over ALL waves
+ *                     of the cell instead of staying with the wave that owns the strip
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows
  *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
  *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)
