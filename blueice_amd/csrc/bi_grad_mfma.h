@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
     constexpr int NB = KG >= 4 ? KG / 4 : 1;       // blocks of 16 streams (product 2's N dimension)
     constexpr int NSP = 16 * NB;
     const int grp = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kq = lane >> 4, col = lane & 15;
     // (product 2 reads the rows of streams 0 .. 16 NB - 1 -- more than the 4 KG of product 1 when KG < 4: every index is
     //  clamped to a valid row here, and the rows of streams beyond NS are zeroed where they are loaded)

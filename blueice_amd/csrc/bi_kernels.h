@@ -2360,7 +2360,7 @@ template <int CB, int KG, bool MASK, int PROD = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
     constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int slot = blockIdx.x * 4 + wave;
     const int64_t item0 = a.grp_first[grp];
     const int n_items = a.grp_items[grp];
@@ -2557,7 +2557,7 @@ template <int CB, int KG, bool MASK>
 __global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
     constexpr int STRIP = CB * 16;
     const int grp = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int slot = blockIdx.x * 4 + wave;
     const int64_t item0 = a.grp_first[grp];
     const int n_items = a.grp_items[grp];

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     else if (a.xcd_mode == 2) linear = (((blockIdx.x >> 3) / gx) * 8 + (blockIdx.x & 7)) * gx + (blockIdx.x >> 3) % gx;
     if (linear >= total) return;
     const int grp = (int)(linear / gx);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (readfirstlane: everything derived from the wave's number -- its slot, its strips, the item ranges of the shared pass -- is
+    //  then scalar for the compiler too; taken for lane-dependent, the item loops' address arithmetic moves to the vector unit)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int slot = (int)(linear % gx) * 4 + wave;
     const int64_t item0 = a.grp_first[grp];
     const int n_items = a.grp_items[grp];
@@ -130,32 +132,35 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     // the cell together, wave w taking items w, w + nslots, ... of each -- into its own partial slot, as always.  Both passes
     // use the same predicate, so every strip is worked exactly once whatever its counts are.
     const bool share = a.nslots > 1 && a.share_slow;
-    int own_strip = slot, batch0 = -64;
-    unsigned long long batch = 0ull;
+    // (loop state: ONE cursor and the pass -- the kernel is at its limit of scalar registers, and what does not fit is
+    //  computed with vector instructions inside the item loops)
+    int cursor = slot;
     bool shared = false;
     while (true) {
         int strip;
         if (!shared) {
-            if (own_strip >= n_strips) {
+            if (cursor >= n_strips) {
                 if (!share) break;
                 shared = true;
+                cursor = 0;
                 continue;
             }
-            strip = own_strip;
-            own_strip += a.nslots;
+            strip = cursor;
+            cursor += a.nslots;
             if (share && !(cnt[(int64_t)strip * STRIP] == cnt[(int64_t)strip * STRIP + STRIP - 1])) continue;
         } else {
-            if (batch == 0ull) {                             // the next 64 strips, one per lane
-                batch0 += 64;
-                if (batch0 >= n_strips) break;
-                const int s = min(batch0 + lane, n_strips - 1);
-                const bool mixed = !(cnt[(int64_t)s * STRIP] == cnt[(int64_t)s * STRIP + STRIP - 1]);
-                batch = __builtin_amdgcn_ballot_w64(mixed && batch0 + lane < n_strips);
+            if (cursor >= n_strips) break;
+            // the 64 strips around the cursor, one per lane; the first mixed one at or behind it
+            const int batch0 = cursor & ~63;
+            const int s = min(batch0 + lane, n_strips - 1);
+            const bool mixed = !(cnt[(int64_t)s * STRIP] == cnt[(int64_t)s * STRIP + STRIP - 1]);
+            const unsigned long long batch = __builtin_amdgcn_ballot_w64(mixed && batch0 + lane < n_strips && batch0 + lane >= cursor);
+            if (batch == 0ull) {
+                cursor = batch0 + 64;
                 continue;
             }
-            const int bit = __builtin_ctzll(batch);
-            batch &= batch - 1;
-            strip = batch0 + bit;
+            strip = batch0 + __builtin_ctzll(batch);
+            cursor = strip + 1;
         }
         // items of this strip that this wave works: all of them, or its share
         const int i_first = shared ? slot : 0, i_step = shared ? a.nslots : 1;

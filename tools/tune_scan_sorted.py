@@ -9,7 +9,7 @@ m = SyntheticModel.named('C2')
 ctx = DeviceContext(0)
 m.upload(ctx, threads=8)
 for label, sparse, dense, P, wpcs in (('dense data, every bin', 0, True, 131072, (0, 48, 80, 96)),
-                                      ('default path', 1, False, 1000000, (0, 8, 20))):
+                                      ('default path', 1, False, 1000000, (0, 4, 6, 8, 12, 16, 20, 24))):
     ctx.set_param('sparse', sparse)
     ctx.upload_counts(m.counts(dense=dense))
     z, r = m.random_points(P, seed=11)
