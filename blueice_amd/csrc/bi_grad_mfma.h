@@ -117,16 +117,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int r = 0; r < 4; ++r) odd_lane |= n4[r] != n4[r] || n4[r] < 0.0 || n4[r] != floor(n4[r]);
         const bool odd = __builtin_amdgcn_ballot_w64(odd_lane) != 0ull;
 
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bi_double4 mu = bi_double4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) mu = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[j][kg], mu, 0, 0, 0);
-            // sum_b n log mu over the lane's four bins of its point (scipy's values for every argument)
-            bool neg = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) neg |= !(mu[r] >= 0.0);
-            bad[j] |= neg;
+        // The four items in PAIRS: two chains of product 1 interleaved, then -- where the block takes the product form for
+        // both items, the rule -- ONE straight-line epilogue for the two (two logarithms and eight reciprocals in flight
+        // together: with two waves per SIMD a single item's dependent chains leave the vector unit waiting on itself), then
+        // the two items' product 2.  Anything unusual falls back to the item-by-item epilogue with scipy's values for
+        // every argument.  (9 % of the kernel at 131 072 points.)
+        auto careful = [&](int j, const bi_double4& mu, double (&f)[4]) {
             bool done = false;
             if (uniform) {
                 const bool ok = mu[0] > kProdFloor && mu[1] > kProdFloor && mu[2] > kProdFloor && mu[3] > kProdFloor;
@@ -158,13 +154,56 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
                     }
                 }
             }
-            // f = n / mu feeds product 2 straight from these registers: A[m = point = col][k = kq <-> bin 4 r + kq]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = n4[r] != 0.0 ? n4[r] / mu[r] : 0.0;
+        };
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+            bi_double4 mu0 = bi_double4{0.0, 0.0, 0.0, 0.0}, mu1 = bi_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                mu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp][kg], mu0, 0, 0, 0);
+                mu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp + 1][kg], mu1, 0, 0, 0);
+            }
+            // sum_b n log mu over the lane's four bins of its point, and f = n / mu for product 2
+            bool neg0 = false, neg1 = false, ok = uniform;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double f = n4[r] != 0.0 ? n4[r] / mu[r] : 0.0;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) g[j][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b2[r][nb], g[j][nb], 0, 0, 0);
+                neg0 |= !(mu0[r] >= 0.0);
+                neg1 |= !(mu1[r] >= 0.0);
+                ok &= mu0[r] > kProdFloor && mu1[r] > kProdFloor;
             }
+            bad[jp] |= neg0;
+            bad[jp + 1] |= neg1;
+            const double q0 = (mu0[0] * mu0[1]) * (mu0[2] * mu0[3]), q1 = (mu1[0] * mu1[1]) * (mu1[2] * mu1[3]);
+            double f0[4], f1[4];
+            if (__builtin_amdgcn_ballot_w64(ok && pos_normal(q0) && pos_normal(q1)) == ~0ull) {
+                // (one positive count, every mu a normal number above 2^-127: n / mu as n times a reciprocal refined by two
+                //  Newton steps -- relative error < 2^-50, the slopes are held to 1e-8 --, 7 instructions instead of 15)
+                ll[jp] += n_first * bin_log_fast(q0);
+                ll[jp + 1] += n_first * bin_log_fast(q1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double r0 = __builtin_amdgcn_rcp(mu0[r]), r1 = __builtin_amdgcn_rcp(mu1[r]);
+                    r0 = __builtin_fma(__builtin_fma(-mu0[r], r0, 1.0), r0, r0);
+                    r1 = __builtin_fma(__builtin_fma(-mu1[r], r1, 1.0), r1, r1);
+                    r0 = __builtin_fma(__builtin_fma(-mu0[r], r0, 1.0), r0, r0);
+                    r1 = __builtin_fma(__builtin_fma(-mu1[r], r1, 1.0), r1, r1);
+                    f0[r] = n_first * r0;
+                    f1[r] = n_first * r1;
+                }
+            } else {
+                careful(jp, mu0, f0);
+                careful(jp + 1, mu1, f1);
+            }
+            // f feeds product 2 straight from these registers: A[m = point = col][k = kq <-> bin 4 r + kq]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    g[jp][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[r], b2[r][nb], g[jp][nb], 0, 0, 0);
+                    g[jp + 1][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[r], b2[r][nb], g[jp + 1][nb], 0, 0, 0);
+                }
         }
     }
 
@@ -306,11 +345,14 @@ int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
         bi_plan::Class& k = plan->classes[0];
         const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
         const int NSP = kg >= 4 ? 4 * kg : 16;
-        // slices: enough waves for two per SIMD over the whole chip; a wave wants at least ~8 blocks of 16 bins
+        // slices: EIGHT times the waves that are resident at once (two per SIMD over the whole chip) -- cells hold different
+        // numbers of points, and with one round of waves the longest quad of the fullest cell set the time (131 072 points of
+        // C2: 6.8 ms with 1 slice, 4.9 with 2, 4.2 with 4, 4.05 with 8, 4.3 with 32: tools/profile/grad_slices.py); a wave
+        // wants at least ~8 blocks of 16 bins
         const int64_t quads_max = (plan->max_group_items + 3) / 4;
         const int64_t quads_all = std::max<int64_t>(1, (k.n_items + 3) / 4);
         const int64_t n_blocks = (int64_t)plan->max_item_tiles * (kTile / 16);
-        const int64_t want = 2 * 4 * (int64_t)c->prop.multiProcessorCount;
+        const int64_t want = 8 * 2 * 4 * (int64_t)c->prop.multiProcessorCount;
         int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>({(want + quads_all - 1) / quads_all, n_blocks / 8 > 0 ? n_blocks / 8 : 1, 64}));
         if (c->grad_slices > 0) n_slices = (int)std::min<int64_t>(c->grad_slices, std::max<int64_t>(1, n_blocks));
         const size_t ni = (size_t)k.n_items;
