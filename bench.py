@@ -400,19 +400,20 @@ def toy_leg(ctx, ranks, model, T, steps):
     ctx.profile(False)
     kernel_ms = ranks.max_over_ranks(kernel_ms)
     ctx.set_param('toy_offset', 0)
-    # algorithmic bytes of a call on this rank: the 2^d*S template rows once (log mu of every bin) + 4 bytes per list entry
-    # (the bin's byte offset within its tile and 15 bits of count) of every dataset; the entries are gathered against a tile of
-    # log mu held in LDS (runs are padded to 16-byte groups: at most 3 more entries per dataset and tile, not counted here)
+    # algorithmic bytes of a call on this rank: the 2^d*S template rows once (log mu of every bin) + one list entry (2 bytes: the
+    # bin's byte offset within its tile and a count of at most 7 -- what these toys hold; 4 bytes otherwise) per non-empty bin of
+    # every dataset; the entries are gathered against a tile of log mu held in LDS (runs are padded to 16-byte groups, not
+    # counted here)
     NS = 2 ** model.d * model.S
-    nbytes = 8.0 * NS * model.B + 4.0 * nnz
+    entry_bytes = int(ctx.get_param('tm_entry_bytes'))
+    nbytes = 8.0 * NS * model.B + float(entry_bytes) * nnz
     step_ms = elapsed / steps * 1e3
-    roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, bytes_per_call=nbytes, launches_per_call=int(n_launch),
+    roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, bytes_per_call=nbytes, list_entry_bytes=entry_bytes, launches_per_call=int(n_launch),
                 kernel_ms_per_call=kernel_ms, achieved=nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None,
                 achieved_over_whole_step=nbytes / (step_ms * 1e-3) / 1e9, traffic=None,
                 note='algorithmic bytes per call / summed kernel time of the call (HIP events): the log-mu pass streams the '
-                     '2^d*S rows at HBM rate, the dataset pass reads 4-byte list entries against log mu tiles in LDS and is '
-                     'bound by that gather, not by HBM -- the fraction of the HBM peak is small by construction; what the '
-                     'call is measured by is evaluations per second')
+                     '2^d*S rows at HBM rate, the dataset pass streams the list entries (%d bytes each) against log mu tiles in '
+                     'LDS; what the call is measured by is evaluations per second' % entry_bytes)
     roof['frac'] = roof['achieved'] / HBM_PEAK_GBS if roof['achieved'] else None
     return dict(workload='C3: 10^4 toy datasets (drawn on the device), one parameter point per call, datasets split '
                          'by range over the ranks', scaling='strong', datasets=T, steps=steps, value=T * steps / elapsed,

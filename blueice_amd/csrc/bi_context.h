@@ -121,8 +121,10 @@ struct bi_ctx {
     bool toy_blocks_done_zeroed = false;
     unsigned long long toy_seq = 0;
     int64_t n_toy_polled = 0;                 // calls that returned on the completion word
+    int64_t dot_entry16 = 1;                  // parameter: two-byte entries in the tile-major lists where every count is <= 7
+    int tm_width = 4;                         // bytes per entry of the lists as built (2 or 4)
     int64_t dot_blocks_per_cu = 0;            // parameter: blocks of the tiled kernel per CU the dataset split aims at (0 = as many as are resident)
-    int64_t dot_lanes = 8;                    // parameter: lanes per (dataset, tile) run of the tiled kernel: 8 (96 entry slots) or 16 (128)
+    int64_t dot_lanes = 0;                    // parameter: lanes per (dataset, tile) run of the tiled kernel: 0 = by entry width (8 with four-byte entries, 4 with two-byte ones), or 4 / 8 / 16
     int64_t toy_events = 1;                   // parameter: toys of sparse expectations are drawn event by event (0 = always one draw per bin)
     int64_t last_toy_method = 0;              // read-only: 1 = the last bi_generate_toys drew event by event, 0 = bin by bin
     std::vector<int64_t> h_nz_off;            // [T+1]

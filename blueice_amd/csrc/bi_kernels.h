@@ -1331,20 +1331,27 @@ __device__ __forceinline__ double row16_sum(double v) {
 // the row kernel.  Every (dataset, tile) run is padded to a multiple of FOUR entries with kTmPadEntry -- count 0, and the
 // offset of an extra LDS slot behind the tile that holds 0.0, never log mu = -inf -- so that a lane's 16-byte load is
 // wholly inside its run or wholly outside it (one test per load, not per entry) and every load is 16-byte aligned.
+// Round 4, measured: with the entry loads taken out the kernel runs in 24 us instead of 86 -- the ENTRY STREAM is its time
+// (376 MB at C2: 54 us of HBM at best), neither the LDS gathers nor the arithmetic.  So where every count is at most 7 -- toys
+// of sparse expectations: all of them -- an entry is TWO bytes: bin * 8 (the LDS byte offset, bits 3..15) | count (bits
+// 0..2), eight entries per 16-byte load, runs padded to multiples of eight with 0 (count 0: the term is dropped by a select,
+// there is no room for the offset of the extra slot).  Data with a larger count anywhere keeps the 4-byte entries.
 constexpr uint32_t kTmPadEntry = (uint32_t)kDotTile << 3;
-__global__ void k_tm_counts(const int32_t* __restrict__ tile_off, int64_t T, int n_tl, int64_t* __restrict__ cnt /*[n_tl * T + 1]*/) {
+__global__ void k_tm_counts(const int32_t* __restrict__ tile_off, int64_t T, int n_tl, int64_t* __restrict__ cnt /*[n_tl * T + 1]*/,
+                            int group /* entries per 16-byte load: 4 or 8 */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > (int64_t)n_tl * T) return;
     if (i == (int64_t)n_tl * T) { cnt[i] = 0; return; }
     const int64_t tl = i / T, t = i % T;
     const int32_t* __restrict__ o = tile_off + t * (n_tl + 1) + tl;
-    cnt[i] = (o[1] - o[0] + 3) & ~3;                // (the run's padded length: the list is pre-filled with kTmPadEntry)
+    cnt[i] = (o[1] - o[0] + group - 1) & ~(group - 1);     // (the run's padded length: the list is pre-filled with padding entries)
 }
 
+template <typename ENTRY>
 __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restrict__ nz_idx, const double* __restrict__ nz_n,
                                                          const int64_t* __restrict__ nz_off, const int32_t* __restrict__ tile_off,
                                                          int64_t T, int n_tl, const int64_t* __restrict__ tm_off,
-                                                         uint32_t* __restrict__ tm_entries, int* __restrict__ bad) {
+                                                         ENTRY* __restrict__ tm_entries, int* __restrict__ bad) {
     const int64_t t = blockIdx.x;
     const int64_t lo = nz_off[t], hi = nz_off[t + 1];
     const int32_t* __restrict__ o = tile_off + t * (n_tl + 1);
@@ -1353,8 +1360,13 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
         const int idx = nz_idx[j];
         const double n = nz_n[j];
         const int tl = idx / kDotTile;
-        if (!(n >= 1.0 && n < 32768.0 && n == floor(n))) any_bad = true;
-        tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = ((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n << 17);
+        if constexpr (sizeof(ENTRY) == 2) {
+            if (!(n >= 1.0 && n <= 7.0 && n == floor(n))) any_bad = true;
+            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = (ENTRY)(((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n & 7u));
+        } else {
+            if (!(n >= 1.0 && n < 32768.0 && n == floor(n))) any_bad = true;
+            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = ((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n << 17);
+        }
     }
     if (any_bad) atomicOr(bad, 1);
 }
@@ -1396,9 +1408,12 @@ __device__ __forceinline__ double row_group_sum(double v) {
         BI_DPP_ADD(0x120 + 4);
         BI_DPP_ADD(0x120 + 2);
         BI_DPP_ADD(0x120 + 1);
-    } else {
-        static_assert(L == 8, "groups of 8 or 16 lanes");
+    } else if constexpr (L == 8) {
         BI_DPP_ADD(0x141);            // row_half_mirror
+        BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
+        BI_DPP_ADD(0x4E);             // quad_perm:[2,3,0,1]
+    } else {
+        static_assert(L == 4, "groups of 4, 8 or 16 lanes");
         BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
         BI_DPP_ADD(0x4E);             // quad_perm:[2,3,0,1]
     }
@@ -1409,12 +1424,16 @@ __device__ __forceinline__ double row_group_sum(double v) {
 // L lanes per (dataset, tile) run, AHEAD 16-byte loads per lane requested up front: 4 L AHEAD entry slots per run.
 // <16, 2>: 128 slots, 64 runs in flight per block (round 3).  <8, 3>: 96 slots -- a run at C2 is ~76 entries, so 79 % of the
 // slots carry an entry instead of 59 % --, 128 runs in flight per block, three rotate-and-add steps instead of four (round 4).
-template <int L, int AHEAD>
-__global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_t* __restrict__ tm_entries,
+// W: bytes per entry (4, or 2: counts up to 7) -- 16 / W entries per 16-byte load, (16 / W) L AHEAD slots per run.
+template <int L, int AHEAD, int W = 4>
+__global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const void* __restrict__ tm_entries_v,
                                                                    const int64_t* __restrict__ tm_off, int64_t T, int n_tl,
                                                                    const double* __restrict__ logmu, int64_t B, int64_t t0,
                                                                    int64_t n, double* __restrict__ partial /*[n_tl][n]*/) {
-    static_assert(4 * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
+    typedef typename std::conditional<W == 2, uint16_t, uint32_t>::type entry_t;
+    constexpr int EPL = 16 / W;                                        // entries per lane and load
+    static_assert(EPL * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
+    const entry_t* __restrict__ tm_entries = static_cast<const entry_t*>(tm_entries_v);
     __shared__ double s_mu[kDotTile + 1];                              // (+ the slot of the padding entries: 0.0)
     const int tl = blockIdx.x;
     const int64_t bin0 = (int64_t)tl * kDotTile;
@@ -1424,7 +1443,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
     const int c0 = min(c0u, (int)n - 1);                               // (clamped: a block without datasets still loads validly)
     const int64_t* __restrict__ off = tm_off + (int64_t)tl * T + t0;
     const int64_t base = off[c0];                                  // block-uniform: the entries of this block start here
-    const uint32_t* __restrict__ ent = tm_entries + base;
+    const entry_t* __restrict__ ent = tm_entries + base;
     const uint32_t* __restrict__ off32 = reinterpret_cast<const uint32_t*>(off);   // low words: all a block-relative index needs
     const uint32_t base32 = (uint32_t)base;
     constexpr int kStep = kDotThreads / L, kAhead = AHEAD, kDepth = BI_DOT_DEPTH, kRing = 2 * (kDepth + 1);   // entries kDepth runs ahead, offsets 2 kDepth; the ring a multiple of the entry buffers
@@ -1437,11 +1456,11 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
         ra = off32[2 * qc];
         rb = off32[2 * qc + 2];
     };
-    // (a lane takes four consecutive entries per load: a group's load covers 16 L contiguous bytes of its run)
+    // (a lane takes EPL consecutive entries per load: a group's load covers 16 L contiguous bytes of its run)
     auto load_entries = [&](uint32_t ra, bi_uint4 (&e)[kAhead]) {
-        const uint32_t* __restrict__ p = ent + (int)(ra - base32) + 4 * gl;
+        const entry_t* __restrict__ p = ent + (int)(ra - base32) + EPL * gl;
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + 4 * L * k, 16);     // (4-byte aligned 16-byte load)
+        for (int k = 0; k < kAhead; ++k) __builtin_memcpy(&e[k], p + EPL * L * k, 16);   // (16-byte load, 16-byte aligned: runs are whole groups)
     };
     bi_uint4 E[kDepth + 1][kAhead];
     uint32_t RA[kRing], RB[kRing];
@@ -1473,23 +1492,55 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_tiled(const uint32_
                 __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this step's arithmetic, not after it
                 const bi_uint4 (&e)[kAhead] = E[u % (kDepth + 1)];
                 const int a = (int)(RA[u % kRing] - base32), b = (int)(RB[u % kRing] - base32);
-                const int len = b - a - 4 * gl;                  // (padded) entries of the run from this lane's first on
-                double s = 0.0, lm[4 * kAhead];
+                const int len = b - a - EPL * gl;                // (padded) entries of the run from this lane's first on
+                double s = 0.0;
+                if constexpr (W == 4) {
+                    double lm[4 * kAhead];
 #define BI_TM_LOG(x) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_mu) + ((x) & 0x1FFF8u)))
 #pragma unroll
-                for (int k = 0; k < 4 * kAhead; ++k) lm[k] = BI_TM_LOG(e[k >> 2][k & 3]);      // LDS reads in flight together
+                    for (int k = 0; k < 4 * kAhead; ++k) lm[k] = BI_TM_LOG(e[k >> 2][k & 3]);      // LDS reads in flight together
 #pragma unroll
-                for (int g = 0; g < kAhead; ++g) {
-                    double sg = (double)(e[g][0] >> 17) * lm[4 * g];
+                    for (int g = 0; g < kAhead; ++g) {
+                        double sg = (double)(e[g][0] >> 17) * lm[4 * g];
 #pragma unroll
-                    for (int k = 1; k < 4; ++k) sg = __builtin_fma((double)(e[g][k] >> 17), lm[4 * g + k], sg);
-                    s += 4 * L * g < len ? sg : 0.0;             // (a load behind the run's end read other runs' entries: dropped whole)
-                }
-                for (int j = a + gl + 4 * L * kAhead; j < b; j += L) {                      // (runs beyond 4 L AHEAD entries)
-                    const uint32_t x = ent[j];
-                    s = __builtin_fma((double)(x >> 17), BI_TM_LOG(x), s);
-                }
+                        for (int k = 1; k < 4; ++k) sg = __builtin_fma((double)(e[g][k] >> 17), lm[4 * g + k], sg);
+                        s += 4 * L * g < len ? sg : 0.0;         // (a load behind the run's end read other runs' entries: dropped whole)
+                    }
+                    for (int j = a + gl + 4 * L * kAhead; j < b; j += L) {                  // (runs beyond 4 L AHEAD entries)
+                        const uint32_t x = ent[j];
+                        s = __builtin_fma((double)(x >> 17), BI_TM_LOG(x), s);
+                    }
 #undef BI_TM_LOG
+                } else {
+                    // two entries per word: LDS byte offset = entry & 0xFFF8, count = entry & 7 (0 = padding: its term is dropped,
+                    // whatever log mu of bin 0 is)
+                    double lm[8 * kAhead];
+#define BI_TM_LOG16(x) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_mu) + ((x) & 0xFFF8u)))
+#pragma unroll
+                    for (int k = 0; k < 4 * kAhead; ++k) {
+                        const uint32_t x = e[k >> 2][k & 3];
+                        lm[2 * k] = BI_TM_LOG16(x);
+                        lm[2 * k + 1] = BI_TM_LOG16(x >> 16);
+                    }
+#pragma unroll
+                    for (int g = 0; g < kAhead; ++g) {
+                        double sg = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t x = e[g][k];
+                            const uint32_t n0 = x & 7u, n1 = (x >> 16) & 7u;
+                            sg = __builtin_fma((double)n0, n0 ? lm[8 * g + 2 * k] : 0.0, sg);
+                            sg = __builtin_fma((double)n1, n1 ? lm[8 * g + 2 * k + 1] : 0.0, sg);
+                        }
+                        s += 8 * L * g < len ? sg : 0.0;         // (a load behind the run's end read other runs' entries: dropped whole)
+                    }
+                    for (int j = a + gl + 8 * L * kAhead; j < b; j += L) {                  // (runs beyond 8 L AHEAD entries)
+                        const uint32_t x = ent[j];
+                        const uint32_t n0 = x & 7u;
+                        s = __builtin_fma((double)n0, n0 ? BI_TM_LOG16(x) : 0.0, s);
+                    }
+#undef BI_TM_LOG16
+                }
                 s = row_group_sum<L>(s);
                 if (gl == 0 && q < c1) partial[(int64_t)tl * n + q] = s;
             }

@@ -66,8 +66,9 @@ const ParamDef kParams[] = {
     {"dot_tiled", kParamRW, BI_P_GET(c->dot_tiled), BI_P_FLAG(dot_tiled)},
     {"score_sorted", kParamRW, BI_P_GET(c->score_sorted), BI_P_FLAG(score_sorted)},
     {"toy_fast_call", kParamRW, BI_P_GET(c->toy_fast_call), BI_P_RANGE(0, 7, toy_fast_call, "toy_fast_call: bits 1 | 2 | 4")},
+    {"dot_entry16", kParamRW, BI_P_GET(c->dot_entry16), [](bi_ctx* c, int64_t v) -> int { c->dot_entry16 = v ? 1 : 0; c->nz_tile_epoch = -1; return BI_OK; }},
     {"dot_blocks_per_cu", kParamRW, BI_P_GET(c->dot_blocks_per_cu), BI_P_RANGE(0, 16, dot_blocks_per_cu, "dot_blocks_per_cu in [0, 16]")},
-    {"dot_lanes", kParamRW, BI_P_GET(c->dot_lanes), BI_P_SET(c->dot_lanes = v == 16 ? 16 : 8)},
+    {"dot_lanes", kParamRW, BI_P_GET(c->dot_lanes), BI_P_SET(c->dot_lanes = (v == 16 || v == 8 || v == 4) ? v : 0)},
     {"compact_budget", kParamRW, BI_P_GET(c->compact_budget), BI_P_SET(c->compact_budget = v)},
     {"toy_offset", kParamRW, BI_P_GET(c->toy_offset), BI_P_RANGE(0, INT64_MAX, toy_offset, "toy_offset >= 0")},
     {"mail_timeout_ms", kParamRW, BI_P_GET(c->mail_timeout_ms),
@@ -86,6 +87,7 @@ const ParamDef kParams[] = {
     BI_P_RO("padded_bins", c->Bp),
     BI_P_RO("n_scan_launches", c->n_scan_launches),
     BI_P_RO("n_toy_polled", c->n_toy_polled),
+    BI_P_RO("tm_entry_bytes", c->tm_width),
     BI_P_RO("events_sorted", c->ev_sorted ? 1 : 0),
     BI_P_RO("n_grad_mfma_launches", c->n_grad_mfma_launches),
     BI_P_RO("n_valid_launches", c->n_valid_launches),

@@ -1111,32 +1111,48 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
                                       rocprim::plus<int64_t>(), c->stream);
         if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
             (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
-            (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t))) ||
-            // (every run padded to whole 16-byte groups: at most 3 entries each; + pad: the kernel's unconditional read-ahead)
-            (rc = dev_alloc(c, c->tm_entries, (size_t)(nnz + 3 * cells + kDotPad) * sizeof(uint32_t)))) {
+            (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t)))) {
             drop();
             return rc;
         }
-        hipError_t e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
-        if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)c->tm_entries.p, (int)kTmPadEntry, (size_t)(nnz + 3 * cells + kDotPad), c->stream);
         hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
                            (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p);
-        hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
-                           n_tl, (int64_t*)d_cnt.p);
-        size_t tb = d_tmp.bytes;
-        if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1),
-                                                         rocprim::plus<int64_t>(), c->stream);
-        hipLaunchKernelGGL(k_tm_scatter, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
-                           (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
-                           (const int64_t*)c->tm_off.p, (uint32_t*)c->tm_entries.p, (int*)d_bad.p);
-        int bad = 0;
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        else (void)hipStreamSynchronize(c->stream);
+        hipError_t e = hipGetLastError();
+        // two-byte entries where every count is at most 7 (toys of sparse expectations), four-byte entries otherwise: the first
+        // format is tried, and a count that does not fit sends the build to the second
+        c->tm_ok = false;
+        for (int width = c->dot_entry16 ? 2 : 4; e == hipSuccess && !c->tm_ok; width = 4) {
+            const int group = 16 / width;
+            const size_t n_entries = (size_t)(nnz + (group - 1) * cells + kDotPad);     // (every run padded to whole 16-byte groups; + the kernel's read-ahead)
+            if ((rc = dev_alloc(c, c->tm_entries, n_entries * width))) { drop(); return rc; }
+            e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
+            if (e == hipSuccess && width == 2) e = hipMemsetAsync(c->tm_entries.p, 0, n_entries * 2, c->stream);
+            if (e == hipSuccess && width == 4) e = hipMemsetD32Async((hipDeviceptr_t)c->tm_entries.p, (int)kTmPadEntry, n_entries, c->stream);
+            hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
+                               n_tl, (int64_t*)d_cnt.p, group);
+            size_t tb = d_tmp.bytes;
+            if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1),
+                                                             rocprim::plus<int64_t>(), c->stream);
+            if (width == 2)
+                hipLaunchKernelGGL((k_tm_scatter<uint16_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                                   (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
+                                   (const int64_t*)c->tm_off.p, (uint16_t*)c->tm_entries.p, (int*)d_bad.p);
+            else
+                hipLaunchKernelGGL((k_tm_scatter<uint32_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                                   (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
+                                   (const int64_t*)c->tm_off.p, (uint32_t*)c->tm_entries.p, (int*)d_bad.p);
+            int bad = 0;
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) break;
+            c->tm_ok = bad == 0;
+            c->tm_width = width;
+            if (width == 4) break;
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);
         drop();
         if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets (tile-major lists): %s", hipGetErrorString(e));
-        c->tm_ok = bad == 0;
         if (!c->tm_ok) { dev_free(c->tm_entries); dev_free(c->tm_off); }
         c->nz_tile_epoch = c->epoch;
     }
@@ -1200,23 +1216,28 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
                 // (and few enough datasets per block for its 32-bit entry indices: datasets x kDotTile < 2^31)
                 // as many blocks as are resident at once (the 8-lane variant's registers allow one per CU, the 16-lane
                 // variant's two; asked from the runtime once): ONE round, every block's start-up paid once
-                static std::atomic<int> resident_cache[2];
-                std::atomic<int>& rslot = resident_cache[c->dot_lanes == 8 ? 0 : 1];
+                // variant: 4-byte entries <8, 3> (96 slots per run) or <16, 2>; 2-byte entries <8, 2, 2> (128 slots) or, dot_lanes 4,
+                // <4, 3, 2> (96 slots)
+                // (dot_lanes 0 = the best measured for the entry width: 8 lanes with four-byte entries, 4 with two-byte ones)
+                const int variant = c->tm_width == 2 ? ((c->dot_lanes == 4 || c->dot_lanes == 0) ? 3 : 2) : (c->dot_lanes == 16 ? 1 : 0);
+                static std::atomic<int> resident_cache[4];
+                std::atomic<int>& rslot = resident_cache[variant];
                 int resident = c->dot_blocks_per_cu > 0 ? (int)c->dot_blocks_per_cu : rslot.load();
                 if (resident <= 0) {
                     int r = 0;
-                    const void* f = c->dot_lanes == 8 ? (const void*)k_dataset_dot_tiled<8, 3> : (const void*)k_dataset_dot_tiled<16, 2>;
+                    const void* f = variant == 0 ? (const void*)k_dataset_dot_tiled<8, 3, 4> : variant == 1 ? (const void*)k_dataset_dot_tiled<16, 2, 4>
+                                  : variant == 2 ? (const void*)k_dataset_dot_tiled<8, 2, 2> : (const void*)k_dataset_dot_tiled<4, 3, 2>;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, f, kDotThreads, 0) != hipSuccess || r < 1) r = 1;
                     rslot.store(r);
                     resident = r;
                 }
                 const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((ni + 255) / 256, (int64_t)resident * c->prop.multiProcessorCount / n_tl),
                                                                  (ni + 262143) / 262144});
-#define BI_DOT(L, AHEAD)                                                                                           \
-    hipLaunchKernelGGL((k_dataset_dot_tiled<L, AHEAD>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream, \
-                       (const uint32_t*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,                  \
+#define BI_DOT(L, AHEAD, W)                                                                                        \
+    hipLaunchKernelGGL((k_dataset_dot_tiled<L, AHEAD, W>), dim3((unsigned)n_tl, by), dim3(kDotThreads), 0, c->stream, \
+                       (const void*)c->tm_entries.p, (const int64_t*)c->tm_off.p, c->T, n_tl,                      \
                        (const double*)c->logmu.p, c->B, t0 + s0, ni, (double*)c->scratch2.p)
-                if (c->dot_lanes == 8) BI_DOT(8, 3); else BI_DOT(16, 2);
+                if (variant == 0) BI_DOT(8, 3, 4); else if (variant == 1) BI_DOT(16, 2, 4); else if (variant == 2) BI_DOT(8, 2, 2); else BI_DOT(4, 3, 2);
 #undef BI_DOT
             } else if (csr)
                 hipLaunchKernelGGL(k_dataset_dot_csr, dim3((unsigned)ni), dim3(kThreads), 0, c->stream,

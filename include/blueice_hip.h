@@ -378,8 +378,13 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     default); 0 = always one Poisson draw per bin.  Read-only `last_toy_method`: 1 / 0 for the last call.
  *   dot_tiled         bi_eval_datasets over non-empty-bin lists: batches of >= 64 datasets take the kernel that stages bin tiles
  *                     of log mu in LDS over tile-major lists (1, default); 0 = always one block per dataset
- *   dot_lanes         ... lanes per (dataset, tile) run of that kernel: 8 (96 entry slots per run, 128 runs in flight per block;
- *                     default) or 16 (128 slots, 64 runs in flight: round 3)
+ *   dot_lanes         ... lanes per (dataset, tile) run of that kernel: 0 = the best measured for the lists' entry width (default: 8
+ *                     lanes x three 16-byte loads = 96 entry slots with four-byte entries, 4 lanes x three loads = 96 slots with
+ *                     two-byte ones), or 4 / 8 / 16 (16: 128 slots, round 3's shape)
+ *   dot_entry16       ... the tile-major lists hold TWO-byte entries (bin within the tile, count) where every count of every dataset is
+ *                     at most 7 -- the kernel is bound by reading the lists --, four-byte entries otherwise (1, default; 0 = always
+ *                     four bytes; read-only `tm_entry_bytes`: the width of the lists as built).  With two-byte entries dot_lanes
+ *                     8 and 16 mean 128 entry slots per run (8 lanes, two loads each), 4 means 96 (three loads per lane)
  *   dot_blocks_per_cu ... blocks of that kernel per CU its split of the datasets aims at: 0 = as many as are resident at once (one
  *                     round of blocks; default), n = n per CU
  *   score_sorted      bi_score_events / bi_simulate_events (set on the TARGET context): from 4096 events on, the events are ordered
@@ -414,7 +419,7 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     fails does the same before it gives up
  *   debug_skip_post, debug_late_post   (write; fault injection for tests) block k of the NEXT launch that finishes through the
  *                     mailbox never posts its partial sum / posts it after the collector has given up; consumed by that launch
- * read-only: tile_bins, padded_bins, n_scan_launches, n_toy_polled (bi_eval_datasets calls that returned on the completion word), events_sorted, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
+ * read-only: tile_bins, padded_bins, n_scan_launches, n_toy_polled (bi_eval_datasets calls that returned on the completion word), tm_entry_bytes, events_sorted, n_valid_launches, n_sorted_scans, n_bb_exact, n_mail_resets, user_allocations, csr_ready, compact_ready, compact_sorted (the compacted copy is ordered by count), split_ready, ps_nonneg, nnz_total;
  *            last_scan_nslots / last_valid_nslots / last_scan_resident (waves per cell the planner chose for the scan kernels of
  *            the last plan, and the resident blocks per CU it sized them by), last_toy_method (1 = event by event);
  *   single_calls, single_ns_host, single_ns_launch, single_ns_wait   wall time (ns, summed over single_calls calls) of

@@ -176,10 +176,10 @@ def test_tiled_dataset_kernel_random_shapes(seed):
         rows, _ = ctx.eval_datasets(None, [1.3])
         ctx.set_param('dot_tiled', 1)
         np.testing.assert_allclose(tiled, rows, rtol=1e-13, atol=0)
-        assert ctx.get_param('dot_lanes') == 8                        # (the default: 8 lanes per run, 96 entry slots)
+        assert ctx.get_param('dot_lanes') == 0                        # (the default: by entry width -- here 8 lanes per run, 96 entry slots)
         ctx.set_param('dot_lanes', 16)                                # round 3's shape: 16 lanes, 128 slots
         wide, _ = ctx.eval_datasets(None, [1.3])
-        ctx.set_param('dot_lanes', 8)
+        ctx.set_param('dot_lanes', 0)
         np.testing.assert_allclose(wide, rows, rtol=1e-13, atol=0)
         # round 4's short call: descriptors in the kernel arguments (bit 1), the finish with 64 datasets per block (2), the
         # completion word polled instead of a stream synchronise (4) -- the same numbers whichever way the call travels;
@@ -209,6 +209,31 @@ def test_tiled_dataset_kernel_random_shapes(seed):
         np.testing.assert_array_equal(part, tiled[lo:hi + 64])
         want = np.array([np.sum(stats.poisson(1.3 * mu).logpmf(counts[t])) for t in (0, one_tile, T - 1)])
         np.testing.assert_allclose(tiled[[0, one_tile, T - 1]], want, rtol=1e-10)
+        assert ctx.get_param('tm_entry_bytes') == 4                   # (counts up to 39: four-byte entries)
+        # counts of at most 7 everywhere (what toys of sparse expectations look like): two-byte entries, eight per load --
+        # against the row kernel, against four-byte entries of the same data, and with 4 lanes per run instead of 8
+        small = np.minimum(counts, rng.integers(1, 8, size=counts.shape))
+        ctx.upload_counts(small)
+        two, st2 = ctx.eval_datasets(None, [1.3])
+        assert st2 == 0 and ctx.get_param('tm_entry_bytes') == 2
+        ctx.set_param('dot_tiled', 0)
+        rows2, _ = ctx.eval_datasets(None, [1.3])
+        ctx.set_param('dot_tiled', 1)
+        np.testing.assert_allclose(two, rows2, rtol=1e-13, atol=0)
+        ctx.set_param('dot_lanes', 8)                                 # (the default for two-byte entries is 4 lanes per run)
+        eight, _ = ctx.eval_datasets(None, [1.3])
+        ctx.set_param('dot_lanes', 0)
+        np.testing.assert_allclose(eight, rows2, rtol=1e-13, atol=0)
+        ctx.set_param('dot_entry16', 0)
+        four, _ = ctx.eval_datasets(None, [1.3])
+        assert ctx.get_param('tm_entry_bytes') == 4
+        ctx.set_param('dot_entry16', 1)
+        np.testing.assert_allclose(four, rows2, rtol=1e-13, atol=0)
+        part2, _ = ctx.eval_datasets(None, [1.3], int(lo), int(hi) + 64)
+        assert ctx.get_param('tm_entry_bytes') == 2
+        np.testing.assert_array_equal(part2, two[lo:hi + 64])
+        want2 = np.array([np.sum(stats.poisson(1.3 * mu).logpmf(small[t])) for t in (0, one_tile, T - 1)])
+        np.testing.assert_allclose(two[[0, one_tile, T - 1]], want2, rtol=1e-10)
     finally:
         ctx.close()
 
