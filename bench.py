@@ -665,12 +665,12 @@ def main():
                              'over the whole step; the per-bin logarithm on the vector ALU shares the fp64 units and does '
                              'not overlap with the MFMAs (DESIGN.md section 4)' % bins)
         elif args.config == 'C3':
-            nbytes = 8.0 * (2 ** model.d * model.S) * model.B + 4.0 * leg['nonempty_bins_this_rank']
+            nbytes = leg['roofline']['bytes_per_call']       # (the leg's own accounting: rows once + one list entry per non-empty bin)
             gbs = nbytes / step_s / 1e9
             roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, achieved=gbs, frac=gbs / HBM_PEAK_GBS, traffic=None,
-                        note='algorithmic bytes of a call: the 2^d*S template rows once (log mu) + 4 bytes per non-empty bin '
-                             'of every dataset; the call is short (0.3 ms, three launches) and its gather runs out of LDS, '
-                             'so the fraction of the HBM peak is small by construction')
+                        list_entry_bytes=leg['roofline'].get('list_entry_bytes'),
+                        note='algorithmic bytes of a call over the whole step: the 2^d*S template rows once (log mu) + one list entry '
+                             '(list_entry_bytes) per non-empty bin of every dataset; three launches')
         else:
             gbs = leg['streamed_bytes_this_rank'] / step_s / 1e9
             roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, achieved=gbs, frac=gbs / HBM_PEAK_GBS, traffic=None,

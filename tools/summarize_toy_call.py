@@ -40,7 +40,9 @@ def main(rnd):
     c = counters('pmc1')
     c.update(counters('pmc2'))
     line = json.loads(open(os.path.join(SRC, 'plain.json')).read().strip().splitlines()[-1])
-    entries = line.get('config', {}).get('nonempty_bins_total') or line.get('nonempty_bins_this_rank') or 94226163
+    leg = line.get('leg', {})
+    entries = leg.get('nonempty_bins_this_rank') or 94226163
+    entry_bytes = (leg.get('roofline') or {}).get('list_entry_bytes') or 4
     derived = {}
     if c:
         cyc = c['GRBM_GUI_ACTIVE'] / 8.0                       # (the counter adds the 8 XCDs up)
@@ -52,7 +54,8 @@ def main(rnd):
             'lds_busy_fraction_of_CU_cycles': c['SQ_LDS_IDX_ACTIVE'] / (cyc * 256) if 'SQ_LDS_IDX_ACTIVE' in c else None,
             'lds_bank_conflict_share_of_lds_busy': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'] if 'SQ_LDS_IDX_ACTIVE' in c else None,
             'wave_time_waiting_on_counters': c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES'] if 'SQ_WAIT_INST_ANY' in c else None,
-            'entry_stream_TBps': entries * 4 / (dur_us * 1e-6) / 1e12,
+            'list_entry_bytes': entry_bytes,
+            'entry_stream_TBps': entries * entry_bytes / (dur_us * 1e-6) / 1e12,
         }
     out = dict(
         round=rnd,
@@ -62,9 +65,11 @@ def main(rnd):
                   'rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU -- (same)'],
         bench_line_plain=dict(value=line.get('value'), unit=line.get('unit'), ms_per_step=line.get('ms_per_step')),
         kernel_trace=trace, k_dataset_dot_tiled_counters_median_per_launch=c, derived=derived,
-        previous_round='profiles/r03_toy_call.json: log mu 46 us, dot 90 us, finish 15.6 us, call to call 221 us; 19.7 vector instructions per 64 entries',
+        previous_round='profiles/r03_toy_call.json: log mu 46 us, dot 90 us, finish 15.6 us, call to call 221 us; 19.7 vector instructions per 64 entries; '
+                       'earlier in round 4 (four-byte entries): dot 84.7 us, call to call 176 us',
         note='the bank-conflict share of LDS-busy time is a property of the access pattern (64 independent random 8-byte reads per instruction: '
-             'expected worst bank load ~3.5 over 32 bank pairs); no pipe is saturated')
+             'expected worst bank load ~3.5 over 32 bank pairs).  Measured with the entry loads taken out the kernel runs in 24 us: the entry '
+             'stream is its time, which is why the lists went to two-byte entries')
     dst = os.path.join(ROOT, 'profiles', 'r%02d_toy_call.json' % rnd)
     with open(dst, 'w') as f:
         json.dump(out, f, indent=1)
