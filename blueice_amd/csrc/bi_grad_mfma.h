@@ -345,15 +345,16 @@ int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
         bi_plan::Class& k = plan->classes[0];
         const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
         const int NSP = kg >= 4 ? 4 * kg : 16;
-        // slices: EIGHT times the waves that are resident at once (two per SIMD over the whole chip) -- cells hold different
-        // numbers of points, and with one round of waves the longest quad of the fullest cell set the time (131 072 points of
-        // C2: 6.8 ms with 1 slice, 4.9 with 2, 4.2 with 4, 4.05 with 8, 4.3 with 32: tools/profile/grad_slices.py); a wave
-        // wants at least ~8 blocks of 16 bins
+        // slices: SIX times the waves that are resident at once (two per SIMD over the whole chip), at most 16 -- cells hold
+        // different numbers of points, and with one round of waves the longest quad of the fullest cell set the time (131 072
+        // points of C2: kernels 6.8 ms with 1 slice, 4.9 with 2, 4.2 with 4, 4.05 with 8), while every slice adds 4 KB of
+        // partial sums per work item for the finish to read (16 384 points: 1.32 ms per call with 16 slices, 2.0 with 64;
+        // tools/profile/grad_slices.py); a wave wants at least ~8 blocks of 16 bins
         const int64_t quads_max = (plan->max_group_items + 3) / 4;
         const int64_t quads_all = std::max<int64_t>(1, (k.n_items + 3) / 4);
         const int64_t n_blocks = (int64_t)plan->max_item_tiles * (kTile / 16);
-        const int64_t want = 8 * 2 * 4 * (int64_t)c->prop.multiProcessorCount;
-        int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>({(want + quads_all - 1) / quads_all, n_blocks / 8 > 0 ? n_blocks / 8 : 1, 64}));
+        const int64_t want = 6 * 2 * 4 * (int64_t)c->prop.multiProcessorCount;
+        int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>({(want + quads_all - 1) / quads_all, n_blocks / 8 > 0 ? n_blocks / 8 : 1, 16}));
         if (c->grad_slices > 0) n_slices = (int)std::min<int64_t>(c->grad_slices, std::max<int64_t>(1, n_blocks));
         const size_t ni = (size_t)k.n_items;
         if ((rc = dev_alloc(c, d_pll, ni * n_slices * 16 * 8)) || (rc = dev_alloc(c, d_pg, ni * n_slices * NSP * 16 * 8)) ||
