@@ -232,3 +232,36 @@ def test_every_stream_count_from_1_to_32():
     ctx.close()
     # the matrix-core scan ran for every stream count in at least one data form
     assert {ns for ns, _ in seen} == set(range(1, 33)), sorted(set(range(1, 33)) - {ns for ns, _ in seen})
+
+
+@pytest.mark.parametrize('sparse', [0, 1])
+def test_mixed_strips_shared_among_the_waves_of_a_cell(mini, sparse):
+    """Strips whose 64 bins do not carry one count -- two runs meeting, the end of the data next to the padding, odd counts --
+    are worked by all waves of a cell together (scan_share_slow, the default) instead of by the wave that owns the strip:
+    the same likelihoods (the partial sums are added in another order: 1e-12), edge cases included, for dense data and for
+    the compacted non-empty bins, and for few points per cell (fewer work items than waves)."""
+    from oracle import blueice_oracle as orc
+    m, ctx = mini
+    rng = np.random.default_rng(5)
+    counts = m.counts(dense=not sparse).astype(float)
+    if not sparse:
+        counts[rng.integers(0, len(counts), 7)] = [np.nan, -1.0, 2.5, 0.0, 0.0, 33.0, 1e9]      # odd strips in the middle of runs
+    ctx.set_param('sparse', sparse)
+    ctx.upload_counts(counts)
+    dense = m.dense_model()
+    for P in (3000, 1500):
+        z, r = m.random_points(P, seed=40 + P)
+        out = {}
+        for share in (1, 0):
+            ctx.set_param('scan_share_slow', share)
+            before = ctx.get_param('n_scan_launches')
+            out[share], st = ctx.eval(z, r)
+            assert ctx.get_param('n_scan_launches') == before + 1, 'the batch did not take the matrix-core scan kernel'
+        ctx.set_param('scan_share_slow', 1)
+        a, b = out[1], out[0]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b))
+        ok = np.isfinite(a)
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-12)
+        for i in range(0, P, 97):
+            want = orc.loglikelihood(dense, counts, z[i], r[i])
+            assert (np.isnan(want) and np.isnan(a[i])) or a[i] == want or abs(a[i] - want) <= 1e-10 * max(1.0, abs(want)), (P, i, a[i], want)
