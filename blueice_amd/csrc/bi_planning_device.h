@@ -743,18 +743,17 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, G, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);               // d_keys = item index + 1
-        e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
-        const int64_t n_items = h_scal[1];
         // groups of items sharing (cell, dataset): their number decides which kernels take the batch
         hipLaunchKernelGGL(k_plan_group_flags, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);   // d_idx = group id + 1
+        // (the two counts in ONE round trip: every host synchronisation of the planner is ~35 us of a call)
         int64_t n_groups = 0;
-        e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
+        const int64_t n_items = h_scal[1];
         const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
         const bool scan_shape = c->scan_mfma && !bb && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535;
         // Every bin visited, mostly empty data, several items per cell: split the scan into the non-empty-bin pass (the
@@ -805,17 +804,6 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                            split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr, bb ? (double*)k.aux.p : (double*)nullptr,
                            bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr);
         e = hipGetLastError();
-        int64_t h_zero_u = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
-        // Beeston-Barlow points at which some bin can have U_b == 0: the reference's first-root assertion then hangs on the
-        // last bits of N(z), which only the host planner's pass in numpy's summation order reproduces (bb_exact_totals)
-        if (bb && c->bb_exact && h_zero_u > 0) return abort_plan(kPlanNeedsHost);
-        plan->bytes = (int64_t)sizeof(double) * ((int64_t)NS + 1) * (compacted ? h_scal[2] * kTile : n_items * c->B);
-        plan->launches = (n_items + 65534) / 65535;
-
         auto group_tables = [&]() -> int {
             int rc2;
             if ((rc2 = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc2 = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
@@ -827,12 +815,21 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                                grad_mode ? (unsigned long long*)(scal + 3) : (unsigned long long*)nullptr);
             return BI_OK;
         };
+        // (gradient batches: the group tables go out before the read-back, so that their largest group travels with it)
+        if (e == hipSuccess && grad_mode && (rc = group_tables())) return abort_plan(rc);
+        int64_t h_zero_u = 0, h_max = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && grad_mode) e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
+        // Beeston-Barlow points at which some bin can have U_b == 0: the reference's first-root assertion then hangs on the
+        // last bits of N(z), which only the host planner's pass in numpy's summation order reproduces (bb_exact_totals)
+        if (bb && c->bb_exact && h_zero_u > 0) return abort_plan(kPlanNeedsHost);
+        plan->bytes = (int64_t)sizeof(double) * ((int64_t)NS + 1) * (compacted ? h_scal[2] * kTile : n_items * c->B);
+        plan->launches = (n_items + 65534) / 65535;
+
         if (grad_mode) {
-            if ((rc = group_tables())) return abort_plan(rc);
-            int64_t h_max = 0;
-            e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
             plan->n_groups = n_groups;
             plan->max_group_items = h_max;
             plan->max_item_tiles = (int)max_tiles;
