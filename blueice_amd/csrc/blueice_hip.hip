@@ -1276,6 +1276,9 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     // (falls back to the stream sync, which also reports a faulted kernel; every 256th call synchronises anyway, so the
     //  runtime retires its completed commands at a steady pace)
     if (e == hipSuccess && (!arrived || (seq & 255ull) == 0)) e = hipStreamSynchronize(c->stream);
+    // (a completion word that never came -- a launch that failed part way -- leaves the finish kernel's block counter in an
+    //  unknown state: it is zeroed again before the next call, which would otherwise wait out its 50 ms every time)
+    if (done_word && !arrived) c->toy_blocks_done_zeroed = false;
     if (e == hipSuccess && n && host_out) memcpy(out, res, (size_t)n * sizeof(double));
     cleanup();
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets: %s", hipGetErrorString(e));
