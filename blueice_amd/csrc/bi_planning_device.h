@@ -878,9 +878,22 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                 };
                 double best = 1e300;
                 for (int64_t b = 1; b <= b_max; ++b) best = std::min(best, pipe_cost(b));
+                int64_t b_model = 1;
                 for (int64_t b = 1; b <= b_max; ++b)
-                    if (pipe_cost(b) <= 1.03 * best) return b * 4;
-                return 4;
+                    if (pipe_cost(b) <= 1.03 * best) { b_model = b; break; }
+                // Since the strips of mixed counts are shared among a cell's waves (round 4) the measured optimum is simply
+                // about THREE rounds of the resident waves over all cells, with at least four strips per wave (dense data of C2:
+                // 48 waves per cell 125.6 ms, 128-384 122.0; 16 cells of 2500 strips: 836 waves per cell 11.1 ms, 252-504 10.4;
+                // the 155 compacted strips of C2 keep their 32 waves: tools/tune_scan_split_shapes.py).  The model above decides
+                // only where that target cannot be met.
+                const int64_t b_cap = std::min<int64_t>(b_max, std::max<int64_t>(1, strips / 16));
+                int64_t b_target = std::min<int64_t>(b_cap, std::max<int64_t>(1, (3 * capacity + n_groups / 2) / n_groups));
+                // (only where the target means several rounds: within ONE round of resident blocks the model's count of blocks
+                //  per CU decides -- 640 blocks on 256 CUs are 3 on half of them: 40 waves per cell 12.1 ms, 32 waves 10.1)
+                if (b_target * n_groups > capacity)
+                    for (int64_t b = b_target; b >= 1 && b * n_groups > capacity; --b)
+                        if (pipe_cost(b) < 1e299) return b * 4;                             // (the nearest evened-out split below the target)
+                return b_model * 4;
             }
             double best_cost = 1e300;
             int64_t best_b = 1;
