@@ -827,7 +827,7 @@ def main():
             'note': 'fp64 FMA work of the morph alone (2 * 2^d*S * bins flop per evaluation) of the busiest rank over the '
                     'whole step (planning + non-empty-bin pass + k_scan_valid + gather)'}
         legs['C4-dense']['roofline_scan']['frac'] = legs['C4-dense']['roofline_scan']['achieved'] / FP64_PEAK_TFLOPS
-        legs['C3'] = toy_leg(ctx, ranks, model, 10000, 20)
+        legs['C3'] = toy_leg(ctx, ranks, model, 10000, 100)      # (100 calls of ~0.13 ms: a steadier mean than 20)
         ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
     if rank == 0:
