@@ -1157,11 +1157,27 @@ __global__ __launch_bounds__(kThreads) void k_row_stats(const double* __restrict
                                                         double* __restrict__ out) {
     const double* __restrict__ r = rows + (int64_t)blockIdx.x * Bp;
     double s = 0.0, mn = __builtin_inf(), bad = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += kThreads) {
-        const double v = r[b];
-        s += v;
-        mn = fmin(mn, v);
-        if (!(fabs(v) < __builtin_inf())) bad = 1.0;
+    {   // (four loads in flight per thread: with one, the 37 MB tensor of a 9400-event unbinned toy took 147 us)
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t b = threadIdx.x;
+        for (; b + 3 * kThreads < B; b += 4 * kThreads) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = r[b + k * kThreads];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s4[k] += v[k];
+                mn = fmin(mn, v[k]);
+                if (!(fabs(v[k]) < __builtin_inf())) bad = 1.0;
+            }
+        }
+        for (; b < B; b += kThreads) {
+            const double v = r[b];
+            s4[0] += v;
+            mn = fmin(mn, v);
+            if (!(fabs(v) < __builtin_inf())) bad = 1.0;
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
     __shared__ double sh[3][kThreads / 64];
     s = wave_sum(s);
