@@ -214,15 +214,17 @@ class Ranks:
 # ---------------------------------------------------------------------------------------------------------
 # strong-scaling legs
 # ---------------------------------------------------------------------------------------------------------
-def predicted_ceiling(units, step_ms, kernel_ms, world):
+def predicted_ceiling(units, step_ms, kernel_ms, world, undivided_kernel_ms=0.0):
     """What a strong-scaling leg can reach at N ranks, from this run's own split of a step: the kernels' share divides by
     N, everything else (planning of ALL units on every rank, copies, the gather, the read-back) is paid by every rank in
-    full.  `kernel_ms` is this run's kernel time per step on the busiest rank (HIP events), i.e. 1/world of the total."""
+    full.  `kernel_ms` is this run's kernel time per step on the busiest rank (HIP events), i.e. 1/world of the total;
+    `undivided_kernel_ms` is the part of it that every rank repeats in full (the toy leg's log mu pass over all bins)."""
     kernel_ms = min(kernel_ms, step_ms)          # (the step that carries the HIP events is a little slower than the timed ones)
-    fixed = step_ms - kernel_ms
-    total_kernel = kernel_ms * world
+    undivided = min(max(0.0, undivided_kernel_ms), kernel_ms)
+    fixed = step_ms - kernel_ms + undivided
+    total_kernel = (kernel_ms - undivided) * world
     return dict(model='per-rank fixed ms + kernel ms / N', fixed_ms_per_rank=fixed, kernel_ms_total=total_kernel,
-                measured_at_n=world,
+                kernel_ms_repeated_by_every_rank=undivided, measured_at_n=world,
                 evals_per_s={str(n): units / ((fixed + total_kernel / n) * 1e-3) for n in (1, 2, 4, 8)})
 
 
@@ -402,6 +404,14 @@ def toy_leg(ctx, ranks, model, T, steps):
     n_launch, kernel_ms = ctx.profile_read()
     ctx.profile(False)
     kernel_ms = ranks.max_over_ranks(kernel_ms)
+    # the part of the kernels that does not shrink with the number of ranks: the log mu pass over all bins (a call on 64
+    # datasets is that pass and next to nothing else)
+    ctx.eval_datasets(points[0], r, 0, min(64, t1_ - t0_))
+    ctx.profile(True)
+    ctx.eval_datasets(points[0], r, 0, min(64, t1_ - t0_))
+    _, logmu_ms = ctx.profile_read()
+    ctx.profile(False)
+    logmu_ms = ranks.max_over_ranks(logmu_ms)
     ctx.set_param('toy_offset', 0)
     # algorithmic bytes of a call on this rank: the 2^d*S template rows once (log mu of every bin) + one list entry (2 bytes: the
     # bin's byte offset within its tile and a count of at most 7 -- what these toys hold; 4 bytes otherwise) per non-empty bin of
@@ -423,7 +433,7 @@ def toy_leg(ctx, ranks, model, T, steps):
                 unit='evals/s', ms_per_step=step_ms, generate_s=gen_s, toys_rechecked_bitwise=checked,
                 nonempty_bins_this_rank=nnz, gather=ranks.kind, roofline=roof,
                 step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, step_ms - kernel_ms)),
-                predicted_ceiling=predicted_ceiling(T, step_ms, kernel_ms, world))
+                predicted_ceiling=predicted_ceiling(T, step_ms, kernel_ms, world, undivided_kernel_ms=logmu_ms))
 
 
 def c5_leg(ctx, ranks, steps=24, threads=8):

@@ -66,6 +66,10 @@ def test_host_threads_are_shared_among_the_ranks():
     assert pc['fixed_ms_per_rank'] == 3.0 and abs(pc['evals_per_s']['8'] - 1e6 / ((3.0 + 9.0 / 8) * 1e-3)) < 1e-3
     pc2 = bench.predicted_ceiling(10 ** 6, step_ms=3.0 + 9.0 / 4, kernel_ms=9.0 / 4, world=4)      # the same leg measured at N = 4
     assert abs(pc2['evals_per_s']['8'] - pc['evals_per_s']['8']) < 1e-3 and abs(pc2['evals_per_s']['1'] - pc['evals_per_s']['1']) < 1e-3
+    # the toy leg: the log mu pass over all bins is repeated by every rank in full, only the rest of the kernels divides
+    pc3 = bench.predicted_ceiling(10 ** 4, step_ms=0.14, kernel_ms=0.10, world=1, undivided_kernel_ms=0.047)
+    assert abs(pc3['fixed_ms_per_rank'] - 0.087) < 1e-12 and abs(pc3['evals_per_s']['8'] - 1e4 / ((0.087 + 0.053 / 8) * 1e-3)) < 1e-3
+    assert abs(pc3['evals_per_s']['1'] - 1e4 / 0.14e-3) < 1e-3
 
 
 def test_a_failing_rank_fails_the_command():
