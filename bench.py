@@ -243,6 +243,28 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     world, rank = ranks.world, ranks.rank
     work = [model.random_points(P, seed=900 + s) for s in range(steps + 1)]      # step 0 is the warm-up
     device_deal = world > 1
+    can_reside = True
+    # The device planner refuses (ValueError: BI_ERR_INVALID) Beeston-Barlow batches in which some bin can have U_b == 0, or
+    # with bb_exact = 1, and infinite rates of a source that may go negative: such a leg is dealt on the host and planned
+    # from host arrays, on every rank alike (the ranks agree before the first step)
+    refused = 0
+    try:
+        probe = ctx.plan_share(work[0][0], work[0][1], None, rank, world) if device_deal else None
+        if probe is None:
+            bz, br = ctx.device_alloc(work[0][0].nbytes), ctx.device_alloc(work[0][1].nbytes)
+            bz.from_host(work[0][0]); br.from_host(work[0][1])
+            try:
+                probe = ctx.plan_resident(P, bz, br)
+            finally:
+                bz.free(); br.free()
+        probe.close()
+    except ValueError as e:
+        log('%s: the device planner refuses this batch (%s): host dealing, host-array plans' % (label, e))
+        refused = 1
+    if ranks.comm is not None:
+        refused = int(ranks.comm.all_reduce(np.array([refused], dtype=np.int64), 'bor')[0])
+    if refused:
+        device_deal, can_reside = False, False
     stride = P if world == 1 else -(-P // world)
     send, _ = ranks.buffers(stride)
     send.from_host(np.zeros(stride))
@@ -294,7 +316,6 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     # the same steps with the points already in HBM when the clock starts (bi_plan_points_resident): the leg's `value`;
     # the rate with the points handed over as host arrays -- the reference's calling convention, H2D inside -- beside it
     elapsed = elapsed_host
-    can_reside = True
     if can_reside:
         held = []
         for z, r in work:
@@ -333,7 +354,8 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     assert np.all(np.isfinite(out)), '%s: non-finite values in the gathered scan' % label
     return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
                 ms_per_step=elapsed / steps * 1e3,
-                inputs='points resident in HBM when the clock starts (bi_plan_points_resident); results copied to the host inside',
+                inputs=('points resident in HBM when the clock starts (bi_plan_points_resident); results copied to the host inside' if can_reside
+                        else 'host arrays (the device planner refused the batch: host planner, H2D inside the clock)'),
                 value_host_points=P * steps / elapsed_host, ms_per_step_host_points=elapsed_host / steps * 1e3,
                 points_per_rank_min_max=seen['share'],
                 dealing=('device planner sort, inside the step' if device_deal else

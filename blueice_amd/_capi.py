@@ -111,6 +111,11 @@ def load():
             raise DeviceError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    # BLUEICE_AMD_LIB exists for A/B runs of two builds of THIS library; it is not a backend switch: whatever is loaded must
+    # say it is the gfx950 build (the host build of the boundary tests calls itself "... not the product")
+    version = (lib.bi_version() or b'').decode()
+    if not version.startswith('blueice_hip') or '(gfx950)' not in version or 'not the product' in version:
+        raise DeviceError("%s is not a gfx950 build of libblueice_hip (bi_version: %r)" % (LIB_PATH, version))
     _lib = lib
     return lib
 

@@ -1,4 +1,5 @@
-"""Build libblueice_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build libblueice_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU): six translation units compiled
+side by side, rebuilt when the sha256 of the sources' content changes (lib/libblueice_hip.sha256).
 
     python -m blueice_amd.build [--force]
 
@@ -6,17 +7,34 @@ build_host() compiles csrc/host_backend.cpp -- the minimal entry points of the s
 host -- into lib/libblueice_host.so.  That library is a BOUNDARY TEST BUILD: the package
 never loads it (blueice_amd/_capi.py binds libblueice_hip.so only); tests and tools/ load it by explicit path.
 """
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SRC = os.path.join(CSRC, 'blueice_hip.hip')          # the one translation unit; bi_*.h are included by it
+# one translation unit per heavy kernel family (csrc/bi_common.h says which), compiled side by side
+UNITS = ('blueice_hip', 'tu_morph', 'tu_scan', 'tu_scan_sorted', 'tu_grad', 'tu_prim')
 HDR = os.path.join(os.path.dirname(_HERE), 'include', 'blueice_hip.h')
 OUT_DIR = os.path.join(_HERE, 'lib')
+OBJ_DIR = os.path.join(_HERE, 'lib', 'obj')
 OUT = os.path.join(OUT_DIR, 'libblueice_hip.so')
+STAMP = os.path.join(OUT_DIR, 'libblueice_hip.sha256')
 ARCH = 'gfx950'
+
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC',
+         # no implicit FMA contraction: the compatibility morph and the Beeston-Barlow roots follow the
+         # reference's operation order exactly; the hot loop uses explicit fma()
+         '-ffp-contract=off',
+         # fp64 MFMA accumulators in VGPRs: the scan kernels compare / use every matrix element with vector
+         # instructions, and with the accumulators in AGPRs each element costs two v_accvgpr_read first (no vector
+         # instruction executes beside an fp64 MFMA on gfx950, so every one of them is MFMA time lost)
+         '-mllvm', '--amdgpu-mfma-vgpr-form',
+         # only the C ABI of include/blueice_hip.h is exported; the launchers between the translation units stay inside
+         '-fvisibility=hidden',
+         '-Wall', '-Wno-unused-function']
 
 
 def hipcc():
@@ -26,25 +44,55 @@ def hipcc():
     return 'hipcc'
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OUT_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT):
-        deps = [HDR] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
-        newest = max(os.path.getmtime(f) for f in deps)
-        if os.path.getmtime(OUT) >= newest:
-            return OUT
-    cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-shared', '-fPIC',
-           # no implicit FMA contraction: the compatibility morph and the Beeston-Barlow roots follow the
-           # reference's operation order exactly; the hot loop uses explicit fma()
-           '-ffp-contract=off',
-           # fp64 MFMA accumulators in VGPRs: the scan kernels compare / use every matrix element with vector
-           # instructions, and with the accumulators in AGPRs each element costs two v_accvgpr_read first (no vector
-           # instruction executes beside an fp64 MFMA on gfx950, so every one of them is MFMA time lost)
-           '-mllvm', '--amdgpu-mfma-vgpr-form',
-           '-Wall', '-Wno-unused-function', '-o', OUT, SRC]
+def _sources():
+    return sorted([HDR] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))])
+
+
+def source_hash():
+    """sha256 over the CONTENT of every source the library is built from, and the flags: what the rebuild is gated on
+    (a fresh clone has fresh mtimes but the same content; a touched file with the same bytes is not a change)."""
+    h = hashlib.sha256()
+    h.update(' '.join(FLAGS).encode())
+    for f in _sources():
+        if f.endswith('host_backend.cpp'):
+            continue
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def up_to_date():
+    if not (os.path.exists(OUT) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == source_hash()
+
+
+def build(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if not force and up_to_date():
+        return OUT
+    digest = source_hash()
+    cc = hipcc()
+
+    def compile_unit(name):
+        obj = os.path.join(OBJ_DIR, name + '.o')
+        cmd = [cc] + FLAGS + ['-c', '-o', obj, os.path.join(CSRC, name + '.hip')]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    jobs = jobs or max(1, min(len(UNITS), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_unit, UNITS))
+    cmd = [cc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-fvisibility=hidden', '-o', OUT] + objs
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(STAMP, 'w') as fh:
+        fh.write(digest + '\n')
     return OUT
 
 

@@ -3,24 +3,22 @@
 
 struct bi_ctx;
 
-namespace {
-
 constexpr int kThreads = 256;           // 4 wave64 per block
 constexpr int kBinsPerThread = 2;       // one 16-byte load per stream per lane
 constexpr int kTile = kThreads * kBinsPerThread;  // 512 bins = 4 KiB per stream per block tile
 constexpr int kMaxDim = 8;              // shape parameters
 constexpr int kMaxG = 16;               // points per cell pass
 
-thread_local std::string g_create_error;
+// (the library is several translation units -- one per heavy kernel family, compiled in parallel: types that cross them
+//  sit at global scope, state that must exist once is `inline`)
+inline thread_local std::string g_create_error;
 
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    struct ::bi_ctx* owner = nullptr;  // context whose recycle cache takes the buffer back on dev_free
+    struct bi_ctx* owner = nullptr;    // context whose recycle cache takes the buffer back on dev_free
     bool view = false;                 // a window into somebody else's allocation: dev_free only forgets it
 };
-
-}  // namespace
 
 struct bi_plan {
     int64_t P = 0;

@@ -13,6 +13,9 @@
 //                         variable j is a shape parameter (z_i = x_j) or a rate multiplier (rate_scale_s = x_j * unit_s)
 #pragma once
 
+#include <new>
+#include <stdexcept>
+
 namespace {
 
 struct FitState {
@@ -424,6 +427,21 @@ int device_objective(void* user, int64_t n, int F, const double* x, const int64_
     return BI_OK;
 }
 
+// the entry points' argument checks: at most 2^24 problems per call (the optimiser's state is ~(F^2 + 8 F) doubles per problem),
+// kink counts >= 0 and every variable's kinks ascending (the line search finds the next kink by bisection)
+constexpr int64_t kFitMaxProblems = (int64_t)1 << 24;
+bool kinks_are_valid(int F, const int32_t* n_kinks, const double* kinks) {
+    if (!n_kinks) return true;
+    int64_t off = 0;
+    for (int j = 0; j < F; ++j) {
+        if (n_kinks[j] < 0 || (n_kinks[j] > 0 && !kinks)) return false;
+        for (int q = 1; q < n_kinks[j]; ++q)
+            if (!(kinks[off + q - 1] <= kinks[off + q])) return false;
+        off += n_kinks[j];
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -431,9 +449,17 @@ extern "C" {
 int bi_minimize_batched(bi_objective_fn fun, void* user, int64_t P, int F, const double* x0, const double* lo, const double* hi,
                         const int32_t* n_kinks, const double* kinks, double gtol, int max_iter, double* x_out, double* f_out,
                         int32_t* flags_out, int64_t* counters) {
-    if (!fun || P < 0 || F < 1 || F > 64 || !x0 || !lo || !hi || !x_out || !f_out || !flags_out) return BI_ERR_INVALID;
+    if (!fun || P < 0 || P > kFitMaxProblems || F < 1 || F > 64 || !x0 || !lo || !hi || !x_out || !f_out || !flags_out) return BI_ERR_INVALID;
+    if (!kinks_are_valid(F, n_kinks, kinks)) return BI_ERR_INVALID;
     if (P == 0) { if (counters) counters[0] = counters[1] = counters[2] = 0; return BI_OK; }
-    return minimize_batched(fun, user, P, F, x0, lo, hi, n_kinks, kinks, gtol, max_iter, x_out, f_out, flags_out, counters);
+    // (nothing may unwind through the C ABI: the optimiser's state is std::vectors of P F^2 doubles)
+    try {
+        return minimize_batched(fun, user, P, F, x0, lo, hi, n_kinks, kinks, gtol, max_iter, x_out, f_out, flags_out, counters);
+    } catch (const std::bad_alloc&) {
+        return BI_ERR_NOMEM;
+    } catch (const std::exception&) {
+        return BI_ERR_INVALID;
+    }
 }
 
 int bi_fit_batched(bi_ctx* c, int64_t P, int F, const int32_t* var_kind, const int32_t* var_index, const double* z0,
@@ -442,17 +468,24 @@ int bi_fit_batched(bi_ctx* c, int64_t P, int F, const int32_t* var_kind, const i
                    double* f_out, int32_t* flags_out, int64_t* counters) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (P < 0 || F < 1 || F > 64 || !var_kind || !var_index || !scale0 || !unit || (c->d > 0 && !z0) || !x0 || !lo || !hi || !x_out ||
+    if (P < 0 || P > kFitMaxProblems || F < 1 || F > 64 || !var_kind || !var_index || !scale0 || !unit || (c->d > 0 && !z0) || !x0 || !lo || !hi || !x_out ||
         !f_out || !flags_out)
         return fail(c, BI_ERR_INVALID, "bi_fit_batched: bad arguments");
     for (int j = 0; j < F; ++j)
         if ((var_kind[j] == 0 && (var_index[j] < 0 || var_index[j] >= c->d)) || (var_kind[j] == 1 && (var_index[j] < 0 || var_index[j] >= c->S)) ||
             (var_kind[j] != 0 && var_kind[j] != 1))
             return fail(c, BI_ERR_INVALID, "bi_fit_batched: variable %d is neither a shape parameter nor a rate multiplier of this model", j);
+    if (!kinks_are_valid(F, n_kinks, kinks)) return fail(c, BI_ERR_INVALID, "bi_fit_batched: n_kinks must be >= 0 and the kinks of a variable ascending");
     if (P == 0) { if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0; return BI_OK; }
     DeviceObjective o{};
     o.c = c; o.F = F; o.var_kind = var_kind; o.var_index = var_index; o.z0 = z0; o.scale0 = scale0; o.unit = unit; o.dataset = dataset;
-    rc = minimize_batched(device_objective, &o, P, F, x0, lo, hi, n_kinks, kinks, gtol, max_iter, x_out, f_out, flags_out, counters);
+    try {
+        rc = minimize_batched(device_objective, &o, P, F, x0, lo, hi, n_kinks, kinks, gtol, max_iter, x_out, f_out, flags_out, counters);
+    } catch (const std::bad_alloc&) {
+        return fail(c, BI_ERR_NOMEM, "bi_fit_batched: out of host memory for %lld problems of %d variables", (long long)P, F);
+    } catch (const std::exception& e) {
+        return fail(c, BI_ERR_INVALID, "bi_fit_batched: %s", e.what());
+    }
     if (counters) counters[3] = o.evaluations;
     return rc;
 }

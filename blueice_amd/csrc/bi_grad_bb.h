@@ -1,5 +1,5 @@
 // bi_grad_bb.h -- host half of bi_eval_grad for Beeston-Barlow models: per point the coefficient COLUMNS of the value
-// and of its derivatives (k_morph_bbgrad, bi_kernels.h), one work item per point, k_finish for the sums.
+// and of its derivatives (k_morph_bbgrad, bi_k_bbgrad.h), one work item per point, k_finish for the sums.
 #pragma once
 
 namespace {

@@ -1,113 +1,15 @@
-// bi_kernels.h -- every __global__ / __device__ function of libblueice_hip (gfx950 only).
-// Included once by blueice_hip.hip; see DESIGN.md section 4 for what each kernel is for and what bounds it.
+// bi_k_misc.h -- the small kernels of the main translation unit (blueice_hip.hip): uploads, reductions, finish kernels,
+// the toy-MC form, toy generation, histogramming, event scoring.  The heavy template families live in bi_k_morph.h,
+// bi_k_bbgrad.h, bi_k_scan.h, bi_scan_sorted.h and bi_grad_mfma.h, one translation unit each.
 #pragma once
 
 namespace {
-
-// ------------------------------------------------------------------------------------------
-// device code
-// ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ unsigned wave_or(unsigned v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
-    return v;
-}
-
-// Natural logarithm for the per-bin terms, table-driven (the scheme of Tang's table-driven log as used by modern
-// libms, laid out for this hardware): x = 2^k z with z in [0.6875, 1.375); the 7 leading mantissa bits pick a
-// subinterval with centre c from a 128-entry {1/c, log c hi, log c lo} table held in LDS (bi_log_table.h); then
-//     log x = (k ln2_hi + log c_hi) + ( r + (r^2 P(r) + k ln2_lo + log c_lo) ),   r = z / c - 1   (one fma, |r| <= 2^-7)
-// where the first bracket is EXACT in one fma (ln2_hi on a 2^-37 grid, log c_hi on a 2^-43 grid), P is log1p's Taylor
-// polynomial through r^8, and the sum of the first bracket and r is carried with its rounding error.  16 fp64
-// instructions, one conversion and 6 integer ones per call (round 1: 19 + 1 + 6: it also had to recover the rounding of an
-// inexact k ln2 + log c), two LDS reads, no division and no transcendental-rate instruction; worst error 0.70 ulp, 98.6 %
-// of results correctly rounded
-// (tools/gen_log_table.py, tests/test_gpu_golden.py::test_device_log_accuracy).  On a chip where no vector instruction
-// executes beside an fp64 MFMA, the logarithm's instruction count is what bounds scans over dense data.
-// Every kernel that calls bin_log fills the LDS table first: log_table_load(), or the overlapped form in morph_tiles.
-__shared__ double4 s_log_table[128];
-
-__device__ __forceinline__ void log_table_load() {
-    if (threadIdx.x < 128) s_log_table[threadIdx.x] = kLogTable[threadIdx.x];
-    __syncthreads();
-}
-
-__device__ __forceinline__ bool pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
-// Factors of the product forms of sum n log mu (k_scan_mfma): up to eight of them, each above 2^-127, multiply to at least
-// 2^-1016 -- a normal number -- in any grouping; a comparison with it is false for nan, zero and negative numbers too.
-constexpr double kProdFloor = 0x1p-127;
-
-// the core: x must be a positive normal number (anything else gives a meaningless but harmless value);
-// k_adjust is added to the binary exponent
-__device__ __forceinline__ double log_core(double x, int k_adjust) {
-    const unsigned long long ix = __double_as_longlong(x);
-    const int hi = (int)(ix >> 32);
-    const int t = hi - 0x3FE60000;                  // bits(x) - bits(0.6875), high word
-    const int k0 = t >> 20;
-    const int k = k0 + k_adjust;
-    // high word of z = hi - (k0 << 20), as ONE 24-bit multiply-add (|k0| <= 2^10, 2^20 < 2^23; written as an instruction
-    // because the compiler turns the product back into a mask and a subtraction)
-    int zhi;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(zhi) : "v"(k0), "s"(-(1 << 20)), "v"(hi));
-    const double z = __longlong_as_double(((unsigned long long)(unsigned)zhi << 32) | (ix & 0xFFFFFFFFull));
-    const double4 e = s_log_table[(t >> 13) & 127];
-    const double kd = (double)k;
-    const double r = fma(z, e.x, -1.0);
-    const double w = fma(kd, kLn2Hi, e.y);         // exact
-    const double tail = fma(kd, kLn2Lo, e.z);
-    double p = fma(r, -1.0 / 8.0, e.w);            // e.w = 1/7: arrives in a vector register with the table entry
-    p = fma(r, p, -1.0 / 6.0);
-    p = fma(r, p, 1.0 / 5.0);
-    p = fma(r, p, -1.0 / 4.0);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    const double q = fma(r * r, p, tail);
-    // w + r with its rounding error kept (|w| >= |r| wherever w != 0: k != 0, or a subinterval away from the two that touch
-    // 1): where log c and r nearly cancel -- arguments a little off 1 -- the plain r + q would cost up to an ulp
-    const double h = w + r;
-    const double err = (w - h) + r;
-    return h + (err + q);
-}
-
-// for arguments known to be positive normal numbers
-__device__ __forceinline__ double bin_log_fast(double x) { return log_core(x, 0); }
-
-// for any argument, still without a branch: denormals are scaled by 2^54 first; log 0 = -inf, log of a negative
-// number or nan = nan, log inf = inf (numpy.log's values)
-__device__ __forceinline__ double bin_log(double x) {
-    const bool tiny = x < 2.2250738585072014e-308;
-    double y = log_core(tiny ? x * 18014398509481984.0 : x, tiny ? -54 : 0);
-    if (x == 0.0) y = -__builtin_inf();
-    if (!(x >= 0.0)) y = __builtin_nan("");
-    if (x == __builtin_inf()) y = x;
-    return y;
-}
 
 // self-test hook: out[i] = bin_log(x[i])
 __global__ void k_selftest_log(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
     log_table_load();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bin_log(x[i]);
-}
-
-template <bool NT>
-__device__ __forceinline__ double2 stream_load(const double* p) {
-    if constexpr (NT) {
-        // streamed-once data: nontemporal hint (global_load_dwordx4 ... nt) keeps it from displacing L2 / MALL lines
-        double2 v;
-        v.x = __builtin_nontemporal_load(p);
-        v.y = __builtin_nontemporal_load(p + 1);
-        return v;
-    } else {
-        return *reinterpret_cast<const double2*>(p);
-    }
 }
 
 // measurement probe: a plain sum over n2 16-byte elements -- the read-only streaming ceiling the morph kernel is
@@ -158,732 +60,9 @@ __global__ __launch_bounds__(kThreads) void k_read_rows(const double* __restrict
     if (s == 0.123456789) sink[0] = s;      // keeps the loads alive, practically never stores
 }
 
-// Poisson log-pmf without the data-only lgamma(n+1) term, scipy semantics
-// (scipy/stats/_distn_infrastructure.py logpmf + _discrete_distns.py poisson._logpmf):
-//   mu not >= 0 (negative or nan) or n nan -> nan
-//   n negative or non-integer             -> -inf
-//   else xlogy(n, mu) - mu                  (xlogy(0, mu) = 0, also for mu = 0)
-__device__ __forceinline__ double poisson_term(double n, double mu) {
-    double t;
-    if (n > 0.0) {
-        t = n * bin_log(mu) - mu;  // mu = 0 -> -inf; mu < 0 -> nan
-    } else {
-        t = -mu;
-    }
-    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
-    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
-    return t;
-}
-
-// The same term without a branch, for unrolled loops (the compiler can then batch the table reads of many terms).
-// Only valid where n > 0 implies that mu is a positive normal number -- the caller checks that for the whole wave
-// (needs_checked_term) and takes poisson_term otherwise.  Same operations, same bits.
-__device__ __forceinline__ bool needs_checked_term(double n, double mu) { return n > 0.0 && !pos_normal(mu); }
-
-__device__ __forceinline__ double poisson_term_fast(double n, double mu) {
-    const double lg = bin_log_fast(mu);            // not used where n <= 0
-    double t = (n > 0.0) ? n * lg - mu : -mu;
-    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
-    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
-    return t;
-}
-
-// ... for a bin column in which no lane has n > 0
-__device__ __forceinline__ double poisson_term_nolog(double n, double mu) {
-    double t = -mu;
-    if (!(mu >= 0.0) || n != n) t = __builtin_nan("");
-    else if (n < 0.0 || n != floor(n)) t = -__builtin_inf();
-    return t;
-}
-
-// Beeston-Barlow roots, evaluated in the reference's own operation order without FMA
-// contraction (blueice/likelihood.py:693-712) so that the sign tests behind its two asserts
-// see the same rounding.
-__device__ __forceinline__ void bb_roots(double a, double p, double U, double d, double& r1, double& r2) {
-#pragma clang fp contract(off)
-    double U2 = U * U, p2 = p * p, a2 = a * a, d2 = d * d;
-    double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * a * p2 + 2 * U * a * p - 2 * U * d * p2 - 2 * U * d * p +
-                  a2 * p2 + 2 * a * d * p2 + d2 * p2;
-    double lead = -U * p - U + a * p + d * p;
-    double den = 2 * p * (p + 1);
-    double sq = sqrt(disc);
-    r1 = (lead - sq) / den;
-    r2 = (lead + sq) / den;
-}
-
-// ---- in-launch finishing through mailboxes -------------------------------------------------------------------
-// A work item's blocks post their partial sums into 8-byte mailbox slots and EXIT; the item's last block in dispatch
-// order (blockIdx.x == gridDim.x - 1: every sibling was dispatched before it, so they are running or done) collects
-// them, sums them in block order (fixed order => bitwise reproducible) and writes the result -- what the k_finish
-// launch did, without the launch.  A slot is one naturally aligned 8-byte granule written by ONE system-scope
-// (sc0 sc1, write-through) store and read with system-scope loads (MI355X_MICROARCH.md "Valid forms": sc0 sc1
-// stores and loads on both sides need no fence); "empty" is a signalling-NaN bit pattern that no arithmetic result
-// can have (posted NaNs are canonicalised), and the collector puts it back as it takes a value, so the slots are
-// empty again when the launch ends.  Posting costs a block one store and no wait: round 2 first tried arrival
-// tickets (publish, drain, returning atomics) and measured +27 us on a 300 us launch -- every one of 8192 blocks
-// held its CU slot for ~4 us of round trips -- and round 1's release fence per block was worse still.
-// The collector's wait is bounded (LaunchArgs::mail_timeout ticks of the 100 MHz wall clock, 2 s by default): if a value never arrives it gives
-// up, reports BI_ST_INTERNAL and the result is nan -- no wave can spin forever.
-constexpr unsigned long long kMailEmpty = 0x7FF4B10E1CE00001ull;
-constexpr long long kMailTicksPerMs = 100000;                          // wall_clock64 runs at 100 MHz
-
-__device__ __forceinline__ void mail_post(double* slot, double v) {
-    if (v != v) v = __builtin_nan("");                                   // never the "empty" pattern
-    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// take the value out of a slot (waiting for it), leave the slot empty; *late is set if the wait ran out
-__device__ __forceinline__ double mail_take(double* slot, long long deadline, bool* late) {
-    unsigned long long bits;
-    for (;;) {
-        bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (bits != kMailEmpty) break;
-        if ((long long)wall_clock64() > deadline) { *late = true; return __builtin_nan(""); }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), kMailEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return __longlong_as_double(bits);
-}
-
-// The collector's inner step: the values of slots q0, q0 + stride, ... (up to 4, below `total`) added to s in that order.
-// The four loads go out together -- a system-scope load takes about a microsecond, and by the time the last block
-// collects nearly every sibling has posted, so polling one slot after the other would only add their latencies up
-// (measured on a one-item launch of 1954 blocks x 8 columns: 86 us with sequential takes, the kernel proper 45).
-__device__ __forceinline__ double mail_take4(double* mail, int q0, int stride, int total, double s, long long deadline, bool* late) {
-    unsigned long long bits[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = q0 + u * stride;
-        bits[u] = q < total ? __hip_atomic_load(reinterpret_cast<unsigned long long*>(mail + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                            : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = q0 + u * stride;
-        if (q >= total) break;
-        if (bits[u] == kMailEmpty) {
-            s += mail_take(mail + q, deadline, late);            // not there yet: wait for this one
-        } else {
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(mail + q), kMailEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s += __longlong_as_double(bits[u]);
-        }
-    }
-    return s;
-}
-
-// Beeston-Barlow status bits travel through one word per result slot: a block that has any ORs them in BEFORE it
-// posts its partial (returning atomic: performed when it returns), the collector swaps the word for 0 after the
-// partials have arrived
-__device__ __forceinline__ void flags_post(unsigned* word, unsigned f) {
-    if (f) {
-        const unsigned old = __hip_atomic_fetch_or(word, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("" ::"v"(old) : "memory");                           // the post below must not be hoisted above the return
-    }
-}
-__device__ __forceinline__ unsigned flags_take(unsigned* word) {
-    return __hip_atomic_exchange(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ void k_mail_init(unsigned long long* slots, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slots[i] = kMailEmpty;
-}
-
-struct LaunchArgs {
-    const double* ps;       // [rows][Bp]
-    const double* nm;       // [A][Bp] (BB) or null
-    const double* counts;   // [T][Bp]
-    const int64_t* rowoff;  // [items][NS]  element offsets of the stream rows
-    const double* coef;     // [items][NS][G]
-    const double* aux;      // [items][G][2]  (p_cal, N) for BB
-    const int64_t* item_cnt; // [items] element offset of the item's counts row
-    const int32_t* item_tiles; // [items] 512-bin tiles of the item's rows (NULL: n_tiles)
-    double* partial;        // [items][nbx][G]
-    unsigned* pflags;       // [items][nbx][G]
-    int64_t B, Bp;
-    double outlier;         // MODE 2: likelihood given to events with a non-positive density (0 = none)
-    int n0, n1, n2;         // streams into U (or mu), into P_i, into a
-    int n_tiles;
-    int chunks;             // > 1: consecutive blocks work in `chunks` far-apart regions of the rows
-    int n_keep;             // NT kernels: the first n_keep stream rows are loaded with the default (cacheable) policy
-    // in-launch finish (k_morph_reduce): when fin_mail != NULL the item's last block collects the item's partials
-    // from the mailbox slots and writes the results -- no k_finish launch behind the morph launch
-    double* fin_mail;           // [items][nbx][G] mailbox slots, empty on entry and on exit
-    unsigned* fin_flags;        // [items][G] status words (Beeston-Barlow), zero on entry and on exit
-    const int64_t* fin_perm;    // [items][G]  result index of every slot (-1: unused slot)
-    const double* fin_slot_lg;  // [items][G]  constant subtracted from the sum
-    double* fin_out;            // results (device or pinned host memory)
-    int32_t* fin_status;        // or NULL
-    int nan_S;              // MODE 2 with non-finite pdf values: number of sources (streams are [corner][source]); the
-                            // sum over sources then skips nan terms -- np.nansum, blueice/likelihood.py:686.  0 = off
-    long long mail_timeout = 2000 * kMailTicksPerMs; // in-launch finish: ticks of the 100 MHz wall clock a collector waits (context: mail_timeout_ms;
-                            // default 2 s, far beyond any delay a busy, shared GPU causes)
-    int skip_post = -1, late_post = -1;   // fault injection (tests): this block never posts / posts after the collector gave up; -1 = off
-};
-
-// the post of a block's partial sum with the two injected faults (both -1 in production: two scalar compares per block)
-__device__ __forceinline__ void mail_post_checked(const LaunchArgs& a, double* slot, double v) {
-    if ((int)blockIdx.x == a.skip_post) return;
-    if ((int)blockIdx.x == a.late_post) {
-        const long long until = (long long)wall_clock64() + 2 * a.mail_timeout;
-        while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-    }
-    mail_post(slot, v);
-}
-
-// The morph + reduce kernel.  blockIdx.y = item (a cell pass with up to G points),
-// blockIdx.x strides over 512-bin tiles.
-
-// The accumulate + per-bin term loop shared by the batched kernel and the single-point kernel: tiles
-// tile0, tile0 + tile_step, ... of one work item.
-template <int G, bool BB, bool NT, int MODE>
-__device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* __restrict__ rowoff,
-                                            const double* __restrict__ coef, const double* __restrict__ aux_base,
-                                            const double* __restrict__ cnt, int n_tiles, int tile0, int tile_step,
-                                            double (&sum)[G], unsigned (&flg)[G]) {
-    // the log table travels global -> registers -> LDS; the request goes out first and lands under the first tile's
-    // row loads, so a block that lives for only a few tiles does not wait for it separately
-    double4 tab = {0.0, 0.0, 0.0, 0.0};
-    if (threadIdx.x < 128) tab = kLogTable[threadIdx.x];
-    bool tab_pending = true;
-    // XCD-aware tile order: with 8 chunks block b -- dispatched to XCD b % 8 -- streams the b % 8-th contiguous region of
-    // every row instead of every 8th tile (measured +6 % on the 113-stream BB pass, +1 % on C2); short rows keep the
-    // plain order, where the padded chunk count would cost some blocks a second tile
-    const int chunks = (a.chunks > 1 && n_tiles >= 64 * a.chunks) ? a.chunks : 1;
-    const int per_chunk = (n_tiles + chunks - 1) / chunks;
-    for (int lt = tile0; lt < per_chunk * chunks; lt += tile_step) {     // (the trip count is the same for a whole block)
-        const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
-        if (tile >= n_tiles) continue;
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        double acc[G][2];
-#pragma unroll
-        for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
-
-        int k0 = 0;
-        if constexpr (NT && G == 1 && MODE != 2 && MODE != 3) {
-            // rows meant to stay in the Infinity Cache between calls (repeated evaluations in one cell): default policy
-            k0 = a.n_keep;
-#pragma unroll 8
-            for (int k = 0; k < k0; ++k) {
-                const double2 v = stream_load<false>(a.ps + rowoff[k] + bin0);
-                const double c = coef[k];
-                acc[0][0] = fma(c, v.x, acc[0][0]);
-                acc[0][1] = fma(c, v.y, acc[0][1]);
-            }
-        }
-        if constexpr (MODE == 2 || MODE == 3) if (a.nan_S > 0) {
-            // np.nansum over sources (likelihood.py:686): a source whose morphed density times its rate is nan at an
-            // event contributes nothing there.  Per source the corners are summed first (the morph), then the test.
-            const int S = a.nan_S, nc = a.n0 / S;
-            for (int s = 0; s < S; ++s) {
-                double part[G][2];
-#pragma unroll
-                for (int g = 0; g < G; ++g) { part[g][0] = 0.0; part[g][1] = 0.0; }
-                for (int c = 0; c < nc; ++c) {
-                    const int k = c * S + s;
-                    const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const double cf = coef[k * G + g];
-                        part[g][0] = fma(cf, v.x, part[g][0]);
-                        part[g][1] = fma(cf, v.y, part[g][1]);
-                    }
-                }
-                if constexpr (MODE == 3) {        // gradient: a source dropped from the value is dropped from its slopes too
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (part[0][j] == part[0][j]) {
-#pragma unroll
-                            for (int g = 0; g < G; ++g) acc[g][j] += part[g][j];
-                        }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if (part[g][0] == part[g][0]) acc[g][0] += part[g][0];
-                        if (part[g][1] == part[g][1]) acc[g][1] += part[g][1];
-                    }
-                }
-            }
-            k0 = a.n0;
-        }
-#pragma unroll 8
-        for (int k = k0; k < a.n0; ++k) {
-            const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const double c = coef[k * G + g];
-                acc[g][0] = fma(c, v.x, acc[g][0]);
-                acc[g][1] = fma(c, v.y, acc[g][1]);
-            }
-        }
-        double2 nv;
-        if constexpr (MODE == 2 || MODE == 3) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
-        if (tab_pending) {
-            if (threadIdx.x < 128) s_log_table[threadIdx.x] = tab;
-            __syncthreads();
-            tab_pending = false;
-        }
-
-        if constexpr (MODE == 2) {
-            // extended unbinned likelihood (blueice/likelihood.py:678-690): the "bins" are the events,
-            // the term is log(sum_s mu_s p_s(x_e)) with the outlier clamp; -sum_s mu_s is added by the host
-            bool checked = false;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (a.outlier != 0.0 && !(acc[g][j] > 0.0)) acc[g][j] = a.outlier;
-                    checked |= bin0 + j < a.B && !pos_normal(acc[g][j]);
-                }
-            }
-            const bool fast = __ballot(checked) == 0ull;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const double lg = fast ? bin_log_fast(acc[g][j]) : bin_log(acc[g][j]);   // (wave-uniform choice)
-                    if (bin0 + j < a.B) sum[g] += lg;
-                }
-            }
-        } else if constexpr (MODE == 3) {
-            // value + gradient of the extended unbinned likelihood (blueice/likelihood.py:678-690): column 0 is the event's
-            // density lambda_e = sum_s mu_s p_s(x_e), columns 1.. its derivatives; d log(lambda) = d lambda / lambda.  An event
-            // that takes the outlier likelihood (lambda not > 0) is a constant: no slope.  -sum_s d mu_s is added by the host.
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                double lam = acc[0][j];
-                const bool clamped = a.outlier != 0.0 && !(lam > 0.0);
-                if (clamped) lam = a.outlier;
-                const double lg = bin_log(lam);
-                if (bin0 + j < a.B) {
-                    sum[0] += lg;
-                    const double inv = clamped ? 0.0 : 1.0 / lam;
-#pragma unroll
-                    for (int g = 1; g < G; ++g) sum[g] += acc[g][j] * inv;
-                }
-            }
-        } else if constexpr (MODE == 1) {
-            sum[0] += poisson_term(nv.x, acc[0][0]) + poisson_term(nv.y, acc[0][1]);
-            const double f0 = (nv.x != 0.0 ? nv.x / acc[0][0] : 0.0) - 1.0;
-            const double f1 = (nv.y != 0.0 ? nv.y / acc[0][1] : 0.0) - 1.0;
-#pragma unroll
-            for (int g = 1; g < G; ++g) sum[g] += f0 * acc[g][0] + f1 * acc[g][1];
-        } else if constexpr (!BB) {
-            // per bin column of the wave: no lane has counts -> no logarithm at all (the usual case with sparse data);
-            // every lane that needs one has a positive normal mu -> the branch-free form; else the checked form
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const double n = j ? nv.y : nv.x;
-                bool checked = false;
-#pragma unroll
-                for (int g = 0; g < G; ++g) checked |= needs_checked_term(n, acc[g][j]);
-                if (__ballot(n > 0.0) == 0ull) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sum[g] += poisson_term_nolog(n, acc[g][j]);
-                } else if (__ballot(checked) == 0ull) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sum[g] += poisson_term_fast(n, acc[g][j]);
-                } else {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sum[g] += poisson_term(n, acc[g][j]);
-                }
-            }
-        } else {
-            double pi[G][2], ai[G][2];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
-#pragma unroll 8
-            for (int k = 0; k < a.n1; ++k) {
-                const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    // (the reference's own order -- value = value + V * w, blueice/pdf_morphers.py:70 via scipy -- with
-                    // separate multiply and add: P_i and a feed the root formula, whose sign tests see last bits)
-                    const double c = coef[(a.n0 + k) * G + g];
-                    pi[g][0] = __dadd_rn(pi[g][0], __dmul_rn(v.x, c));
-                    pi[g][1] = __dadd_rn(pi[g][1], __dmul_rn(v.y, c));
-                }
-            }
-#pragma unroll 8
-            for (int k = 0; k < a.n2; ++k) {
-                const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const double c = coef[(a.n0 + a.n1 + k) * G + g];
-                    ai[g][0] = __dadd_rn(ai[g][0], __dmul_rn(v.x, c));
-                    ai[g][1] = __dadd_rn(ai[g][1], __dmul_rn(v.y, c));
-                }
-            }
-            const double* __restrict__ aux = aux_base;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const double p_cal = aux[g * 2 + 0];
-                const double Ntot = aux[g * 2 + 1];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (bin0 + j < a.B) {
-                        const double n = j ? nv.y : nv.x;
-                        const double U = acc[g][j];
-                        const double ab = ai[g][j];
-                        // likelihood.py:645-646
-                        const double w = pi[g][j] / ab * Ntot;
-                        double r1, r2;
-                        bb_roots(ab, w * p_cal, U, n, r1, r2);
-                        // likelihood.py:649 asserts root1 <= 0 -- evaluated here in the reference's own operation order.
-                        // (Where U_b == 0 that root is 0 analytically and its sign is decided by the last bit of the
-                        // inputs; see DESIGN.md section 2 for what that means for parity.)
-                        if (!(r1 <= 0.0)) flg[g] |= BI_ST_BB_ROOT1;
-                        const double A = (U == 0.0) ? (n + ab) / (1.0 + p_cal) : r2;
-                        if (!(0.0 <= A)) flg[g] |= BI_ST_BB_NEG;
-                        const double mu = U + (A * w) * p_cal;
-                        sum[g] += poisson_term(n, mu);
-                    }
-                }
-            }
-        }
-    }
-
-}
-
-// MODE 2: as MODE 0 for the extended unbinned likelihood (rows hold pdf values at the events).
-// MODE 3: as MODE 1 (value + gradient columns of ONE point) for the extended unbinned likelihood.
-// MODE 0: G parameter points of one cell.  MODE 1 (gradient): ONE point; column 0 of the coefficient matrix
-// gives mu, columns 1.. give d mu / d theta_j (theta = shape parameters, then rate scales), and the per-bin
-// chain rule d ll / d theta_j = (n / mu - 1) * d mu / d theta_j is reduced alongside the likelihood.
-template <int G, bool BB, bool NT, int MODE = 0>
-__global__ __launch_bounds__(kThreads) void k_morph_reduce(LaunchArgs a) {
-    const int item = blockIdx.y;
-    const int NS = a.n0 + a.n1 + a.n2;
-    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
-    const double* __restrict__ coef = a.coef + (int64_t)item * NS * G;
-    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
-    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
-
-    double sum[G];
-    unsigned flg[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { sum[g] = 0.0; flg[g] = 0u; }
-
-    morph_tiles<G, BB, NT, MODE>(a, rowoff, coef, a.aux + (int64_t)item * G * 2, cnt, n_tiles, (int)blockIdx.x, (int)gridDim.x, sum, flg);
-
-    __shared__ double s_sum[kThreads / 64][G];
-    __shared__ unsigned s_flg[kThreads / 64][G];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const double s = wave_sum(sum[g]);
-        const unsigned f = BB ? wave_or(flg[g]) : 0u;
-        if (lane == 0) { s_sum[wave][g] = s; s_flg[wave][g] = f; }
-    }
-    __syncthreads();
-    const bool fuse = a.fin_mail != nullptr;
-    const int nbx = gridDim.x;
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
-        double s = s_sum[0][g];
-        unsigned f = s_flg[0][g];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w][g]; f |= s_flg[w][g]; }
-        const int64_t o = ((int64_t)item * nbx + blockIdx.x) * G + g;
-        if (fuse) {
-            if (BB) flags_post(a.fin_flags + (int64_t)item * G + g, f);
-            mail_post_checked(a, a.fin_mail + o, s);
-        } else {
-            a.partial[o] = s;
-            a.pflags[o] = f;
-        }
-    }
-    if (!fuse || (int)blockIdx.x != nbx - 1) return;
-
-    // ---- the item's last block does what k_finish would do, in k_finish's summation order ----
-    const long long deadline = (long long)wall_clock64() + a.mail_timeout;
-    double* __restrict__ mail = a.fin_mail + (int64_t)item * nbx * G;
-    bool late = false;
-    if (nbx <= 64) {
-        // k_finish's 64-lane form: one wave per slot, lane b takes block b's partial
-        for (int g = wave; g < G; g += kThreads / 64) {
-            double s = lane < nbx ? mail_take(mail + (int64_t)lane * G + g, deadline, &late) : 0.0;
-            s = wave_sum(s);
-            const bool any_late = __ballot(late) != 0ull;
-            const int64_t p = a.fin_perm[(int64_t)item * G + g];
-            if (lane == 0) {
-                const unsigned f = (BB ? flags_take(a.fin_flags + (int64_t)item * G + g) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
-                if (p >= 0) {
-                    a.fin_out[p] = s - a.fin_slot_lg[(int64_t)item * G + g];
-                    if (a.fin_status) a.fin_status[p] |= (int32_t)f;
-                }
-            }
-        }
-        return;
-    }
-    // 256-lane form.  The item's slots are contiguous, [block][g]: thread t takes slots t, t + 256, ... -- always column
-    // g = t % G, since G divides 256 -- four loads in flight at a time, then the threads of a column are added in a fixed
-    // order (G = 1: k_finish's own order -- wave tree, then the four waves; G > 1: through LDS, thread by thread).
-    {
-        const int total = nbx * G;
-        double s = 0.0;
-        for (int q0 = threadIdx.x; q0 < total; q0 += 4 * kThreads) s = mail_take4(mail, q0, kThreads, total, s, deadline, &late);
-        __shared__ double s_part[kThreads];
-        __shared__ unsigned s_late[kThreads / 64];
-        const unsigned lt = __ballot(late) != 0ull ? 1u : 0u;
-        if constexpr (G == 1) s = wave_sum(s);
-        __syncthreads();                           // (s_sum / s_flg above are done with)
-        s_part[threadIdx.x] = s;
-        if (lane == 0) s_late[wave] = lt;
-        __syncthreads();
-        if (threadIdx.x < G) {
-            const int g = threadIdx.x;
-            double t = 0.0;
-            if constexpr (G == 1) {
-                t = s_part[0];
-#pragma unroll
-                for (int w = 1; w < kThreads / 64; ++w) t += s_part[w * 64];
-            } else {
-                for (int j = 0; j < kThreads / G; ++j) t += s_part[g + G * j];
-            }
-            unsigned any_late = 0u;
-#pragma unroll
-            for (int w = 0; w < kThreads / 64; ++w) any_late |= s_late[w];
-            const int64_t p = a.fin_perm[(int64_t)item * G + g];
-            const unsigned f = (BB ? flags_take(a.fin_flags + (int64_t)item * G + g) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
-            if (p >= 0) {
-                a.fin_out[p] = t - a.fin_slot_lg[(int64_t)item * G + g];
-                if (a.fin_status) a.fin_status[p] |= (int32_t)f;
-            }
-        }
-    }
-}
-
-// ---- value + analytic gradient with Beeston-Barlow (bi_eval_grad, bb_source >= 0) ----------------------------------
-// mu_b = U_b + A_b p_b with p_b = r_i P_b / a_b (likelihood.py:645-646: w p_cal = P/a N * r_i/N) and A_b the second root
-// of the per-bin quadratic (likelihood.py:706-708) -- or, where U_b == 0 exactly, the reference's special case
-// A_b = (n_b + a_b) / (1 + p_cal) with the SCALAR p_cal = r_i / N (likelihood.py:652-653).  Everything is smooth in
-// (U, P, a, r_i, N), and those are linear in the coefficient columns, so the chain rule runs per bin:
-//     d mu = dU + p dA + A dp,   dA = A_a da + A_p dp + A_U dU,   dp = (dr_i P + r_i dP) / a - p da / a.
-// Column 0 of the coefficient matrices gives the values (U, P, a), column q >= 1 their derivatives with respect to
-// parameter q: all G columns for the U streams, but only the first DZ = 1 + d (padded) for the P and a streams -- rate
-// scales do not move the Beeston-Barlow source's template or its Monte-Carlo counts -- which is what keeps the
-// accumulators in registers (C5: 11 + 5 + 5 column pairs instead of 3 x 11).  aux[q] = {d r_i, d N} for q >= 1,
-// aux[0] = {p_cal, N}.  The value column follows the value kernel's operation order, so ll equals bi_eval's.
-template <int G, int DZ, bool NT>
-__global__ __launch_bounds__(kThreads) void k_morph_bbgrad(LaunchArgs a) {
-    static_assert(DZ <= G, "shape columns are a prefix of all columns");
-    const int item = blockIdx.y;
-    const int NS = a.n0 + a.n1 + a.n2;
-    const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
-    // coefficient block of an item: [n0][G] for the U streams, then [n1][DZ] and [n2][DZ]
-    const int64_t coef_per_item = (int64_t)a.n0 * G + (int64_t)(a.n1 + a.n2) * DZ;
-    const double* __restrict__ cU = a.coef + (int64_t)item * coef_per_item;
-    const double* __restrict__ cP = cU + (int64_t)a.n0 * G;
-    const double* __restrict__ cA = cP + (int64_t)a.n1 * DZ;
-    const double* __restrict__ aux = a.aux + (int64_t)item * G * 2;
-    const double* __restrict__ cnt = a.counts + a.item_cnt[item];
-    const int n_tiles = a.item_tiles ? a.item_tiles[item] : a.n_tiles;
-    log_table_load();
-
-    double sum[G];
-    unsigned flg = 0u;
-#pragma unroll
-    for (int g = 0; g < G; ++g) sum[g] = 0.0;
-    const double p_cal = aux[0], Ntot = aux[1];
-    const double r_i = p_cal * Ntot;
-    const int chunks = (a.chunks > 1 && n_tiles >= 64 * a.chunks) ? a.chunks : 1;
-    const int per_chunk = (n_tiles + chunks - 1) / chunks;
-    for (int lt = blockIdx.x; lt < per_chunk * chunks; lt += gridDim.x) {
-        const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
-        if (tile >= n_tiles) continue;
-        const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        double acc[G][2], pi[DZ][2], ai[DZ][2];
-#pragma unroll
-        for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
-#pragma unroll
-        for (int g = 0; g < DZ; ++g) { pi[g][0] = pi[g][1] = ai[g][0] = ai[g][1] = 0.0; }
-#pragma unroll 4
-        for (int k = 0; k < a.n0; ++k) {
-            const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const double c = cU[k * G + g];
-                acc[g][0] = fma(c, v.x, acc[g][0]);
-                acc[g][1] = fma(c, v.y, acc[g][1]);
-            }
-        }
-#pragma unroll 4
-        for (int k = 0; k < a.n1; ++k) {
-            const double2 v = stream_load<NT>(a.ps + rowoff[a.n0 + k] + bin0);
-            // the value column as the value kernel forms it (separate multiply and add, the reference's corner order)
-            pi[0][0] = __dadd_rn(pi[0][0], __dmul_rn(v.x, cP[k * DZ]));
-            pi[0][1] = __dadd_rn(pi[0][1], __dmul_rn(v.y, cP[k * DZ]));
-#pragma unroll
-            for (int g = 1; g < DZ; ++g) {
-                const double c = cP[k * DZ + g];
-                pi[g][0] = fma(c, v.x, pi[g][0]);
-                pi[g][1] = fma(c, v.y, pi[g][1]);
-            }
-        }
-#pragma unroll 4
-        for (int k = 0; k < a.n2; ++k) {
-            const double2 v = stream_load<NT>(a.nm + rowoff[a.n0 + a.n1 + k] + bin0);
-            ai[0][0] = __dadd_rn(ai[0][0], __dmul_rn(v.x, cA[k * DZ]));
-            ai[0][1] = __dadd_rn(ai[0][1], __dmul_rn(v.y, cA[k * DZ]));
-#pragma unroll
-            for (int g = 1; g < DZ; ++g) {
-                const double c = cA[k * DZ + g];
-                ai[g][0] = fma(c, v.x, ai[g][0]);
-                ai[g][1] = fma(c, v.y, ai[g][1]);
-            }
-        }
-        const double2 nv = *reinterpret_cast<const double2*>(cnt + bin0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (bin0 + j >= a.B) continue;
-            const double n = j ? nv.y : nv.x;
-            const double U = acc[0][j], P = pi[0][j], ab = ai[0][j];
-            const double w = P / ab * Ntot;                    // likelihood.py:645-646
-            const double p = w * p_cal;
-            double r1, r2;
-            bb_roots(ab, p, U, n, r1, r2);
-            if (!(r1 <= 0.0)) flg |= BI_ST_BB_ROOT1;
-            const bool special = U == 0.0;
-            const double A = special ? (n + ab) / (1.0 + p_cal) : r2;
-            if (!(0.0 <= A)) flg |= BI_ST_BB_NEG;
-            const double mu = U + (A * w) * p_cal;
-            sum[0] += poisson_term(n, mu);
-            const double f = (n != 0.0 ? n / mu : 0.0) - 1.0;  // d term / d mu
-            const double inv_a = 1.0 / ab;
-            // partial derivatives of the second root
-            double A_a = 0.0, A_p = 0.0, A_U = 0.0;
-            const double t_sp = 1.0 / (1.0 + p_cal);
-            if (!special) {
-                const double p2 = p * p;
-                const double disc = U * U * p2 + 2 * U * U * p + U * U + 2 * U * ab * p2 + 2 * U * ab * p - 2 * U * n * p2 -
-                                    2 * U * n * p + ab * ab * p2 + 2 * ab * n * p2 + n * n * p2;
-                const double inv_2sq = 0.5 / sqrt(disc);
-                const double inv_den = 1.0 / (2 * p * (p + 1));
-                const double D_a = 2 * U * p2 + 2 * U * p + 2 * ab * p2 + 2 * n * p2;
-                const double D_p = 2 * U * U * p + 2 * U * U + 4 * U * ab * p + 2 * U * ab - 4 * U * n * p - 2 * U * n +
-                                   2 * ab * ab * p + 4 * ab * n * p + 2 * n * n * p;
-                const double D_U = 2 * U * p2 + 4 * U * p + 2 * U + 2 * ab * p2 + 2 * ab * p - 2 * n * p2 - 2 * n * p;
-                A_a = (p + D_a * inv_2sq) * inv_den;
-                A_U = (-p - 1.0 + D_U * inv_2sq) * inv_den;
-                A_p = (-U + ab + n + D_p * inv_2sq) * inv_den - A * (4 * p + 2) * inv_den;
-            }
-#pragma unroll
-            for (int g = 1; g < G; ++g) {
-                const double dU = acc[g][j];
-                const double dr = aux[g * 2 + 0];
-                double dP = 0.0, da = 0.0;
-                if (g < DZ) { dP = pi[g][j]; da = ai[g][j]; }
-                const double dp = (dr * P + r_i * dP) * inv_a - p * da * inv_a;
-                double dmu;
-                if (!special) {
-                    const double dA = A_a * da + A_p * dp + A_U * dU;
-                    dmu = dU + p * dA + A * dp;
-                } else {
-                    const double dpc = (dr - p_cal * aux[g * 2 + 1]) / Ntot;
-                    dmu = dp * (n + ab) * t_sp + p * da * t_sp - p * (n + ab) * t_sp * t_sp * dpc;
-                }
-                sum[g] += f * dmu;
-            }
-        }
-    }
-
-    __shared__ double s_sum[kThreads / 64][G];
-    __shared__ unsigned s_flg[kThreads / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const double s = wave_sum(sum[g]);
-        if (lane == 0) s_sum[wave][g] = s;
-    }
-    {
-        const unsigned f = wave_or(flg);
-        if (lane == 0) s_flg[wave] = f;
-    }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
-        double s = s_sum[0][g];
-        unsigned f = s_flg[0];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w][g]; f |= s_flg[w]; }
-        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * G + g;
-        a.partial[o] = s;
-        a.pflags[o] = g == 0 ? f : 0u;
-    }
-}
-
-// ---- the single-point kernel: ONE launch from templates to scalar --------------------------------
-// The call shape of `lf(**kwargs)` inside a minimizer.  The point's stream descriptors (row offsets and
-// coefficients, <= kMaxSingleStreams of them) travel in the kernel-argument block, so the scalar loads hit the
-// kernarg segment and no host-to-device copy precedes the launch; and the reduction is finished inside the
-// launch: every block posts its partial into a mailbox slot and leaves, the last block in dispatch order collects
-// them in block order (fixed order => bitwise reproducible; see mail_post) and writes {ll, status} straight into
-// pinned host memory.
-constexpr int kMaxSingleStreams = 128;
-
-struct SingleDesc {
-    int64_t rowoff[kMaxSingleStreams];
-    double coef[kMaxSingleStreams];
-    double aux[2];        // Beeston-Barlow: p_cal, N
-    double slot_lg;       // constant subtracted from the sum (sum lgamma, empty-bin term, or sum of rates)
-    unsigned* flags;      // one status word (Beeston-Barlow bits), zero on entry and on exit
-    double* out;          // pinned host
-    int32_t* status;      // pinned host
-    unsigned long long* done;   // pinned host: receives `seq` after out / status (the host polls it)
-    unsigned long long seq;
-};
-
-template <bool BB, bool NT, int MODE, bool FUSE>
-__global__ __launch_bounds__(kThreads) void k_morph_single(LaunchArgs a, SingleDesc d) {
-    double sum[1] = {0.0};
-    unsigned flg[1] = {0u};
-    morph_tiles<1, BB, NT, MODE>(a, d.rowoff, d.coef, d.aux, a.counts, a.n_tiles, (int)blockIdx.x, (int)gridDim.x, sum, flg);
-
-    __shared__ double s_sum[kThreads / 64];
-    __shared__ unsigned s_flg[kThreads / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        const double s = wave_sum(sum[0]);
-        const unsigned f = BB ? wave_or(flg[0]) : 0u;
-        if (lane == 0) { s_sum[wave] = s; s_flg[wave] = f; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = s_sum[0];
-        unsigned f = s_flg[0];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { s += s_sum[w]; f |= s_flg[w]; }
-        if constexpr (FUSE) {          // post into the mailbox and leave: the last block collects (see mail_post)
-            if (BB) flags_post(d.flags, f);
-            mail_post_checked(a, a.partial + blockIdx.x, s);
-        } else {                       // a second, tiny launch sums the partials (k_finish_single)
-            a.partial[blockIdx.x] = s;
-            a.pflags[blockIdx.x] = f;
-        }
-    }
-    if constexpr (!FUSE) return;
-    if (blockIdx.x != gridDim.x - 1) return;
-    // the last block in dispatch order: collect the partials of all blocks in block order
-    const long long deadline = (long long)wall_clock64() + a.mail_timeout;
-    bool late = false;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 4 * kThreads) s = mail_take4(a.partial, b, kThreads, (int)gridDim.x, s, deadline, &late);
-    s = wave_sum(s);
-    const unsigned lt = __ballot(late) != 0ull ? 1u : 0u;
-    __syncthreads();   // s_sum / s_flg are reused
-    if (lane == 0) { s_sum[wave] = s; s_flg[wave] = lt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = s_sum[0];
-        unsigned any_late = s_flg[0];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) { t += s_sum[w]; any_late |= s_flg[w]; }
-        const unsigned ff = (BB ? flags_take(d.flags) : 0u) | (any_late ? (unsigned)BI_ST_INTERNAL : 0u);
-        *d.out = t - d.slot_lg;
-        *d.status = (int32_t)ff;
-        __hip_atomic_store(d.done, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // second launch of the single-point path when the grid is too large for in-launch finishing to pay
@@ -2357,224 +1536,6 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish_tiled(const double*
     }
 }
 
-}  // namespace
-
-namespace {
-
-// ---- the scan kernel: many points per grid cell, fp64 matrix cores ---------------------------------------
-// For a batch whose points pile up in few grid cells (likelihood scans), mu[point][bin] = sum_k coef[point][k] *
-// row[k][bin] is a [points x streams] x [streams x bins] product.  One wave owns a strip of 16 CB bins of the cell's
-// 2^d*S template rows, holds it in registers in v_mfma_f64_16x16x4 operand layout (k = lane >> 4,
-// bin = lane & 15; loaded once, every 128-byte cache line fully used) and loops over ALL 16-point work items of
-// the cell: per item KG coalesced coefficient loads (coef[k][point], point = lane & 15) and, for the CB 16-bin blocks
-// of the strip, KG MFMAs each, then the Poisson epilogue of the block.  Two cross-row exchanges leave the 16
-// per-point sums in the first 16 lanes, which add them (no-return fp64 atomics) into a partial slot that only this
-// wave ever touches, so the result is deterministic.
-// Bound: 78.6 TFLOP/s fp64 matrix peak / (2 * 2^d*S * B flop per evaluation) = 1.2 M evaluations/s at C2 for the
-// FMA work alone; fp64 MFMA and fp64 VALU share the same units on this chip (measured: tools/micro/
-// mfma_valu_overlap.hip), so the epilogue's logarithms add to that rather than hide under it.
-// Plain binned likelihood, up to 32 streams (K <= 32); everything else takes k_morph_reduce.
-typedef double bi_double4 __attribute__((ext_vector_type(4)));
-
-struct ScanArgs {
-    const double* ps;
-    const double* counts;
-    const int64_t* rowoff;      // [items][NS]   (rows of a group = rows of its first item)
-    const double* coef;         // [items][NS][16]
-    const int64_t* item_cnt;    // [items]
-    const int32_t* item_tiles;  // [items] 512-bin tiles of the item's rows
-    const int64_t* grp_first;   // [groups] first item of the group
-    const int32_t* grp_items;   // [groups] items in the group
-    double* partial;            // [items][nslots][16], zero on entry
-    int NS;
-    int nslots;                 // waves per group = gridDim.x * 4
-    int n_groups;               // k_scan_sorted (one-dimensional grid, dealt to the XCDs in contiguous ranges of blocks)
-    int xcd_mode;               // 0 launch order, 1 contiguous ranges (default), 2 group g -> XCD g mod 8
-    int share_slow;             // k_scan_sorted: strips of mixed counts are worked by all waves of the cell together
-};
-
-// sum of a double over the 4 DPP rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): one half-row exchange and one half-wave
-// exchange (v_permlane16_swap / v_permlane32_swap, gfx950), every lane ends up with the total
-__device__ __forceinline__ double rows4_sum(double v) {
-#define BI_SWAP_ADD(SWAP)                                                                                          \
-    do {                                                                                                           \
-        const unsigned long long u = __double_as_longlong(v);                                                      \
-        const auto lo = SWAP((unsigned)u, (unsigned)u, false, false);                                              \
-        const auto hi = SWAP((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);                              \
-        v = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) +                                      \
-            __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);                                       \
-    } while (0)
-    BI_SWAP_ADD(__builtin_amdgcn_permlane16_swap);
-    BI_SWAP_ADD(__builtin_amdgcn_permlane32_swap);
-#undef BI_SWAP_ADD
-    return v;
-}
-
-// CB: 16-bin blocks per strip (strip = CB * 16 bins).  KG: groups of 4 streams (4 KG >= NS).  MASK: NS < 4 KG,
-// the coefficient operands of the padding streams must be zeroed.
-// Operand roles: the template strip is the MFMA's A operand (row i = bin = lane & 15, k = lane >> 4), the coefficients
-// its B operand (k = lane >> 4, column j = point = lane & 15), so lane (kq, col) receives mu[bin = 4 r + kq][point = col]
-// in accumulator element r: ALL FOUR elements of a lane belong to ONE point.  The per-point sum therefore needs three
-// in-lane additions and two cross-row exchanges per item (rows4_sum: ~10 vector instructions) -- with the operands the
-// other way round (bins along the lanes of a row) it took four 16-lane rotations per accumulator element, ~60
-// instructions per item, a fifth of the kernel's vector work when every bin has data.
-// PROD = 1: the rows are the compacted non-empty bins of sparse data -- blocks whose counts are all 1 or 2 take one logarithm of
-// the product mu^n over a lane's four bins (a separate instantiation, so that the dense-data kernel keeps its code).
-// (Rows ordered by their count -- dense data, or the count-sorted compacted copy -- are k_scan_sorted's, bi_scan_sorted.h.)
-// MASK: the ROWS of the padding streams are zeroed once per strip; their coefficient reads are steered to a valid element
-// of the item's last stream group (one select on a scalar condition per group, no per-group offset registers).
-template <int CB, int KG, bool MASK, int PROD = 0>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 2 ? 3 : 2))) void k_scan_mfma(ScanArgs a) {
-    constexpr int STRIP = CB * 16;
-    const int grp = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int slot = blockIdx.x * 4 + wave;
-    const int64_t item0 = a.grp_first[grp];
-    const int n_items = a.grp_items[grp];
-    const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
-    const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
-    const int n_strips = a.item_tiles[item0] * (kTile / STRIP);
-    // (the group's row offsets: in LDS, read again for every strip -- as loop invariants they would hold 2 KG registers)
-    __shared__ int64_t s_rowoff[4 * KG];
-    if (threadIdx.x < 4 * KG) s_rowoff[threadIdx.x] = rowoff[min((int)threadIdx.x, a.NS - 1)];
-    log_table_load();
-    const int kq = lane >> 4, col = lane & 15;
-    const int aoff0 = min(kq, a.NS - 1) * 16 + col;          // coefficient of K group kg sits at aoff0 + kg * 64 ...
-    const int kg_last = (a.NS - 1) >> 2;                     // ... up to the group that holds stream NS - 1: from there on
-    const int alast = min(kg_last * 4 + kq, a.NS - 1) * 16 + col;   // the lane reads this (valid) element instead
-#define BI_COEF_AT(kg) ((MASK && (kg) >= kg_last) ? alast : aoff0 + (kg) * 64)
-
-    for (int strip = slot; strip < n_strips; strip += a.nslots) {
-        const int64_t bin0 = (int64_t)strip * STRIP;
-        double b[KG][CB], n[CB][4];
-        int kqo = kq;
-        asm volatile("" : "+v"(kqo));           // (opaque: keeps the LDS reads inside the strip loop)
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const int64_t row = s_rowoff[kg * 4 + kqo];               // streams beyond NS: a valid row, zeroed
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                const double v = a.ps[row + bin0 + cb * 16 + col];
-                b[kg][cb] = (MASK && kg * 4 + kq >= a.NS) ? 0.0 : v;
-            }
-        }
-        // Everything about the counts is known per bin, once per strip: kind 0 = empty bin (term -mu),
-        // 1 = n > 0 (adds n log mu), 2 = negative / non-integer n (-inf), 3 = nan n (nan); scipy's poisson.logpmf
-        // (the four kinds of a lane's bins packed into one register, 2 bits each: registers decide the occupancy here)
-        int kinds[CB];
-        bool special[CB], alldata[CB], ones_twos[CB];
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            kinds[cb] = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = cnt[bin0 + cb * 16 + 4 * r + kq];
-                n[cb][r] = v;
-                kinds[cb] |= ((v != v) ? 3 : ((v < 0.0 || v != floor(v)) ? 2 : (v > 0.0 ? 1 : 0))) << (2 * r);
-            }
-            special[cb] = __ballot(kinds[cb] != 0) != 0ull;       // wave-uniform: does any bin of this block need more
-            alldata[cb] = __ballot(kinds[cb] == 0x55) == ~0ull;   // ... every bin holds a count > 0: the logarithm alone decides
-            // ... and every count is 1 or 2 (the non-empty bins of sparse data): sum n log mu = log prod mu^n, and the four
-            // bins of a lane belong to one point, so four logarithms become five multiplications and one logarithm.  The
-            // factors are positive normal numbers (checked per item); a product that leaves that range takes the bin-wise form.
-            bool small = true;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) small &= n[cb][r] == 1.0 || n[cb][r] == 2.0;
-            ones_twos[cb] = PROD == 1 && __ballot(small) == ~0ull;
-        }
-#define BI_KIND(cb, r) ((kinds[cb] >> (2 * (r))) & 3)
-
-        // coefficient operands: coef[k][point]; streams beyond NS read a valid element (their rows are zero)
-        double av[KG];
-        {
-            const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = coef[BI_COEF_AT(kg)];
-        }
-        // (the item's coefficient block and its partial slot advance by fixed steps: pointers, not products per item)
-        const double* __restrict__ coef_next = a.coef + item0 * a.NS * 16;
-        double* __restrict__ dst = a.partial + (item0 * a.nslots + slot) * 16 + col;
-        const int64_t coef_step = (int64_t)a.NS * 16, dst_step = (int64_t)a.nslots * 16;
-        for (int it = 0; it < n_items; ++it) {
-            if (it + 1 < n_items) coef_next += coef_step;
-            double s[4] = {0.0, 0.0, 0.0, 0.0};      // four chains, one point
-            double mn = 0.0;                          // running minimum of mu: a negative expectation makes the result nan
-            bi_double4 acc[CB];
-            // all chains first (no vector instruction executes beside an fp64 MFMA anyway), then the next item's
-            // coefficients are requested straight into the registers the chains have just read -- they arrive under the
-            // epilogues, and there is neither a second register set nor a rotation
-#define BI_CHAIN(cb)                                                                                               \
-    do {                                                                                                           \
-        acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
-        _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
-            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[kg][cb], av[kg], acc[cb], 0, 0, 0);                   \
-    } while (0)
-    /* (the linear part, -sum_b mu_b = -sum_k coef_k * rowsum_k, is in the per-point constant: k_plan_fill, linear_outside) */ \
-#define BI_EPILOGUE(cb)                                                                                            \
-    do {                                                                                                           \
-        if (alldata[cb]) { /* dense data: n log mu in every bin; mu <= 0 / nan comes out of the checked logarithm */ \
-            if (PROD == 1 && ones_twos[cb]) { /* (wave-uniform) product form */                                    \
-                bool low = false;                                                                                  \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) low |= !(acc[cb][r] > kProdFloor);                   \
-                if (__ballot(low) == 0ull) {                                                                       \
-                    /* counts of 1 and 2 only: ONE logarithm of the product of mu^n.  At most eight factors above  */ \
-                    /* kProdFloor: no partial product can be subnormal, one that overflows stays +inf to the end   */ \
-                    double f[4];                                                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
-                        f[r] = (PROD == 1 && n[cb][r] == 2.0) ? acc[cb][r] * acc[cb][r] : acc[cb][r];              \
-                    const double prod = (f[0] * f[1]) * (f[2] * f[3]);                                             \
-                    if (__ballot(!pos_normal(prod)) == 0ull) {                                                     \
-                        s[cb & 3] += bin_log_fast(prod);                                                           \
-                        break;                                                                                     \
-                    }                                                                                              \
-                }                                                                                                  \
-            }                                                                                                      \
-            bool checked = false;                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= !pos_normal(acc[cb][r]);                      \
-            if (__ballot(checked) == 0ull) {                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] = fma(n[cb][r], bin_log_fast(acc[cb][r]), s[r]); \
-            } else {                                                                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) s[r] += n[cb][r] * bin_log(acc[cb][r]);              \
-            }                                                                                                      \
-            break;                                                                                                 \
-        }                                                                                                          \
-        mn = fmin(mn, fmin(fmin(acc[cb][0], acc[cb][1]), fmin(acc[cb][2], acc[cb][3])));                           \
-        if (special[cb]) {                                                                                         \
-            bool checked = false;                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) checked |= BI_KIND(cb, r) == 1 && !pos_normal(acc[cb][r]);  \
-            if (__ballot(checked) == 0ull) {                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                    \
-                    const double lg = bin_log_fast(acc[cb][r]);                                                    \
-                    if (BI_KIND(cb, r) == 1) s[r] += n[cb][r] * lg;                                                   \
-                }                                                                                                  \
-            } else {                                                                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
-                    if (BI_KIND(cb, r) == 1) s[r] += n[cb][r] * bin_log(acc[cb][r]);                                  \
-            }                                                                                                      \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-                if (BI_KIND(cb, r) > 1) s[r] += BI_KIND(cb, r) == 2 ? -__builtin_inf() : __builtin_nan("");              \
-        }                                                                                                          \
-    } while (0)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) BI_CHAIN(cb);
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) av[kg] = coef_next[BI_COEF_AT(kg)];
-            double tot = 0.0;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) BI_EPILOGUE(cb);
-            tot = (s[0] + s[1]) + (s[2] + s[3]);
-            if (mn < 0.0) tot = __builtin_nan("");
-#undef BI_CHAIN
-#undef BI_EPILOGUE
-#undef BI_KIND
-            tot = rows4_sum(tot);                     // over the four DPP rows: the 16 bins of the block are spread 4 r + kq
-            if (kq == 0) unsafeAtomicAdd(dst, tot);
-            dst += dst_step;
-        }
-    }
-#undef BI_COEF_AT
-}
-
 // The finish of a scan plan: partial is [items][nslots][16] (point fastest), one wave per item.  Lane l takes point
 // l & 15 and the slots l >> 4, l >> 4 + 4, ...: every load instruction of the wave covers 64 consecutive doubles (k_finish
 // walks the same array with one 8-byte element per 128-byte line and took 1.3 ms for the 640 MB of a 10^6-point scan;
@@ -2593,115 +1554,6 @@ __global__ __launch_bounds__(kThreads) void k_finish_scan(const double* __restri
     if (lane < 16) {
         const int64_t p = perm[item * 16 + g];
         if (p >= 0) out[p] = s - slot_lg[item * 16 + g];
-    }
-}
-
-// ---- the validity pass of a dense scan over sparse data -----------------------------------------------------
-// "Every bin visited" with mostly empty data splits into two passes (plan->valid, bi_planning_device.h):
-//   (A) the bins WITH data, on the compacted rows: n log mu - mu for those bins, and the linear remainder
-//       -sum_{empty b} mu_b = -sum_k coef_k * (row total over the empty bins) from tables -- the non-empty-bin form;
-//   (B) this kernel, over ALL bins: mu[point][bin] on the fp64 matrix cores exactly as in k_scan_mfma, and the one
-//       thing an empty bin can still do to the result -- scipy's poisson.logpmf is nan where mu is negative or nan
-//       (blueice/likelihood.py:674), whatever n is.  So the epilogue is one compare per matrix element, no logarithm,
-//       no running sums, no cross-lane reduction; a point with any such bin is flagged and set to nan afterwards.
-// With non-negative templates and rates (B) can never fire (that is why (A) alone is the default path); it is what makes
-// the split exact for templates or rates of either sign.  Per 16-point item and 64-bin strip: 32 MFMAs (2048 cycles of
-// the SIMD's fp64 pipe) + 16 v_cmp -- against ~240 vector instructions in k_scan_mfma, which matter because on this
-// chip NO vector instruction executes beside an fp64 MFMA (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_scan_pmc.json).
-struct ValidArgs {
-    const double* ps;
-    const int64_t* rowoff;      // [items][NS] element offsets of the FULL rows (rows of a group = rows of its first item)
-    const double* coef;         // [items][NS][16]
-    const int64_t* grp_first;   // [groups]
-    const int32_t* grp_items;   // [groups]
-    unsigned* bad;              // [items][16], zero on entry: set to 1 where a point has a bin with mu < 0 or nan
-    int NS;
-    int nslots;                 // waves per group = gridDim.x * 4
-    int n_strips;               // strips of 16 CB bins per full row
-};
-
-template <int CB, int KG, bool MASK>
-__global__ __launch_bounds__(kThreads) void k_scan_valid(ValidArgs a) {
-    constexpr int STRIP = CB * 16;
-    const int grp = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int slot = blockIdx.x * 4 + wave;
-    const int64_t item0 = a.grp_first[grp];
-    const int n_items = a.grp_items[grp];
-    const int64_t* __restrict__ rowoff = a.rowoff + item0 * a.NS;
-    const int kq = lane >> 4, col = lane & 15;
-    const int aoff0 = min(kq, a.NS - 1) * 16 + col;
-
-    for (int strip = slot; strip < a.n_strips; strip += a.nslots) {
-        const int64_t bin0 = (int64_t)strip * STRIP + col;
-        double b[KG][CB];
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const int64_t row = rowoff[min(kg * 4 + kq, a.NS - 1)];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[kg][cb] = a.ps[row + bin0 + cb * 16];
-        }
-        double av[KG];
-        {
-            const double* __restrict__ coef = a.coef + item0 * a.NS * 16;
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = kg * 4 + kq;
-                av[kg] = coef[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) av[kg] = 0.0;
-            }
-        }
-        // The next item's coefficients are requested behind the first chain and arrive under the others; two copies of the
-        // item body alternate the two register sets (no rotation), and the coefficient block / flag words advance as pointers.
-        double an[KG];
-        const double* __restrict__ coef_next = a.coef + item0 * a.NS * 16;
-        unsigned* __restrict__ bad = a.bad + item0 * 16 + kq;
-        const int64_t coef_step = (int64_t)a.NS * 16;
-        auto item = [&](double (&cur)[KG], double (&nxt)[KG], bool more) __attribute__((always_inline)) {
-            if (more) coef_next += coef_step;
-            bi_double4 acc[CB];
-            unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};      // per r: lanes whose element is not >= 0
-#define BI_VCHAIN(cb)                                                                                              \
-    do {                                                                                                           \
-        acc[cb] = bi_double4{0.0, 0.0, 0.0, 0.0};                                                                  \
-        _Pragma("unroll") for (int kg = 0; kg < KG; ++kg)                                                          \
-            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[kg], b[kg][cb], acc[cb], 0, 0, 0);                  \
-    } while (0)
-#define BI_VCHECK(cb)                                                                                              \
-    do {                                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) m[r] |= __ballot(!(acc[cb][r] >= 0.0));                      \
-    } while (0)
-            BI_VCHAIN(0);
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = kg * 4 + kq;
-                nxt[kg] = coef_next[MASK ? min(k, a.NS - 1) * 16 + col : aoff0 + kg * 64];
-                if (MASK && k >= a.NS) nxt[kg] = 0.0;
-            }
-#pragma unroll
-            for (int cb = 1; cb < CB; ++cb) {
-                BI_VCHAIN(cb);
-                BI_VCHECK(cb - 1);
-            }
-            BI_VCHECK(CB - 1);
-#undef BI_VCHAIN
-#undef BI_VCHECK
-            if ((m[0] | m[1] | m[2] | m[3]) != 0ull) {         // rare (never with templates and rates >= 0)
-                // element r of lane (kq, col) belongs to point kq + 4 r; lane 16 kq speaks for its row of 16 bins
-                if (col == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((m[r] >> (16 * kq)) & 0xFFFFull) atomicOr(bad + 4 * r, 1u);
-                }
-            }
-            bad += 16;
-        };
-        int it = 0;
-        for (; it + 1 < n_items; it += 2) {
-            item(av, an, true);
-            item(an, av, it + 2 < n_items);
-        }
-        if (it < n_items) item(av, an, false);
     }
 }
 

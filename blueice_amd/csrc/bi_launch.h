@@ -1,88 +1,8 @@
-// bi_launch.h -- kernel launch dispatch (template instantiation tables), HIP-event scopes, state checks.
+// bi_launch.h -- mailbox set-up of in-launch finishing and state checks (main translation unit).  The instantiation tables of
+// the heavy kernel families are in tu_*.hip, declared in bi_common.h.
 #pragma once
 
 namespace {
-
-struct EventScope {
-    bi_ctx* c;
-    size_t idx = (size_t)-1;
-    explicit EventScope(bi_ctx* ctx) : c(ctx) {
-        if (!c->profiling) return;
-        if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            c->ev_pool.emplace_back(a, b);
-        }
-        idx = c->ev_used++;
-        (void)hipEventRecord(c->ev_pool[idx].first, c->stream);
-    }
-    ~EventScope() {
-        if (idx != (size_t)-1) (void)hipEventRecord(c->ev_pool[idx].second, c->stream);
-    }
-};
-
-template <int G>
-void launch_morph(bi_ctx* c, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
-    if (c->unbinned) {
-        if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true, 2>), grid, dim3(kThreads), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_morph_reduce<G, false, false, 2>), grid, dim3(kThreads), 0, c->stream, a);
-        return;
-    }
-    if (bb && nt) hipLaunchKernelGGL((k_morph_reduce<G, true, true>), grid, dim3(kThreads), 0, c->stream, a);
-    else if (bb) hipLaunchKernelGGL((k_morph_reduce<G, true, false>), grid, dim3(kThreads), 0, c->stream, a);
-    else if (nt) hipLaunchKernelGGL((k_morph_reduce<G, false, true>), grid, dim3(kThreads), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_morph_reduce<G, false, false>), grid, dim3(kThreads), 0, c->stream, a);
-}
-
-void launch_morph_grad(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool nt) {
-    EventScope ev(c);
-#define BI_GRAD_CASE(GG)                                                                                          \
-    case GG:                                                                                                      \
-        if (c->unbinned) {                                                                                        \
-            if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 3>), grid, dim3(kThreads), 0, c->stream, a); \
-            else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 3>), grid, dim3(kThreads), 0, c->stream, a); \
-        } else if (nt) hipLaunchKernelGGL((k_morph_reduce<GG, false, true, 1>), grid, dim3(kThreads), 0, c->stream, a); \
-        else hipLaunchKernelGGL((k_morph_reduce<GG, false, false, 1>), grid, dim3(kThreads), 0, c->stream, a);   \
-        break;
-    switch (G) {
-        BI_GRAD_CASE(2)
-        BI_GRAD_CASE(4)
-        BI_GRAD_CASE(8)
-        default:
-            BI_GRAD_CASE(16)
-    }
-#undef BI_GRAD_CASE
-}
-
-// value + gradient with Beeston-Barlow: G columns in all (padded 1 + d + S), DZ of them (padded 1 + d) for the P / a streams
-int launch_morph_bbgrad(bi_ctx* c, int G, int DZ, const LaunchArgs& a, dim3 grid, bool nt) {
-    EventScope ev(c);
-#define BI_BBG(GG, ZZ)                                                                                             \
-    do {                                                                                                            \
-        if (nt) hipLaunchKernelGGL((k_morph_bbgrad<GG, ZZ, true>), grid, dim3(kThreads), 0, c->stream, a);          \
-        else hipLaunchKernelGGL((k_morph_bbgrad<GG, ZZ, false>), grid, dim3(kThreads), 0, c->stream, a);            \
-    } while (0)
-    if (G == 8 && DZ == 4) BI_BBG(8, 4);
-    else if (G == 8 && DZ == 8) BI_BBG(8, 8);
-    else if (G == 16 && DZ == 4) BI_BBG(16, 4);
-    else if (G == 16 && DZ == 8) BI_BBG(16, 8);
-    else return BI_ERR_INVALID;
-#undef BI_BBG
-    return BI_OK;
-}
-
-// nt: the launch streams its template rows exactly once (no two items touch the same anchor), so the loads
-// carry the nontemporal hint: +8 % HBM rate on gfx950; with shared rows the default policy (L2 / MALL) wins.
-void launch_morph_g(bi_ctx* c, int G, const LaunchArgs& a, dim3 grid, bool bb, bool nt) {
-    EventScope ev(c);
-    switch (G) {
-        case 1: launch_morph<1>(c, a, grid, bb, nt); break;
-        case 2: launch_morph<2>(c, a, grid, bb, nt); break;
-        case 4: launch_morph<4>(c, a, grid, bb, nt); break;
-        case 8: launch_morph<8>(c, a, grid, bb, nt); break;
-        default: launch_morph<16>(c, a, grid, bb, nt); break;
-    }
-}
 
 // the mailbox of in-launch finishing: allocated and emptied once (every collector leaves its slots empty again)
 constexpr int64_t kMailSlots = (int64_t)1 << 20;       // 8 MB

@@ -6,8 +6,6 @@
 // (Beeston-Barlow batches are planned on the host).
 #pragma once
 
-#include <rocprim/rocprim.hpp>
-
 namespace {
 
 // Blocks of a matrix-core scan kernel variant that one CU holds at a time (registers decide it), asked from the runtime
@@ -19,14 +17,8 @@ int scan_resident_blocks(bool valid, int cb, int NS, bool by_count = false) {
         std::atomic<int>& slot = sorted_cache[KG - 1][mask];
         int v = slot.load();
         if (v > 0) return v;
-        const void* f = nullptr;
-        switch ((KG - 1) * 2 + mask) {
-#define BI_CASE(K) case ((K) - 1) * 2: f = (const void*)k_scan_sorted<K, false>; break; case ((K) - 1) * 2 + 1: f = (const void*)k_scan_sorted<K, true>; break;
-            BI_CASE(1) BI_CASE(2) BI_CASE(3) BI_CASE(4) BI_CASE(5) BI_CASE(6) BI_CASE(7) BI_CASE(8)
-#undef BI_CASE
-        }
-        int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, kThreads, 0) != hipSuccess || blocks < 1) blocks = 2;
+        int blocks = occupancy_scan_sorted(KG, mask != 0);
+        if (blocks < 1) blocks = 2;
         slot.store(blocks);
         return blocks;
     }
@@ -36,26 +28,8 @@ int scan_resident_blocks(bool valid, int cb, int NS, bool by_count = false) {
     std::atomic<int>& slot = cache[valid ? 1 : 0][cb == 2 ? 0 : 1][kg][mask];
     int v = slot.load();
     if (v > 0) return v;
-    const void* f = nullptr;
-#define BI_PICK(KERNEL, CB)                                                                                        \
-    do {                                                                                                           \
-        switch (kg * 2 + mask) {                                                                                   \
-            case 0: f = (const void*)KERNEL<CB, 1, false>; break;                                                  \
-            case 1: f = (const void*)KERNEL<CB, 1, true>; break;                                                   \
-            case 2: f = (const void*)KERNEL<CB, 2, false>; break;                                                  \
-            case 3: f = (const void*)KERNEL<CB, 2, true>; break;                                                   \
-            case 4: f = (const void*)KERNEL<CB, 4, false>; break;                                                  \
-            case 5: f = (const void*)KERNEL<CB, 4, true>; break;                                                   \
-            case 6: f = (const void*)KERNEL<CB, 8, false>; break;                                                  \
-            default: f = (const void*)KERNEL<CB, 8, true>; break;                                                  \
-        }                                                                                                          \
-    } while (0)
-    if (valid) BI_PICK(k_scan_valid, 4);
-    else if (cb == 2) BI_PICK(k_scan_mfma, 2);
-    else BI_PICK(k_scan_mfma, 4);
-#undef BI_PICK
-    int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, kThreads, 0) != hipSuccess || blocks < 1) blocks = 2;
+    int blocks = occupancy_scan(valid, cb, kg, mask != 0);
+    if (blocks < 1) blocks = 2;
     slot.store(blocks);
     return blocks;
 }
@@ -80,7 +54,7 @@ bool ensure_sorted_rows(bi_ctx* c) {
     DevBuf d_iota, d_perm, d_tmp;
     auto drop = [&]() { dev_free(d_iota); dev_free(d_perm); dev_free(d_tmp); };
     size_t tmp_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+    (void)prim_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                                     (size_t)B, 0u, 64u, c->stream);
     if (dev_alloc(c, c->ps_sorted, (size_t)rows * Bp * sizeof(double)) || dev_alloc(c, c->cnt_sorted, (size_t)Bp * sizeof(double)) ||
         dev_alloc(c, d_iota, (size_t)B * sizeof(int32_t)) || dev_alloc(c, d_perm, (size_t)B * sizeof(int32_t)) ||
@@ -92,7 +66,7 @@ bool ensure_sorted_rows(bi_ctx* c) {
     hipLaunchKernelGGL(k_iota32, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, (int32_t*)d_iota.p, B);
     hipError_t e = hipMemsetAsync(c->cnt_sorted.p, 0, (size_t)Bp * sizeof(double), c->stream);
     size_t tb = d_tmp.bytes;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const double*)c->counts.p, (double*)c->cnt_sorted.p, (const int32_t*)d_iota.p,
+    if (e == hipSuccess) e = prim_sort_pairs(d_tmp.p, tb, (const double*)c->counts.p, (double*)c->cnt_sorted.p, (const int32_t*)d_iota.p,
                                                        (int32_t*)d_perm.p, (size_t)B, 0u, 64u, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((Bp + kThreads - 1) / kThreads), (unsigned)rows), dim3(kThreads), 0, c->stream,
@@ -697,14 +671,14 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     // sort (key, point) pairs: keys are cell * T + dataset, rejected points carry the largest key
     size_t tmp_bytes = 0;
     int end_bit = 64;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+    (void)prim_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                     (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     size_t scan_bytes = 0, scan_bytes2 = 0;
-    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, rocprim::maximum<int64_t>(), c->stream);
-    (void)rocprim::inclusive_scan(nullptr, scan_bytes2, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, rocprim::plus<int64_t>(), c->stream);
+    (void)prim_inclusive_scan_max(nullptr, scan_bytes, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, c->stream);
+    (void)prim_inclusive_scan_sum(nullptr, scan_bytes2, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, c->stream);
     if ((rc = dev_alloc(c, d_tmp, std::max({tmp_bytes, scan_bytes, scan_bytes2, (size_t)256})))) return abort_plan(rc);
     size_t tb = d_tmp.bytes;
-    e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+    e = prim_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                   (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
     hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, scal);
@@ -739,14 +713,14 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         const unsigned vblk = (unsigned)((n_valid + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, keys_s, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, rocprim::maximum<int64_t>(), c->stream);  // d_b = group start
+        (void)prim_inclusive_scan_max(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, c->stream);  // d_b = group start
         hipLaunchKernelGGL(k_plan_item_heads, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, G, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);               // d_keys = item index + 1
+        (void)prim_inclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_keys.p, (size_t)n_valid, c->stream);               // d_keys = item index + 1
         // groups of items sharing (cell, dataset): their number decides which kernels take the batch
         hipLaunchKernelGGL(k_plan_group_flags, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
-        (void)rocprim::inclusive_scan(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (size_t)n_valid, rocprim::plus<int64_t>(), c->stream);   // d_idx = group id + 1
+        (void)prim_inclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (size_t)n_valid, c->stream);   // d_idx = group id + 1
         // (the two counts in ONE round trip: every host synchronisation of the planner is ~35 us of a call)
         int64_t n_groups = 0;
         e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);

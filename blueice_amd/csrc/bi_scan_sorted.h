@@ -1,5 +1,5 @@
 // bi_scan_sorted.h -- the matrix-core scan kernel for rows ordered by count (round 4).
-// Included by blueice_hip.hip after bi_kernels.h (uses its logarithm, ScanArgs and the permlane helpers).
+// Translation unit tu_scan_sorted.hip (uses the logarithm, ScanArgs and the permlane helpers of bi_dev_common.h).
 //
 // k_scan_mfma<2,KG,MASK,2> (round 3) took one logarithm per lane, 16-point work item and 32-bin strip and issued 3.8
 // vector instructions per MFMA -- on a chip where nothing executes beside an fp64 MFMA that kept the matrix pipe 69 %
@@ -68,13 +68,6 @@ __device__ __forceinline__ double log_core_s(double x, int k_adjust) {
     const double h = w + r;
     const double err = (w - h) + r;
     return h + (err + q);
-}
-
-// a lane's double as a wave-uniform (scalar) value
-__device__ __forceinline__ double lane_value(double v, int src_lane) {
-    const unsigned long long u = __double_as_longlong(v);
-    return __longlong_as_double(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), src_lane) << 32) |
-                                (unsigned)__builtin_amdgcn_readlane((int)u, src_lane));
 }
 
 constexpr int kFloorHi = 0x38000000;          // high word of 2^-127

@@ -294,17 +294,7 @@ int eval_single_fused(bi_ctx* c, const PointGeom& g, const double* rates, int64_
     const auto t_launch = bi_clock::now();
     {
         EventScope ev(c);
-#define BI_SINGLE(BBv, MODEv)                                                                                          \
-    do {                                                                                                               \
-        if (nt && fuse) hipLaunchKernelGGL((k_morph_single<BBv, true, MODEv, true>), grid, block, 0, c->stream, a, d);    \
-        else if (nt) hipLaunchKernelGGL((k_morph_single<BBv, true, MODEv, false>), grid, block, 0, c->stream, a, d);      \
-        else if (fuse) hipLaunchKernelGGL((k_morph_single<BBv, false, MODEv, true>), grid, block, 0, c->stream, a, d);    \
-        else hipLaunchKernelGGL((k_morph_single<BBv, false, MODEv, false>), grid, block, 0, c->stream, a, d);             \
-    } while (0)
-        if (c->unbinned) BI_SINGLE(false, 2);
-        else if (bb) BI_SINGLE(true, 0);
-        else BI_SINGLE(false, 0);
-#undef BI_SINGLE
+        launch_morph_single(c, bb, nt, fuse, grid, a, d);
     }
     if (!fuse)
         hipLaunchKernelGGL(k_finish_single, dim3(1), block, 0, c->stream, (const double*)a.partial, (const unsigned*)a.pflags,

@@ -51,12 +51,12 @@ int build_compact_templates(bi_ctx* c) {
         const double* cnt = (const double*)c->nz_n.p + lo;
         if (sort_by_count && nnz > 1) {
             size_t tmp_bytes = 0;
-            (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
+            (void)prim_sort_pairs(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr,
                                             (int32_t*)nullptr, (size_t)nnz, 0u, 64u, c->stream);
             if ((rc = dev_alloc(c, d_sidx, (size_t)nnz * sizeof(int32_t))) || (rc = dev_alloc(c, d_sn, (size_t)nnz * sizeof(double))) ||
                 (rc = dev_alloc(c, d_tmp, std::max<size_t>(tmp_bytes, 256)))) { drop(); return rc; }
             size_t tb = d_tmp.bytes;
-            e = rocprim::radix_sort_pairs(d_tmp.p, tb, cnt, (double*)d_sn.p, idx, (int32_t*)d_sidx.p, (size_t)nnz, 0u, 64u, c->stream);
+            e = prim_sort_pairs(d_tmp.p, tb, cnt, (double*)d_sn.p, idx, (int32_t*)d_sidx.p, (size_t)nnz, 0u, 64u, c->stream);
             if (e != hipSuccess) { drop(); return fail(c, BI_ERR_HIP, "template compaction (sort by count): %s", hipGetErrorString(e)); }
             idx = (const int32_t*)d_sidx.p;
             cnt = (const double*)d_sn.p;

@@ -19,32 +19,9 @@
 //
 // No CPU fallback exists: without a HIP device bi_create fails.
 
-#include <hip/hip_runtime.h>
-#include <sched.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <numeric>
-#include <string>
-#include <thread>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/blueice_hip.h"
-
-#define BI_VERSION "blueice_hip 0.1 (gfx950)"
-
-#include "bi_context.h"
-#include "bi_log_table.h"
-#include "bi_kernels.h"
-#include "bi_scan_sorted.h"
+#include "bi_common.h"
+#include "bi_prim.h"
+#include "bi_k_misc.h"
 #include "bi_geometry.h"
 #include "bi_launch.h"
 #include "bi_sparse.h"
@@ -597,39 +574,15 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             EventScope ev(c);
             ++c->n_scan_launches;
             const dim3 sgrid((unsigned)(k.nbx / 4), (unsigned)plan->n_groups);
-            const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
-#define BI_SCAN(CB, KG)                                                                                           \
-    do {                                                                                                          \
-        if (CB == 2 && plan->sparse) { /* compacted rows in bin order: blocks of counts 1 and 2 take the logarithm of the product mu^n */ \
-            if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<2, KG, false, 1>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-            else hipLaunchKernelGGL((k_scan_mfma<2, KG, true, 1>), sgrid, dim3(kThreads), 0, c->stream, sa);     \
-        } else if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_mfma<CB, KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-        else hipLaunchKernelGGL((k_scan_mfma<CB, KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
-    } while (0)
-#define BI_SCAN_KG(CB)                                                                                            \
-    do {                                                                                                          \
-        if (kg == 1) BI_SCAN(CB, 1); else if (kg == 2) BI_SCAN(CB, 2); else if (kg == 4) BI_SCAN(CB, 4); else BI_SCAN(CB, 8); \
-    } while (0)
-    /* rows ordered by count (all bins of dense data, or the compacted non-empty bins): 64-bin strips, four items at a time */ \
-#define BI_SORTED(KG)                                                                                             \
-    do {                                                                                                          \
-        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_sorted<KG, false>), sgrid, dim3(kThreads), 0, c->stream, sa); \
-        else hipLaunchKernelGGL((k_scan_sorted<KG, true>), sgrid, dim3(kThreads), 0, c->stream, sa);              \
-    } while (0)
             if (plan->by_count) {
+                // rows ordered by count (all bins of dense data, or the compacted non-empty bins): 64-bin strips, four items at a time
                 sa.n_groups = (int)plan->n_groups;
                 sa.xcd_mode = (int)c->scan_xcd;
                 sa.share_slow = (int)c->scan_share_slow;
                 const int64_t scan_blocks = (int64_t)(k.nbx / 4) * (c->scan_xcd == 2 ? (plan->n_groups + 7) / 8 * 8 : plan->n_groups);
-                const dim3 sgrid((unsigned)((scan_blocks + 7) / 8 * 8));
-                switch ((NS + 3) / 4) {           // the exact number of 4-stream groups: no matrix work on padding
-                    case 1: BI_SORTED(1); break; case 2: BI_SORTED(2); break; case 3: BI_SORTED(3); break; case 4: BI_SORTED(4); break;
-                    case 5: BI_SORTED(5); break; case 6: BI_SORTED(6); break; case 7: BI_SORTED(7); break; default: BI_SORTED(8); break;
-                }
-            } else if (plan->scan_cb == 2) BI_SCAN_KG(2); else BI_SCAN_KG(4);
-#undef BI_SORTED
-#undef BI_SCAN_KG
-#undef BI_SCAN
+                launch_scan_sorted(c, NS, dim3((unsigned)((scan_blocks + 7) / 8 * 8)), sa);
+            } else
+                launch_scan_mfma(c, plan->scan_cb == 2 ? 2 : 4, plan->sparse, NS, sgrid, sa);
         }
         hipLaunchKernelGGL(k_finish_scan, dim3((unsigned)((k.n_items + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0,
                            c->stream, (const double*)k.partial.p, k.nbx, k.n_items, (const int64_t*)k.perm.p,
@@ -691,14 +644,7 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
             EventScope ev(c);
             ++c->n_valid_launches;
             const dim3 vgrid((unsigned)(plan->valid_nslots / 4), (unsigned)plan->n_groups);
-            const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
-#define BI_VALID(KG)                                                                                              \
-    do {                                                                                                          \
-        if (NS == 4 * KG) hipLaunchKernelGGL((k_scan_valid<4, KG, false>), vgrid, dim3(kThreads), 0, c->stream, va); \
-        else hipLaunchKernelGGL((k_scan_valid<4, KG, true>), vgrid, dim3(kThreads), 0, c->stream, va);              \
-    } while (0)
-            if (kg == 1) BI_VALID(1); else if (kg == 2) BI_VALID(2); else if (kg == 4) BI_VALID(4); else BI_VALID(8);
-#undef BI_VALID
+            launch_scan_valid(c, NS, vgrid, va);
         }
         const int64_t n_slots = k.n_items * k.G;
         hipLaunchKernelGGL(k_apply_bad, dim3((unsigned)((n_slots + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
@@ -1107,8 +1053,7 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
         DevBuf d_tile, d_cnt, d_tmp, d_bad;
         auto drop = [&]() { dev_free(d_tile); dev_free(d_cnt); dev_free(d_tmp); dev_free(d_bad); };
         size_t scan_bytes = 0;
-        (void)rocprim::exclusive_scan(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(cells + 1),
-                                      rocprim::plus<int64_t>(), c->stream);
+        (void)prim_exclusive_scan_sum(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(cells + 1), c->stream);
         if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
             (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
             (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t)))) {
@@ -1131,8 +1076,7 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
             hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
                                n_tl, (int64_t*)d_cnt.p, group);
             size_t tb = d_tmp.bytes;
-            if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1),
-                                                             rocprim::plus<int64_t>(), c->stream);
+            if (e == hipSuccess) e = prim_exclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1), c->stream);
             if (width == 2)
                 hipLaunchKernelGGL((k_tm_scatter<uint16_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
                                    (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
@@ -1262,13 +1206,25 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     if (e == hipSuccess && n && !host_out && !out_dev) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     bool arrived = false;
     if (e == hipSuccess && done_word) {
+        // The word arrives ~0.1 ms after the launches for 10^4 datasets: spin for the first ~30 us (a yield costs more than
+        // the wait is worth there), then give the core away between looks -- eight ranks of a node each burning a core per
+        // call is what the launcher's thread cap exists to prevent -- and fall back to the stream synchronise (which also
+        // reports a faulted kernel) after a time that scales with the work: 2 ms + 1 us per dataset, at most 50 ms.
         const volatile unsigned long long* dw = done_word;
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+        const auto t_start = std::chrono::steady_clock::now();
+        const auto t_spin = t_start + std::chrono::microseconds(30);
+        const auto t_end = t_start + std::chrono::microseconds(std::min<int64_t>(50000, 2000 + n));
+        bool yielding = false;
         for (unsigned spin = 0; !(arrived = (*dw == seq)); ++spin) {
+            if (yielding) {
+                sched_yield();
+                if (std::chrono::steady_clock::now() > t_end) break;
+                continue;
+            }
 #if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
 #endif
-            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+            if ((spin & 63u) == 63u && std::chrono::steady_clock::now() > t_spin) yielding = true;
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         ++c->n_toy_polled;
@@ -1365,12 +1321,12 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
         DevBuf d_cdf, d_tmp, d_nev, d_room, d_nnz, d_ovf, d_tidx, d_tn;
         auto drop = [&]() { dev_free(d_cdf); dev_free(d_tmp); dev_free(d_nev); dev_free(d_room); dev_free(d_nnz); dev_free(d_ovf); dev_free(d_tidx); dev_free(d_tn); };
         size_t sb1 = 0, sb2 = 0;
-        (void)rocprim::inclusive_scan(nullptr, sb1, (const double*)nullptr, (double*)nullptr, (size_t)B, rocprim::plus<double>(), c->stream);
-        (void)rocprim::exclusive_scan(nullptr, sb2, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+        (void)prim_inclusive_scan_sum(nullptr, sb1, (const double*)nullptr, (double*)nullptr, (size_t)B, c->stream);
+        (void)prim_exclusive_scan_sum(nullptr, sb2, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(T + 1), c->stream);
         if ((rc = dev_alloc(c, d_cdf, (size_t)B * sizeof(double))) || (rc = dev_alloc(c, d_tmp, std::max<size_t>({sb1, sb2, 256}))) ||
             (rc = dev_alloc(c, d_ovf, 64))) { drop(); cleanup(); return rc; }
         size_t tb = d_tmp.bytes;
-        hipError_t e = rocprim::inclusive_scan(d_tmp.p, tb, mu, (double*)d_cdf.p, (size_t)B, rocprim::plus<double>(), c->stream);
+        hipError_t e = prim_inclusive_scan_sum(d_tmp.p, tb, mu, (double*)d_cdf.p, (size_t)B, c->stream);
         double M = 0.0;
         if (e == hipSuccess) e = hipMemcpyAsync(&M, (const double*)d_cdf.p + (B - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_ovf.p, 0, 64, c->stream);
@@ -1394,7 +1350,7 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
             hipLaunchKernelGGL(k_toy_event_counts, dim3((unsigned)((T + 1 + 255) / 256)), dim3(256), 0, c->stream, M, seed, c->toy_offset, T,
                                npow2, (int64_t*)d_nev.p, (int*)d_ovf.p);
             tb = d_tmp.bytes;
-            e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nev.p, (int64_t*)d_room.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+            e = prim_exclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_nev.p, (int64_t*)d_room.p, (int64_t)0, (size_t)(T + 1), c->stream);
             int64_t n_events = 0;
             int ovf = 0;
             if (e == hipSuccess) e = hipMemcpyAsync(&n_events, (const int64_t*)d_room.p + T, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
@@ -1415,7 +1371,7 @@ int bi_generate_toys(bi_ctx* c, const double* z, const double* rate_scale, int64
                 // (3) non-empty bins per toy -> final offsets; pack
                 e = hipMemsetAsync((int64_t*)d_nnz.p + T, 0, sizeof(int64_t), c->stream);
                 tb = d_tmp.bytes;
-                if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp.p, tb, (const int64_t*)d_nnz.p, (int64_t*)c->nz_off.p, (int64_t)0, (size_t)(T + 1), rocprim::plus<int64_t>(), c->stream);
+                if (e == hipSuccess) e = prim_exclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_nnz.p, (int64_t*)c->nz_off.p, (int64_t)0, (size_t)(T + 1), c->stream);
                 c->h_nz_off.assign((size_t)T + 1, 0);
                 if (e == hipSuccess) e = hipGetLastError();
                 if (e == hipSuccess) e = hipMemcpyAsync(c->h_nz_off.data(), c->nz_off.p, (size_t)(T + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
@@ -1607,7 +1563,7 @@ int score_events_impl(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n
         // events ordered by cell (see k_score_rows): from a few thousand events on, and while 32-bit positions do
         const bool sorted = c->score_sorted && N >= 4096 && N < ((int64_t)1 << 31);
         size_t sort_bytes = 0;
-        if (sorted) (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr,
+        if (sorted) (void)prim_sort_pairs(nullptr, sort_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr,
                                                     (int32_t*)nullptr, (size_t)N, 0u, 64u, c->stream);
         if ((!coords_dev && (rc = dev_alloc(c, d_ev, (size_t)N * k * sizeof(double)))) || (rc = dev_alloc(c, d_grid, (size_t)off * sizeof(double))) ||
             (rc = dev_alloc(c, d_base, (size_t)N * sizeof(int64_t))) || (method == 1 && (rc = dev_alloc(c, d_t, (size_t)N * k * sizeof(double)))) ||
@@ -1632,7 +1588,7 @@ int score_events_impl(bi_ctx* tp, bi_ctx* c, int method, int k, const int32_t* n
                 // (the cell index needs ceil(log2 B) bits: fewer radix passes than 64)
                 unsigned bits = 1;
                 while (bits < 63 && ((int64_t)1 << bits) < tp->B) ++bits;
-                e = rocprim::radix_sort_pairs(d_tmp.p, tb, (const int64_t*)d_base.p, (int64_t*)d_keys.p, (const int32_t*)d_iota.p,
+                e = prim_sort_pairs(d_tmp.p, tb, (const int64_t*)d_base.p, (int64_t*)d_keys.p, (const int32_t*)d_iota.p,
                                               (int32_t*)c->ev_perm.p, (size_t)N, 0u, bits, c->stream);
                 base_used = (const int64_t*)d_keys.p;
             }
@@ -1720,7 +1676,7 @@ int bi_simulate_events(bi_ctx* tp, bi_ctx* c, const double* z, const double* rat
                            dev_free(d_n); dev_free(d_first); dev_free(d_tmp); };
     int rc;
     size_t scan_bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const double*)nullptr, (double*)nullptr, (size_t)B, rocprim::plus<double>(), c->stream);
+    (void)prim_inclusive_scan_sum(nullptr, scan_bytes, (const double*)nullptr, (double*)nullptr, (size_t)B, c->stream);
     std::vector<double> h_edges(edges, edges + off);
     if ((rc = dev_upload(c, d_row, rowoff)) || (rc = dev_upload(c, d_w, g.w)) || (rc = dev_upload(c, d_edges, h_edges)) ||
         (rc = dev_upload(c, d_rates, r)) || (rc = dev_alloc(c, d_dens, (size_t)S * B * sizeof(double))) ||
@@ -1736,8 +1692,7 @@ int bi_simulate_events(bi_ctx* tp, bi_ctx* c, const double* z, const double* rat
     }
     for (int s = 0; e == hipSuccess && s < S; ++s) {
         size_t tb = d_tmp.bytes;
-        e = rocprim::inclusive_scan(d_tmp.p, tb, (const double*)d_dens.p + (size_t)s * B, (double*)d_cdf.p + (size_t)s * B, (size_t)B,
-                                    rocprim::plus<double>(), c->stream);
+        e = prim_inclusive_scan_sum(d_tmp.p, tb, (const double*)d_dens.p + (size_t)s * B, (double*)d_cdf.p + (size_t)s * B, (size_t)B, c->stream);
     }
     std::vector<int64_t> n_s((size_t)S, 0);
     if (e == hipSuccess) {

@@ -148,10 +148,13 @@ def sharded_scan_device(ctx, z, rate_scale, comm=None, dataset=None):
         # The device planner may refuse the batch (infinite rate scales of a source that may go negative are answered on
         # the host: BI_ERR_INVALID) or fail on one rank only (memory): the ranks agree before anybody takes a route, and
         # if any of them has no plan ALL take the host-dealt route below, which answers such points
+        # (the library answers a refusal with BI_ERR_INVALID, which DeviceContext raises as ValueError; a failure of this
+        #  rank alone is a DeviceError or anything else -- whatever it is, this rank still takes part in the agreement, or
+        #  its peers would wait in the all_reduce for ever)
         try:
             plan = ctx.plan_share(z, rate_scale, dataset, rank, world)
             word = 0
-        except DeviceError:
+        except Exception:
             plan, word = None, FAILED
         if int(comm.all_reduce(np.array([word], dtype=np.int64), 'bor')[0]) & FAILED:
             if plan is not None:

@@ -24,6 +24,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its only exports */
+#endif
 
 typedef struct bi_ctx bi_ctx;
 
@@ -431,6 +434,9 @@ int64_t bi_get_param(bi_ctx* ctx, const char* name);               /* unknown or
  * the buffer size the whole list needs */
 int bi_list_params(char* buf, int len);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,22 @@ def test_parameter_names_are_enumerable_and_documented(lib):
     assert lib.bi_list_params(small, 8) == n and len(small.value) == 7
 
 
+def test_library_override_is_not_a_backend_switch():
+    """BLUEICE_AMD_LIB lets an A/B run load another build of libblueice_hip; a library that does not say it is the gfx950
+    build -- the host build of the boundary tests, say -- is refused (a latent backend switch)."""
+    import subprocess
+    import sys
+    from blueice_amd import build
+    host = build.build_host()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from blueice_amd import _capi\n"
+            "from blueice_amd.exceptions import DeviceError\n"
+            "try:\n    _capi.load()\nexcept DeviceError as e:\n    print('refused:', e)\n") % ROOT
+    res = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, BLUEICE_AMD_LIB=host), capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.startswith('refused:'), res.stdout
+
+
 def _compile_c_demo(tmp_path):
     import subprocess
     exe = str(tmp_path / 'c_abi_demo')

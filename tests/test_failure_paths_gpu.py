@@ -1,7 +1,7 @@
 """The error paths of the in-launch finish, taken on purpose ("What's weak" 6).
 
 A work item's blocks post their partial sums into mailbox slots and the item's last block collects them
-(blueice_amd/csrc/bi_kernels.h: mail_post / mail_take).  The collector's wait is bounded; when it runs out the
+(blueice_amd/csrc/bi_dev_common.h: mail_post / mail_take).  The collector's wait is bounded; when it runs out the
 result is nan with BI_ST_INTERNAL and the host empties the mailbox (reset_mail) before the next launch.  Two
 injected faults (bi_set_param debug_skip_post / debug_late_post, consumed by the next mailbox launch):
   skip  block k never posts                  -> the collector times out; nothing is left behind

@@ -119,7 +119,7 @@ def test_products_that_leave_the_double_range_take_the_bin_wise_form(mini):
 def test_sparse_product_form_with_subnormal_intermediates():
     """Non-empty-bin form (PROD = 1): counts of 1 and 2 whose expectations are ~1e-80 next to ~1e+3 -- a pair product of
     the small ones is subnormal while the product of all four is a normal number again (ADVICE round 2,
-    bi_kernels.h: the intermediates are checked too)."""
+    bi_scan_sorted.h: the intermediates are checked too)."""
     from blueice_amd.device import DeviceContext
     from oracle import blueice_oracle as orc
     rng = np.random.default_rng(5)

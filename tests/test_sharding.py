@@ -365,8 +365,12 @@ class _ScriptedCtx:
 
     def plan_share(self, z, r, dataset, rank, world):
         from blueice_amd.exceptions import DeviceError
-        if self.mode == 'plan_refused_everywhere' or (self.mode == 'plan_fails_on_one' and rank == 1):
-            raise DeviceError('scripted: the device planner refuses this batch')
+        # what the library raises: a refusal is BI_ERR_INVALID -> ValueError (DeviceContext._check; tests/test_sharding_gpu.py
+        # asserts exactly that for Beeston-Barlow batches that need exact totals), a failure of one rank is a DeviceError
+        if self.mode == 'plan_refused_everywhere':
+            raise ValueError('scripted: the device planner refuses this batch (needs the host planner)')
+        if self.mode == 'plan_fails_on_one' and rank == 1:
+            raise DeviceError('scripted: hipMalloc failed on this rank')
         n = len(z)
         lo, hi = rank * n // world, (rank + 1) * n // world
         return _ScriptedPlan(np.arange(lo, hi, dtype=float), self.mode == 'run_fails_on_one' and rank == 1)

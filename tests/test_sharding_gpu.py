@@ -441,6 +441,52 @@ def test_device_planner_leaves_exact_totals_to_the_host():
     ctx.close()
 
 
+_BB_RANK_SCRIPT = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from blueice_amd.comm import connect
+from blueice_amd.device import DeviceContext
+from blueice_amd.sharding import sharded_scan_device
+from blueice_amd.synthetic import SyntheticModel
+m = SyntheticModel.named('mini4bb', bb_source=0)
+ctx = DeviceContext(0)
+comm = connect(ctx, backend='socket')
+dense = m.dense_model()
+ps = dense['ps'].copy()
+ps[..., 1:, 3] = 0.0
+ps[..., 1:, 7] = 0.0
+ctx.upload_model(dense['anchor_z'], ps, dense['mus'], dense['n_model'], bb_source=0)
+ctx.set_param('sparse', 0)
+ctx.upload_counts(m.counts(dense=True))
+z, r = m.random_points(1200, seed=6)
+want, want_st = ctx.eval(z, r)
+got, rerun = sharded_scan_device(ctx, z, r, comm)
+np.savez(sys.argv[2] + '.%d.npz' % comm.rank, want=want, got=got, again=rerun())
+comm.close()
+ctx.close()
+"""
+
+
+def test_sharded_scan_of_a_batch_the_device_planner_refuses(tmp_path):
+    """bi_plan_points_share answers a Beeston-Barlow batch that needs exact totals with BI_ERR_INVALID, which
+    DeviceContext raises as ValueError -- sharded_scan_device must take the agreed host-dealt route on every rank (and return the
+    values of ctx.eval), not let the refusal escape on every rank."""
+    script = tmp_path / 'bb_rank.py'
+    script.write_text(_BB_RANK_SCRIPT)
+    out = str(tmp_path / 'bb_res')
+    res = subprocess.run([sys.executable, '-m', 'blueice_amd.launch', '--nproc', '2', '--devices', '0,0', str(script), ROOT, out],
+                         env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    for rank in range(2):
+        g = np.load(out + '.%d.npz' % rank)
+        ok = np.isfinite(g['want'])
+        assert ok.sum() > 1000
+        np.testing.assert_array_equal(g['got'][ok], g['want'][ok])          # the host planner either way: the same bits
+        np.testing.assert_array_equal(g['again'][ok], g['want'][ok])
+        np.testing.assert_array_equal(np.isnan(g['got']), np.isnan(g['want']))
+
+
 def test_device_planner_takes_sources_that_may_go_negative():
     """allow_negative sources (blueice/likelihood.py:403-415): finite rates of either sign are planned on the device, shares and
     resident points included; an INFINITE rate is the host's to answer, and the planner says so."""

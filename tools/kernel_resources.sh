@@ -3,11 +3,17 @@
 # metadata (no GPU needed):   tools/kernel_resources.sh [name filter]
 set -e
 cd "$(dirname "$0")/.."
-OUT=${TMPDIR:-/tmp}/blueice_hip_gfx950.co
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -c -ffp-contract=off -mllvm --amdgpu-mfma-vgpr-form \
-    -Wno-unused-function -o "$OUT.bundle" blueice_amd/csrc/blueice_hip.hip
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input="$OUT.bundle" --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output="$OUT"
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes "$OUT" | python3 -c '
+# (the library is six translation units, blueice_amd/csrc/bi_common.h: each is compiled device-only, side by side, and the
+#  notes of all code objects are read together; UNITS="tu_scan_sorted" limits the run to one of them)
+UNITS=${UNITS:-"blueice_hip tu_morph tu_scan tu_scan_sorted tu_grad tu_prim"}
+OUT=${TMPDIR:-/tmp}/blueice_hip_gfx950
+for u in $UNITS; do
+    ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -c -ffp-contract=off -mllvm --amdgpu-mfma-vgpr-form \
+        -Wno-unused-function -o "$OUT.$u.bundle" blueice_amd/csrc/$u.hip
+      /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input="$OUT.$u.bundle" --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output="$OUT.$u.co" ) &
+done
+wait
+for u in $UNITS; do /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$OUT.$u.co"; done | python3 -c '
 import re, subprocess, sys
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 rows, cur = [], None

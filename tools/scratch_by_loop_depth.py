@@ -1,14 +1,16 @@
 """Where a kernel's scratch (spill) accesses sit: per kernel of the gfx950 code object, the number of scratch_load / scratch_store
 instructions by the loop depth the compiler's own block comments give them (no GPU needed).  Spills outside the innermost
 loops -- set up once per kernel, reloaded once per strip -- cost nothing measurable; spills inside an item loop do.
-    python tools/scratch_by_loop_depth.py [name filter]        (compiles blueice_hip.hip to assembly: ~1.5 min)"""
+    python tools/scratch_by_loop_depth.py [name filter] [unit]   (compiles one translation unit of the library to assembly; unit =
+    tu_scan_sorted (default), tu_morph, tu_scan, tu_grad, blueice_hip: see blueice_amd/csrc/bi_common.h)"""
 import os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
+unit = sys.argv[2] if len(sys.argv) > 2 else 'tu_scan_sorted'
 out = os.path.join(tempfile.gettempdir(), 'blueice_hip_gfx950.s')
 subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-ffp-contract=off',
                 '-mllvm', '--amdgpu-mfma-vgpr-form', '-Wno-unused-function', '-o', out,
-                os.path.join(root, 'blueice_amd', 'csrc', 'blueice_hip.hip')], check=True, stderr=subprocess.DEVNULL)
+                os.path.join(root, 'blueice_amd', 'csrc', unit + '.hip')], check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split('\n')
 FUNC = re.compile(r'^(_Z\w+):')
 mangled = [FUNC.match(l).group(1) for l in lines if FUNC.match(l)]
