@@ -115,6 +115,11 @@ class Ranks:
     """World of this run + the gather buffers in HBM."""
 
     def __init__(self, ctx, backend):
+        # --backend given explicitly: that gather or none (the run ends non-zero if a fallback had to be taken); not given:
+        # RCCL, with the agreed socket fallback allowed -- a gather of a few MB must not be what fails an unattended run
+        self.strict = backend is not None
+        backend = backend or 'rccl'
+        self.requested = backend
         self.world = int(os.environ.get('WORLD_SIZE', 1))
         self.rank = int(os.environ.get('RANK', 0))
         self.ctx = ctx
@@ -144,6 +149,17 @@ class Ranks:
             return 'rccl %s, ncclAllGather on the context stream between device buffers (ctypes binding)' % self.comm.version
         return '%s (host)%s' % (self.comm.kind, ' -- RCCL unavailable: ' + self.comm.fallback_reason
                                 if getattr(self.comm, 'fallback_reason', '') else '')
+
+    def report(self):
+        """What the JSON line says about the gather (collective: every rank calls it)."""
+        from blueice_amd.comm import describe
+        if self.comm is None:
+            return dict(backend_requested=self.requested, gather_kind='none (one process)', rccl_ranks=None, rccl_version=None,
+                        rank_devices=[self.ctx.device], rank_devices_source='this process', gather_fallback_reason=None)
+        return describe(self.comm, self.requested, local_device=self.ctx.device)
+
+    def fallback_taken(self):
+        return self.strict and self.comm is not None and self.requested == 'rccl' and self.comm.kind != 'rccl'
 
     def buffers(self, n):
         """send [n] and recv [world * n] doubles in HBM."""
@@ -458,6 +474,121 @@ def toy_leg(ctx, ranks, model, T, steps):
                 predicted_ceiling=predicted_ceiling(T, step_ms, kernel_ms, world, undivided_kernel_ms=logmu_ms))
 
 
+def toy_points_leg(ctx, ranks, model, T, P, steps):
+    """BASELINE.json configs[2] the way toy-MC users run it: every simulated dataset evaluated at every hypothesis (the loops of
+    blueice/inference.py:392-443 around blueice/model.py:69-91).  One step = P hypotheses x T datasets = P * T evaluations,
+    STRONG scaling: every rank draws the WHOLE ensemble on the device (the Philox counters are global dataset numbers: the same
+    toys on every rank), the hypotheses are dealt to the ranks by grid cell, a rank evaluates its P / N hypotheses with
+    bi_eval_datasets_points (four hypotheses share a pass over the lists, the hypotheses of a cell the pass over its templates),
+    leaves [P / N][T] in HBM, and the blocks are gathered per step.  Beside it, on this rank: the call with 1 and with 4
+    hypotheses (evaluations per second per GPU)."""
+    from blueice_amd.sharding import deal_points_by_cell
+    world, rank = ranks.world, ranks.rank
+    z0, r0 = model.default_point()
+    lo = np.array([g[0] for g in model.anchor_z])
+    hi = np.array([g[-1] for g in model.anchor_z])
+    ctx.set_param('sparse', 1)
+    ctx.set_param('toy_offset', 0)
+    tg = time.perf_counter()
+    ctx.generate_toys(z0, r0, T, seed=4242)
+    gen_s = ranks.max_over_ranks(time.perf_counter() - tg)
+    nnz = int(ctx.get_param('nnz_total'))
+
+    def hypotheses(k, n=P):
+        """n hypotheses of step k: n / 8 shape points (grid cells) x 8 signal strengths -- inputs, made before the clock starts"""
+        shapes = max(1, n // 8)
+        zs = np.stack([lo + np.mod(z0 - lo + 0.01 * (k + 1) + 1.05 * s, hi - lo) for s in range(shapes)])     # (different cells)
+        z = np.repeat(zs, n // shapes, axis=0)
+        r = np.repeat(r0[None, :], len(z), axis=0)
+        r[:, 0] *= np.tile(np.linspace(0.25, 2.0, n // shapes), shapes)
+        return np.ascontiguousarray(z), np.ascontiguousarray(r)
+
+    work = {k: hypotheses(k) for k in range(-1, steps)}
+    deals = {k: deal_points_by_cell(model.anchor_z, work[k][0], world) for k in work}
+    n_max = max(max(len(d) for d in deal) for deal in deals.values())
+    send, _ = ranks.buffers(n_max * T)
+    send.from_host(np.zeros(n_max * T))
+
+    def step(k):
+        z, r = work[k]
+        if world == 1:
+            out, st = ctx.eval_datasets_points(z, r)
+            return out, int(np.bitwise_or.reduce(st))
+        mine = deals[k][rank]
+        st = ctx.eval_datasets_points_device(send.ptr, z[mine], r[mine]) if len(mine) else np.zeros(0, np.int32)
+        parts = ranks.gather(n_max * T)
+        out = np.empty((P, T))
+        for idx, vals in zip(deals[k], parts):
+            out[idx] = vals[:len(idx) * T].reshape(len(idx), T)
+        return out, int(np.bitwise_or.reduce(st)) if len(st) else 0
+
+    step(-1)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out, st = step(k)
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    assert st == 0 and out.shape == (P, T) and np.all(np.isfinite(out))
+    # cross-rank consistency through ANOTHER path: hypotheses another rank evaluated, re-evaluated here one at a time
+    # (bi_eval_datasets: tiles of 8192 bins, one point per pass) -- the same sums in another grouping
+    z, r = work[steps - 1]
+    worst = 0.0
+    for p in sorted({0, P // 2 + 1, P - 1}):
+        one, _ = ctx.eval_datasets(z[p], r[p])
+        worst = max(worst, float(np.max(np.abs(one - out[p]) / np.abs(one))))
+    assert worst <= 1e-12, 'toy hypotheses: gathered values differ from single-point calls by %.2e' % worst
+    step(0)
+    ctx.profile(True)
+    step(0)
+    n_launch, kernel_ms = ctx.profile_read()
+    ctx.profile(False)
+    kernel_ms = ranks.max_over_ranks(kernel_ms)
+    step_ms = elapsed / steps * 1e3
+    # the call by number of hypotheses, on this rank (per GPU): one point per call (bi_eval_datasets), four, all P
+    per_gpu = {}
+    for n_h in (1, 4, P):
+        zh, rh = hypotheses(0, max(n_h, 8))
+        zh, rh = zh[:n_h], rh[:n_h]                      # (n_h <= 8: signal strengths of one shape point -- one grid cell)
+        fn = (lambda: ctx.eval_datasets(zh[0], rh[0])) if n_h == 1 else (lambda: ctx.eval_datasets_points(zh, rh))
+        for _ in range(3):
+            fn()
+        reps = max(5, 60 // n_h)
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        per_gpu[str(n_h)] = n_h * T * reps / (time.perf_counter() - t)
+    # algorithmic bytes of a step on this rank: per pass of 4 hypotheses the 2^d*S template rows of every distinct cell in it,
+    # its 4 log mu rows written and staged once (8 B each way per bin and hypothesis), one list entry per non-empty bin of every
+    # dataset -- once per PASS, not per hypothesis
+    mine = deals[steps - 1][rank]
+    NS = 2 ** model.d * model.S
+    entry_bytes = int(ctx.get_param('tmm_entry_bytes'))
+    n_pass = -(-len(mine) // 4)
+    from blueice_amd.sharding import cell_ids
+    ids = np.sort(cell_ids(model.anchor_z, work[steps - 1][0][mine]))
+    cells_in_passes = sum(len(np.unique(ids[i:i + 4])) for i in range(0, len(ids), 4))
+    nbytes = 8.0 * NS * model.B * cells_in_passes + 2 * 8.0 * model.B * len(mine) + float(entry_bytes) * nnz * n_pass
+    roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, bytes_per_call=nbytes, list_entry_bytes=entry_bytes, launches_per_call=int(n_launch),
+                passes=n_pass, cells_in_passes=int(cells_in_passes), kernel_ms_per_call=kernel_ms,
+                achieved=nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None,
+                achieved_over_whole_step=nbytes / (step_ms * 1e-3) / 1e9, traffic=None,
+                kernels='k_morph_logmu_multi<4> (HBM-bound), k_dataset_dot_multi<4,2,2,4,4096> (bound by LDS bank conflicts: 64 lanes x 32 '
+                        'random bytes per entry; profiles/r05_toy_points.json), k_dataset_finish_multi<4>',
+                note='algorithmic bytes per call / summed kernel time of the call (HIP events); what the call is measured by is '
+                     'evaluations per second')
+    roof['frac'] = roof['achieved'] / HBM_PEAK_GBS if roof['achieved'] else None
+    return dict(workload='C3: 10^4 toy datasets (drawn on the device) x %d hypotheses per step (%d grid cells x %d signal strengths), '
+                         'hypotheses dealt over the ranks by grid cell, every rank holds all datasets' % (P, max(1, P // 8), P // max(1, P // 8)),
+                scaling='strong', datasets=T, hypotheses=P, steps=steps, value=P * T * steps / elapsed, unit='evals/s', ms_per_step=step_ms,
+                generate_s=gen_s, hypotheses_per_rank_min_max=[min(len(d) for d in deals[0]), max(len(d) for d in deals[0])],
+                max_rel_diff_vs_single_point_calls=worst, nonempty_bins=nnz, gather=ranks.kind, roofline=roof,
+                evals_per_s_per_gpu_by_hypotheses_per_call=per_gpu,
+                four_hypotheses_over_one_per_call=per_gpu['4'] / per_gpu['1'],
+                step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, step_ms - kernel_ms)),
+                predicted_ceiling=predicted_ceiling(P * T, step_ms, kernel_ms, world))
+
+
 def c5_leg(ctx, ranks, steps=24, threads=8):
     """configs[4] on one grid cell of its anchor grid (2^4 anchors, 6 sources, 50^4 bins, Beeston-Barlow on source 0;
     blueice/likelihood.py:618-660), uploaded into `ctx` in place of the C2 model:
@@ -587,8 +718,26 @@ def dry_run(args):
     from blueice_amd.comm import connect
     from blueice_amd.sharding import deal_points_by_cell, gather_vector
     from blueice_amd.synthetic import SyntheticModel
+    from blueice_amd.comm import describe
     world, rank = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
-    comm = connect(backend='socket', rank=rank, world=world)
+
+    class DryContext:                                 # what connect() asks of a DeviceContext; there is no GPU here
+        stream, device = 0, int(os.environ.get('LOCAL_RANK', 0))
+
+        def device_alloc(self, n):
+            return type('Buf', (), {'free': lambda self: None})()
+
+        def sync(self):
+            pass
+
+    requested = args.backend or 'rccl'
+    if requested == 'rccl' and os.environ.get('BLUEICE_AMD_RCCL'):
+        top = connect(DryContext(), backend='rccl', rank=rank, world=world, timeout=30.0)     # the init / agreement path, with a stand-in library
+    else:
+        top = connect(backend='socket', rank=rank, world=world)
+    comm = top.boot if top.kind == 'rccl' else top      # (no device memory in a dry run: the vectors travel through the host channel)
+    report = describe(top, requested)
+    strict_fallback = args.backend == 'rccl' and top.kind != 'rccl' and world > 1
     model = SyntheticModel.named('C2')
     z, r = model.random_points(20000, seed=900)
     deal = deal_points_by_cell(model.anchor_z, z, world)
@@ -603,13 +752,13 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': world, 'dry': True,
                           'steps': args.steps, 'warmup': args.warmup,
-                          'config': {'host_threads_per_rank': host_thread_share(world),
-                                     'host_cores_of_this_process': len(os.sched_getaffinity(0))},
+                          'config': dict({'host_threads_per_rank': host_thread_share(world),
+                                          'host_cores_of_this_process': len(os.sched_getaffinity(0))}, **report),
                           'legs': {'C4': {'points': len(z), 'points_per_rank_min_max': [min(len(d) for d in deal), max(len(d) for d in deal)],
-                                          'ranks': ranks_seen[:, 0].tolist(), 'devices': ranks_seen[:, 1].tolist(), 'gather': comm.kind}}}),
+                                          'ranks': ranks_seen[:, 0].tolist(), 'devices': ranks_seen[:, 1].tolist(), 'gather': top.kind}}}),
               flush=True)
-    comm.close()
-    return 0
+    top.close()
+    return 4 if strict_fallback else 0
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -623,8 +772,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-legs', action='store_true')
-    ap.add_argument('--backend', default='rccl', help="gather for N > 1: 'rccl' (direct binding) or 'socket' (host; for "
-                                                      'rehearsals on a box with fewer GPUs than ranks)')
+    ap.add_argument('--backend', default=None, choices=('rccl', 'socket'),
+                    help="gather for N > 1: 'rccl' (direct binding) or 'socket' (host; for rehearsals on a box with fewer GPUs "
+                         'than ranks).  Not given: rccl, falling back to sockets together if RCCL cannot start (the line says so); '
+                         'given as rccl: RCCL or a non-zero exit')
     ap.add_argument('--devices', default=None, help='self-launched N > 1 only: comma-separated GPU index per rank '
                                                     '(default rank r -> GPU r; "0,0" rehearses two ranks on one GPU)')
     ap.add_argument('--dry', action='store_true', help='no GPU: launch, rendezvous, dealing and gather only (tests)')
@@ -654,13 +805,27 @@ def main():
     threads = host_thread_share(world)              # per rank: upload threads and the library's planner threads
     ctx.set_param('host_threads', threads)
     ranks = Ranks(ctx, args.backend)
+    gather_report = ranks.report()                  # (collective) RCCL's own rank count, every rank's GPU, the fallback reason if any
 
     def emit(result):
         if rank == 0:
+            result.setdefault('config', {}).update(gather_report)
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             print(json.dumps(result), flush=True)
             os.dup2(2, 1)
+
+    def leave():
+        """--backend rccl was asked for and the socket fallback was taken: the numbers stand (the line says which gather ran),
+        the command fails -- an 8-GPU run that silently gathered through the host must not pass for an RCCL run."""
+        if ranks.fallback_taken():
+            log('rank %d: --backend rccl was requested but the gather fell back to sockets (%s): exit code 4' % (
+                rank, gather_report.get('gather_fallback_reason')))
+        code = 4 if ranks.fallback_taken() else 0
+        ranks.close()
+        ctx.close()
+        if code:
+            sys.exit(code)
 
     K, W = args.steps, args.warmup
 
@@ -671,7 +836,7 @@ def main():
             model.upload(ctx, threads=min(4, threads))
             steps = max(1, min(K, 5 if args.config != 'C4-dense' else 2))
             if args.config == 'C3':
-                leg = toy_leg(ctx, ranks, model, 10000, max(1, min(K, 50)))
+                leg = toy_points_leg(ctx, ranks, model, 10000, 32, max(1, min(K, 20)))
             else:
                 ctx.set_param('sparse', 1 if args.config == 'C4' else 0)
                 ctx.upload_counts(model.counts())
@@ -719,8 +884,7 @@ def main():
                   'config': {'workload': leg['workload'], 'device': info['arch']}, 'roofline': roof, 'leg': leg,
                   'cpu_baseline': None}
         emit(result)
-        ranks.close()
-        ctx.close()
+        leave()
         return
 
     # ---- headline ----------------------------------------------------------------------------------------
@@ -859,7 +1023,8 @@ def main():
             'note': 'fp64 FMA work of the morph alone (2 * 2^d*S * bins flop per evaluation) of the busiest rank over the '
                     'whole step (planning + non-empty-bin pass + k_scan_valid + gather)'}
         legs['C4-dense']['roofline_scan']['frac'] = legs['C4-dense']['roofline_scan']['achieved'] / FP64_PEAK_TFLOPS
-        legs['C3'] = toy_leg(ctx, ranks, model, 10000, 100)      # (100 calls of ~0.13 ms: a steadier mean than 20)
+        legs['C3'] = toy_points_leg(ctx, ranks, model, 10000, 32, 20)
+        legs['C3-one-point'] = toy_leg(ctx, ranks, model, 10000, 100)      # (100 calls of ~0.13 ms: a steadier mean than 20)
         ctx.set_param('sparse', 0)
         ctx.upload_counts(counts)
     if rank == 0:
@@ -933,8 +1098,7 @@ def main():
             result['roofline_bb'] = {k: kern[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'bytes_per_launch', 'avg_launch_us')}
 
     emit(result)
-    ranks.close()
-    ctx.close()
+    leave()
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ SIGNATURES = {
     'bi_minimize_batched': (C.c_int, [_p, _p, _i64, C.c_int, _p, _p, _p, _p, _p, C.c_double, C.c_int, _p, _p, _p, _p]),
     'bi_fit_batched': (C.c_int, [_p, _i64, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_int, _p, _p, _p, _p]),
     'bi_eval_datasets': (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    'bi_eval_datasets_points': (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _p, _p]),
+    'bi_eval_datasets_points_device': (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _p, _p]),
     'bi_interpolate': (C.c_int, [_p, C.c_int, _p, _p]),
     'bi_eval_full': (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
     'bi_plan_points': (C.c_int, [_p, _i64, _p, _p, _p, C.POINTER(_p)]),

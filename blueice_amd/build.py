@@ -9,6 +9,7 @@ never loads it (blueice_amd/_capi.py binds libblueice_hip.so only); tests and to
 """
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -44,21 +45,39 @@ def hipcc():
     return 'hipcc'
 
 
-def _sources():
-    return sorted([HDR] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))])
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
 
-def source_hash():
-    """sha256 over the CONTENT of every source the library is built from, and the flags: what the rebuild is gated on
-    (a fresh clone has fresh mtimes but the same content; a touched file with the same bytes is not a change)."""
+def _closure(path, seen=None):
+    """the file and every file it includes with quotes, recursively (the library's own sources; <...> headers are the toolchain's)"""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as fh:
+        text = fh.read()
+    for inc in _INCLUDE.findall(text):
+        _closure(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
+
+
+def unit_hash(name):
+    """sha256 over the CONTENT of a translation unit and of everything it includes, and the flags: what its rebuild is gated
+    on (a fresh clone has fresh mtimes but the same content; a touched file with the same bytes is not a change)."""
     h = hashlib.sha256()
     h.update(' '.join(FLAGS).encode())
-    for f in _sources():
-        if f.endswith('host_backend.cpp'):
-            continue
+    for f in sorted(_closure(os.path.join(CSRC, name + '.hip'))):
         h.update(os.path.basename(f).encode() + b'\0')
         with open(f, 'rb') as fh:
             h.update(fh.read())
+    return h.hexdigest()
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for u in UNITS:
+        h.update(unit_hash(u).encode())
     return h.hexdigest()
 
 
@@ -78,10 +97,18 @@ def build(force=False, verbose=False, jobs=None):
 
     def compile_unit(name):
         obj = os.path.join(OBJ_DIR, name + '.o')
+        stamp = obj + '.sha256'
+        want = unit_hash(name)
+        if not force and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as fh:
+                if fh.read().strip() == want:
+                    return obj                      # this unit's sources have not changed
         cmd = [cc] + FLAGS + ['-c', '-o', obj, os.path.join(CSRC, name + '.hip')]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(stamp, 'w') as fh:
+            fh.write(want + '\n')
         return obj
 
     jobs = jobs or max(1, min(len(UNITS), (os.cpu_count() or 2)))

@@ -280,6 +280,12 @@ def load_rccl():
         fn = getattr(lib, name)
         fn.restype = i
         fn.argtypes = args
+    # what the communicator says about itself once it exists (rccl.h): bound when the library has them
+    for name in ('ncclCommCount', 'ncclCommCuDevice', 'ncclCommUserRank'):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = i
+            fn.argtypes = [vp, C.POINTER(i)]
     _rccl = lib
     return lib
 
@@ -308,6 +314,22 @@ class RcclCommunicator:
         v = C.c_int()
         self._lib.ncclGetVersion(C.byref(v))
         self.version = v.value
+        # The communicator's own account of itself: how many ranks it spans, which one this is, which GPU it sits on.  A run
+        # reports these (bench.py: config.rccl_ranks / rank_devices), so that a log answers "did RCCL see N ranks, one per
+        # GPU" without anybody having watched the run; a count that is not the world size is an error here and now.
+        self.n_ranks, self.user_rank, self.device = self._query('ncclCommCount'), self._query('ncclCommUserRank'), self._query('ncclCommCuDevice')
+        if self.n_ranks is not None and self.n_ranks != self.world:
+            raise CommError("ncclCommCount says %d ranks, the launcher started %d" % (self.n_ranks, self.world))
+        if self.user_rank is not None and self.user_rank != self.rank:
+            raise CommError("ncclCommUserRank says rank %d, the launcher says %d" % (self.user_rank, self.rank))
+
+    def _query(self, name):
+        fn = getattr(self._lib, name, None)
+        if fn is None:
+            return None
+        v = C.c_int(-1)
+        self._ok(fn(self._comm, C.byref(v)), name)
+        return int(v.value)
 
     def _ok(self, rc, what):
         if rc != 0:
@@ -373,6 +395,23 @@ class RcclCommunicator:
             self._comm = C.c_void_p()
         if self.boot is not None:
             self.boot.close()
+
+
+def describe(comm, requested='rccl', local_device=None):
+    """What a run should say about its gather, agreed over all ranks: the kind that was requested and the kind that runs,
+    the number of ranks RCCL itself reports (ncclCommCount; None without RCCL), the GPU of every rank as RCCL sees it
+    (ncclCommCuDevice; else the launcher's LOCAL_RANK / `local_device`), and why a fallback was taken.  Collective: every
+    rank calls it."""
+    kind = getattr(comm, 'kind', 'none')
+    host = comm.boot if (kind == 'rccl' and getattr(comm, 'boot', None) is not None) else comm
+    dev = getattr(comm, 'device', None)
+    if dev is None:
+        dev = int(os.environ.get('LOCAL_RANK', -1)) if local_device is None else int(local_device)
+    devices = [int(d) for d in np.ravel(host.all_gather(np.array([float(dev)])))] if host is not None and hasattr(host, 'all_gather') else [dev]
+    return dict(backend_requested=requested, gather_kind=kind, rccl_ranks=getattr(comm, 'n_ranks', None) if kind == 'rccl' else None,
+                rccl_version=getattr(comm, 'version', None) if kind == 'rccl' else None, rank_devices=devices,
+                rank_devices_source='ncclCommCuDevice' if kind == 'rccl' and getattr(comm, 'device', None) is not None else 'launcher',
+                gather_fallback_reason=getattr(comm, 'fallback_reason', '') or None)
 
 
 def exchange_unique_id(boot, lib):

@@ -110,6 +110,15 @@ struct bi_ctx {
     DevBuf tm_entries, tm_off;                // tile-major copy of the non-empty-bin lists (k_dataset_dot_tiled): 4-byte entries, [n_tiles * T + 1] offsets
     int64_t nz_tile_epoch = -1;               // data epoch the copy was built for
     bool tm_ok = false;                       // ... and whether every count fits its 19 bits
+    // the same lists over tiles of kDotTileMulti bins, for the toy-MC call over several parameter points (bi_eval_datasets_points:
+    // the log mu tiles of four points side by side in LDS)
+    DevBuf tmm_entries, tmm_off;
+    int64_t tmm_epoch = -1;
+    bool tmm_ok = false;
+    int tmm_width = 4;
+    int64_t toy_points_pp = 0;                // parameter: points per pass of that call (0 = by the batch: 4, or 2 for two points; 1 = point by point)
+    int64_t toy_points_lanes = 0;             // parameter: lanes per (dataset, tile) run of its kernel (0 = measured default)
+    int64_t n_toy_points_passes = 0;          // read-only: passes over the entry lists the multi-point kernel has made
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
     int64_t score_sorted = 1;                 // parameter: bi_score_events / bi_simulate_events order the events by cell before the gathers
     DevBuf ev_perm;                           // [events] sorted position -> the caller's event (valid while ev_sorted)

@@ -483,7 +483,8 @@ __global__ __launch_bounds__(kThreads) void k_dataset_dot_csr(const int32_t* __r
 constexpr int kDotTile = 8192;      // bins per tile: 64 KB of LDS
 
 __global__ __launch_bounds__(kThreads) void k_csr_tile_offsets(const int32_t* __restrict__ nz_idx, const int64_t* __restrict__ nz_off,
-                                                               int n_tl, int32_t* __restrict__ tile_off /*[T][n_tl + 1]*/) {
+                                                               int n_tl, int32_t* __restrict__ tile_off /*[T][n_tl + 1]*/,
+                                                               int tile_shift /* log2 of the bins per tile */) {
     const int64_t t = blockIdx.x;
     const int64_t lo = nz_off[t], hi = nz_off[t + 1];
     int32_t* __restrict__ dst = tile_off + t * (n_tl + 1);
@@ -492,8 +493,8 @@ __global__ __launch_bounds__(kThreads) void k_csr_tile_offsets(const int32_t* __
         return;
     }
     for (int64_t j = lo + threadIdx.x; j < hi; j += kThreads) {
-        const int cur = nz_idx[j] / kDotTile;
-        const int prev = j > lo ? nz_idx[j - 1] / kDotTile : -1;
+        const int cur = nz_idx[j] >> tile_shift;
+        const int prev = j > lo ? nz_idx[j - 1] >> tile_shift : -1;
         for (int tl = prev + 1; tl <= cur; ++tl) dst[tl] = (int32_t)(j - lo);     // first entry at or beyond the start of tile tl
         if (j == hi - 1)
             for (int tl = cur + 1; tl <= n_tl; ++tl) dst[tl] = (int32_t)(hi - lo);
@@ -546,7 +547,7 @@ template <typename ENTRY>
 __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restrict__ nz_idx, const double* __restrict__ nz_n,
                                                          const int64_t* __restrict__ nz_off, const int32_t* __restrict__ tile_off,
                                                          int64_t T, int n_tl, const int64_t* __restrict__ tm_off,
-                                                         ENTRY* __restrict__ tm_entries, int* __restrict__ bad) {
+                                                         ENTRY* __restrict__ tm_entries, int* __restrict__ bad, int tile_shift) {
     const int64_t t = blockIdx.x;
     const int64_t lo = nz_off[t], hi = nz_off[t + 1];
     const int32_t* __restrict__ o = tile_off + t * (n_tl + 1);
@@ -554,13 +555,13 @@ __global__ __launch_bounds__(kThreads) void k_tm_scatter(const int32_t* __restri
     for (int64_t j = lo + threadIdx.x; j < hi; j += kThreads) {
         const int idx = nz_idx[j];
         const double n = nz_n[j];
-        const int tl = idx / kDotTile;
+        const int tl = idx >> tile_shift;
         if constexpr (sizeof(ENTRY) == 2) {
             if (!(n >= 1.0 && n <= 7.0 && n == floor(n))) any_bad = true;
-            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = (ENTRY)(((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n & 7u));
+            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = (ENTRY)(((uint32_t)(idx - (tl << tile_shift)) << 3) | ((uint32_t)n & 7u));
         } else {
             if (!(n >= 1.0 && n < 32768.0 && n == floor(n))) any_bad = true;
-            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = ((uint32_t)(idx - tl * kDotTile) << 3) | ((uint32_t)n << 17);
+            tm_entries[tm_off[(int64_t)tl * T + t] + (j - lo - o[tl])] = ((uint32_t)(idx - (tl << tile_shift)) << 3) | ((uint32_t)n << 17);
         }
     }
     if (any_bad) atomicOr(bad, 1);
@@ -607,10 +608,12 @@ __device__ __forceinline__ double row_group_sum(double v) {
         BI_DPP_ADD(0x141);            // row_half_mirror
         BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
         BI_DPP_ADD(0x4E);             // quad_perm:[2,3,0,1]
-    } else {
-        static_assert(L == 4, "groups of 4, 8 or 16 lanes");
+    } else if constexpr (L == 4) {
         BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
         BI_DPP_ADD(0x4E);             // quad_perm:[2,3,0,1]
+    } else {
+        static_assert(L == 2, "groups of 2, 4, 8 or 16 lanes");
+        BI_DPP_ADD(0xB1);             // quad_perm:[1,0,3,2]
     }
 #undef BI_DPP_ADD
     return v;

@@ -53,6 +53,18 @@ const ParamDef kParams[] = {
     {"scan_waves_per_cu", kParamRW, BI_P_GET(c->scan_waves_per_cu), BI_P_SET(c->scan_waves_per_cu = v < 0 ? 0 : v)},
     {"host_threads", kParamRW, [](bi_ctx*) -> int64_t { return host_threads(); },
      [](bi_ctx* c, int64_t v) -> int { if (v < 0 || v > 256) return fail(c, BI_ERR_INVALID, "host_threads in [0, 256] (0 = by the process's affinity, at most 16)"); host_threads_setting().store((int)v); return BI_OK; }},
+    {"toy_points_pp", kParamRW, BI_P_GET(c->toy_points_pp),
+     [](bi_ctx* c, int64_t v) -> int {
+         if (v != 0 && v != 1 && v != 2 && v != 4) return fail(c, BI_ERR_INVALID, "toy_points_pp: 0 = by the batch, 1 = point by point, 2 or 4 points per pass");
+         c->toy_points_pp = v;
+         return BI_OK;
+     }},
+    {"toy_points_lanes", kParamRW, BI_P_GET(c->toy_points_lanes),
+     [](bi_ctx* c, int64_t v) -> int {
+         if (v != 0 && v != 2 && v != 4 && v != 8) return fail(c, BI_ERR_INVALID, "toy_points_lanes: 0 = default, or 2 / 4 / 8");
+         c->toy_points_lanes = v;
+         return BI_OK;
+     }},
     {"grad_mfma", kParamRW, BI_P_GET(c->grad_mfma), BI_P_FLAG(grad_mfma)},
     {"grad_mfma_min", kParamRW, BI_P_GET(c->grad_mfma_min), BI_P_RANGE(1, (int64_t)1 << 40, grad_mfma_min, "grad_mfma_min >= 1")},
     {"grad_slices", kParamRW, BI_P_GET(c->grad_slices), BI_P_RANGE(0, 4096, grad_slices, "grad_slices in [0, 4096]")},
@@ -66,7 +78,7 @@ const ParamDef kParams[] = {
     {"dot_tiled", kParamRW, BI_P_GET(c->dot_tiled), BI_P_FLAG(dot_tiled)},
     {"score_sorted", kParamRW, BI_P_GET(c->score_sorted), BI_P_FLAG(score_sorted)},
     {"toy_fast_call", kParamRW, BI_P_GET(c->toy_fast_call), BI_P_RANGE(0, 7, toy_fast_call, "toy_fast_call: bits 1 | 2 | 4")},
-    {"dot_entry16", kParamRW, BI_P_GET(c->dot_entry16), [](bi_ctx* c, int64_t v) -> int { c->dot_entry16 = v ? 1 : 0; c->nz_tile_epoch = -1; return BI_OK; }},
+    {"dot_entry16", kParamRW, BI_P_GET(c->dot_entry16), [](bi_ctx* c, int64_t v) -> int { c->dot_entry16 = v ? 1 : 0; c->nz_tile_epoch = -1; c->tmm_epoch = -1; return BI_OK; }},
     {"dot_blocks_per_cu", kParamRW, BI_P_GET(c->dot_blocks_per_cu), BI_P_RANGE(0, 16, dot_blocks_per_cu, "dot_blocks_per_cu in [0, 16]")},
     {"dot_lanes", kParamRW, BI_P_GET(c->dot_lanes), BI_P_SET(c->dot_lanes = (v == 16 || v == 8 || v == 4) ? v : 0)},
     {"compact_budget", kParamRW, BI_P_GET(c->compact_budget), BI_P_SET(c->compact_budget = v)},
@@ -87,6 +99,8 @@ const ParamDef kParams[] = {
     BI_P_RO("padded_bins", c->Bp),
     BI_P_RO("n_scan_launches", c->n_scan_launches),
     BI_P_RO("n_toy_polled", c->n_toy_polled),
+    BI_P_RO("n_toy_points_passes", c->n_toy_points_passes),
+    BI_P_RO("tmm_entry_bytes", c->tmm_ok ? c->tmm_width : 0),
     BI_P_RO("tm_entry_bytes", c->tm_width),
     BI_P_RO("events_sorted", c->ev_sorted ? 1 : 0),
     BI_P_RO("n_grad_mfma_launches", c->n_grad_mfma_launches),

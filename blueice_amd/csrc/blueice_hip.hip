@@ -103,7 +103,7 @@ void bi_destroy(bi_ctx* c) {
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     if (c->bounce_host) (void)hipHostFree(c->bounce_host);
     dev_free(c->pack_dev);
-    dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off);
+    dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off); dev_free(c->tmm_entries); dev_free(c->tmm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
     dev_free(c->pt_cnt_off); dev_free(c->pt_c_np); dev_free(c->pt_Tz); dev_free(c->pt_rowsum); dev_free(c->pt_rowmin); dev_free(c->pt_nm_tot);
     for (void* q : c->user_allocs) (void)hipFree(q);   // bi_device_alloc buffers nobody freed
@@ -990,6 +990,71 @@ int bi_eval_grad(bi_ctx* c, int64_t P, const double* z, const double* rate_scale
 
 namespace {
 
+// Tile-major copy of the context's non-empty-bin lists for tiles of `tile_bins` bins (a power of two, at most kDotTile): the
+// entries of bin tile 0 (dataset 0, 1, ...), then tile 1, ... -- see k_tm_scatter.  Two-byte entries where every count is at
+// most 7 (toys of sparse expectations), four-byte entries otherwise; ok = false (and nothing kept) when some count fits neither.
+int build_tile_major(bi_ctx* c, int tile_bins, DevBuf& entries, DevBuf& off, bool& ok, int& width_out) {
+    int tile_shift = 0;
+    while ((1 << tile_shift) < tile_bins) ++tile_shift;
+    const int n_tl = (int)((c->B + tile_bins - 1) / tile_bins);
+    const int64_t nnz = c->h_nz_off.back(), cells = (int64_t)n_tl * c->T;
+    const uint32_t pad_entry = (uint32_t)tile_bins << 3;          // four-byte lists: the offset of the extra LDS slot behind the tile (0.0), count 0
+    int rc;
+    DevBuf d_tile, d_cnt, d_tmp, d_bad;
+    auto drop = [&]() { dev_free(d_tile); dev_free(d_cnt); dev_free(d_tmp); dev_free(d_bad); };
+    size_t scan_bytes = 0;
+    (void)prim_exclusive_scan_sum(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(cells + 1), c->stream);
+    if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
+        (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
+        (rc = dev_alloc(c, off, (size_t)(cells + 1) * sizeof(int64_t)))) {
+        drop();
+        return rc;
+    }
+    hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                       (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p, tile_shift);
+    hipError_t e = hipGetLastError();
+    // two-byte entries where every count is at most 7 (toys of sparse expectations), four-byte entries otherwise: the first
+    // format is tried, and a count that does not fit sends the build to the second
+    ok = false;
+    for (int width = c->dot_entry16 ? 2 : 4; e == hipSuccess && !ok; width = 4) {
+        const int group = 16 / width;
+        const size_t n_entries = (size_t)(nnz + (group - 1) * cells + kDotPad);     // (every run padded to whole 16-byte groups; + the kernel's read-ahead)
+        if ((rc = dev_alloc(c, entries, n_entries * width))) { drop(); return rc; }
+        e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
+        // (two-byte entries: 13 bits of offset -- tiles of 8192 bins use them all, their padding is entry 0, dropped by a select on
+        //  the count; tiles of up to 4096 bins leave the bit for the offset of the extra zero slot behind the tile, as four-byte
+        //  entries have it)
+        if (e == hipSuccess && width == 2 && tile_bins > 4096) e = hipMemsetAsync(entries.p, 0, n_entries * 2, c->stream);
+        if (e == hipSuccess && width == 2 && tile_bins <= 4096) e = hipMemsetD16Async((hipDeviceptr_t)entries.p, (unsigned short)pad_entry, n_entries, c->stream);
+        if (e == hipSuccess && width == 4) e = hipMemsetD32Async((hipDeviceptr_t)entries.p, (int)pad_entry, n_entries, c->stream);
+        hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
+                           n_tl, (int64_t*)d_cnt.p, group);
+        size_t tb = d_tmp.bytes;
+        if (e == hipSuccess) e = prim_exclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)off.p, (int64_t)0, (size_t)(cells + 1), c->stream);
+        if (width == 2)
+            hipLaunchKernelGGL((k_tm_scatter<uint16_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                               (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
+                               (const int64_t*)off.p, (uint16_t*)entries.p, (int*)d_bad.p, tile_shift);
+        else
+            hipLaunchKernelGGL((k_tm_scatter<uint32_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
+                               (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
+                               (const int64_t*)off.p, (uint32_t*)entries.p, (int*)d_bad.p, tile_shift);
+        int bad = 0;
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) break;
+        ok = bad == 0;
+        width_out = width;
+        if (width == 4) break;
+    }
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets (tile-major lists): %s", hipGetErrorString(e));
+    if (!ok) { dev_free(entries); dev_free(off); }
+    return BI_OK;
+}
+
 // out_dev != NULL: results stay in HBM at out_dev[0 .. t1 - t0) (the call still returns after the stream has drained:
 // its descriptors travel through the context's pinned staging block, which the next call reuses)
 int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
@@ -1049,55 +1114,7 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
     bool tiled = csr && c->dot_tiled && n >= 64 && n_tl >= 4 && c->h_nz_off.size() == (size_t)c->T + 1 &&
                  c->h_nz_off.back() >= (int64_t)16 * c->T * n_tl && (int64_t)c->T * (n_tl + 1) <= ((int64_t)1 << 28);
     if (tiled && c->nz_tile_epoch != c->epoch) {
-        const int64_t nnz = c->h_nz_off.back(), cells = (int64_t)n_tl * c->T;
-        DevBuf d_tile, d_cnt, d_tmp, d_bad;
-        auto drop = [&]() { dev_free(d_tile); dev_free(d_cnt); dev_free(d_tmp); dev_free(d_bad); };
-        size_t scan_bytes = 0;
-        (void)prim_exclusive_scan_sum(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(cells + 1), c->stream);
-        if ((rc = dev_alloc(c, d_tile, (size_t)c->T * (n_tl + 1) * sizeof(int32_t))) || (rc = dev_alloc(c, d_cnt, (size_t)(cells + 1) * sizeof(int64_t))) ||
-            (rc = dev_alloc(c, d_tmp, std::max<size_t>(scan_bytes, 256))) || (rc = dev_alloc(c, d_bad, 64)) ||
-            (rc = dev_alloc(c, c->tm_off, (size_t)(cells + 1) * sizeof(int64_t)))) {
-            drop();
-            return rc;
-        }
-        hipLaunchKernelGGL(k_csr_tile_offsets, dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
-                           (const int64_t*)c->nz_off.p, n_tl, (int32_t*)d_tile.p);
-        hipError_t e = hipGetLastError();
-        // two-byte entries where every count is at most 7 (toys of sparse expectations), four-byte entries otherwise: the first
-        // format is tried, and a count that does not fit sends the build to the second
-        c->tm_ok = false;
-        for (int width = c->dot_entry16 ? 2 : 4; e == hipSuccess && !c->tm_ok; width = 4) {
-            const int group = 16 / width;
-            const size_t n_entries = (size_t)(nnz + (group - 1) * cells + kDotPad);     // (every run padded to whole 16-byte groups; + the kernel's read-ahead)
-            if ((rc = dev_alloc(c, c->tm_entries, n_entries * width))) { drop(); return rc; }
-            e = hipMemsetAsync(d_bad.p, 0, 64, c->stream);
-            if (e == hipSuccess && width == 2) e = hipMemsetAsync(c->tm_entries.p, 0, n_entries * 2, c->stream);
-            if (e == hipSuccess && width == 4) e = hipMemsetD32Async((hipDeviceptr_t)c->tm_entries.p, (int)kTmPadEntry, n_entries, c->stream);
-            hipLaunchKernelGGL(k_tm_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_tile.p, c->T,
-                               n_tl, (int64_t*)d_cnt.p, group);
-            size_t tb = d_tmp.bytes;
-            if (e == hipSuccess) e = prim_exclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_cnt.p, (int64_t*)c->tm_off.p, (int64_t)0, (size_t)(cells + 1), c->stream);
-            if (width == 2)
-                hipLaunchKernelGGL((k_tm_scatter<uint16_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
-                                   (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
-                                   (const int64_t*)c->tm_off.p, (uint16_t*)c->tm_entries.p, (int*)d_bad.p);
-            else
-                hipLaunchKernelGGL((k_tm_scatter<uint32_t>), dim3((unsigned)c->T), dim3(kThreads), 0, c->stream, (const int32_t*)c->nz_idx.p,
-                                   (const double*)c->nz_n.p, (const int64_t*)c->nz_off.p, (const int32_t*)d_tile.p, c->T, n_tl,
-                                   (const int64_t*)c->tm_off.p, (uint32_t*)c->tm_entries.p, (int*)d_bad.p);
-            int bad = 0;
-            if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) break;
-            c->tm_ok = bad == 0;
-            c->tm_width = width;
-            if (width == 4) break;
-        }
-        if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);
-        drop();
-        if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_datasets (tile-major lists): %s", hipGetErrorString(e));
-        if (!c->tm_ok) { dev_free(c->tm_entries); dev_free(c->tm_off); }
+        if ((rc = build_tile_major(c, kDotTile, c->tm_entries, c->tm_off, c->tm_ok, c->tm_width))) return rc;
         c->nz_tile_epoch = c->epoch;
     }
     tiled = tiled && c->tm_ok;
@@ -1243,7 +1260,22 @@ int eval_datasets_impl(bi_ctx* c, const double* z, const double* rate_scale, int
 
 }  // namespace
 
+#include "bi_toy_points.h"
+
 extern "C" {
+
+int bi_eval_datasets_points(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
+                            int32_t* status) {
+    if (!c) return BI_ERR_INVALID;
+    return eval_datasets_points_impl(c, P, z, rate_scale, t0, t1, out, nullptr, status);
+}
+
+int bi_eval_datasets_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
+                                   double* out_dev, int32_t* status) {
+    if (!c) return BI_ERR_INVALID;
+    if (P > 0 && t1 > t0 && !out_dev) return fail(c, BI_ERR_INVALID, "out_dev is NULL");
+    return eval_datasets_points_impl(c, P, z, rate_scale, t0, t1, nullptr, out_dev, status);
+}
 
 int bi_eval_datasets(bi_ctx* c, const double* z, const double* rate_scale, int64_t t0, int64_t t1, double* out,
                      int32_t* status) {

@@ -357,6 +357,25 @@ class DeviceContext:
                                                       ptr(status)))
         return int(status[0])
 
+    def eval_datasets_points(self, z, rate_scale=None, t0=0, t1=None):
+        """P parameter points against datasets [t0, t1) in one call (the toy-MC form over several hypotheses: the points of a
+        pass share the passes over the templates and over the datasets' lists) -> (ll [P, t1 - t0], status [P])."""
+        t1 = self.T if t1 is None else int(t1)
+        P, z, rate_scale, _ = self._point_args(z, rate_scale, None)
+        out = np.empty((P, max(t1 - int(t0), 0)), dtype=np.float64)
+        status = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.bi_eval_datasets_points(self._h, P, ptr(z), ptr(rate_scale), int(t0), t1, ptr(out), ptr(status)))
+        return out, status
+
+    def eval_datasets_points_device(self, out_ptr, z, rate_scale=None, t0=0, t1=None):
+        """eval_datasets_points with the [P, t1 - t0] result left in HBM at device address `out_ptr` -> status [P]."""
+        t1 = self.T if t1 is None else int(t1)
+        P, z, rate_scale, _ = self._point_args(z, rate_scale, None)
+        status = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.bi_eval_datasets_points_device(self._h, P, ptr(z), ptr(rate_scale), int(t0), t1, C.c_void_p(out_ptr),
+                                                             ptr(status)))
+        return status
+
     def interpolate(self, which, z):
         """which: 'ps' -> [S, B], 'mus' -> [S], 'n_model' -> [B] (the Beeston-Barlow source row)."""
         code = {'ps': 0, 'mus': 1, 'n_model': 2}[which]

@@ -14,7 +14,7 @@ import numpy as np
 from ._capi import ST_INTERNAL
 from .exceptions import DeviceError
 
-__all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys',
+__all__ = ['split_range', 'deal_points_by_cell', 'gather_vector', 'sharded_eval_points', 'sharded_eval_toys', 'sharded_eval_toys_points',
            'sharded_scan_device', 'allreduce_sum', 'bin_sharded_eval']
 
 
@@ -221,6 +221,28 @@ def sharded_eval_toys(eval_range_fn, T, comm=None):
     t0, t1 = ranges[rank]
     local = np.asarray(eval_range_fn(t0, t1), dtype=np.float64) if t1 > t0 else np.zeros(0)
     return np.concatenate(gather_vector(local, [b - a for a, b in ranges], comm))
+
+
+def sharded_eval_toys_points(eval_points_fn, anchor_z, z, rate_scale, T, comm=None):
+    """Toy-MC over several hypotheses: every rank holds ALL T datasets (each draws the whole ensemble: the toys are numbered
+    globally, so N ranks hold the same toys) and the P HYPOTHESES are dealt to the ranks by grid cell -- the hypotheses of a
+    cell share the pass over its templates and, four at a time, the pass over the datasets' lists (bi_eval_datasets_points), so
+    a rank's call stays as efficient as one process's; splitting the DATASETS of one hypothesis instead makes every rank repeat
+    the whole log mu pass.  eval_points_fn(z_local [n, d], rate_local [n, S]) -> ll [n, T].  One gather of n_max * T doubles
+    per rank.  Returns ll [P, T] on every rank.  (The reference: the double loop of blueice/inference.py:392-443 over
+    hypotheses and simulated datasets, blueice/model.py:69-91.)"""
+    z = np.atleast_2d(np.asarray(z, dtype=float))
+    rate_scale = np.atleast_2d(np.asarray(rate_scale, dtype=float))
+    rank, world = _world(comm)
+    P, T = len(z), int(T)
+    deal = deal_points_by_cell(anchor_z, z, world)
+    mine = deal[rank]
+    local = np.asarray(eval_points_fn(z[mine], rate_scale[mine]), dtype=np.float64).reshape(len(mine), T) if len(mine) else np.zeros((0, T))
+    parts = gather_vector(local.ravel(), [len(d) * T for d in deal], comm)
+    out = np.empty((P, T))
+    for idx, vals in zip(deal, parts):
+        out[idx] = vals.reshape(len(idx), T)
+    return out
 
 
 def allreduce_sum(local, comm=None):

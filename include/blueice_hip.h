@@ -257,6 +257,23 @@ int bi_eval_datasets(bi_ctx* ctx, const double* z, const double* rate_scale, int
 int bi_eval_datasets_device(bi_ctx* ctx, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
                             double* out_dev, int32_t* status /*[1] or NULL*/);
 
+/* The toy-MC form over SEVERAL parameter points: P hypotheses against datasets [t0, t1) in one call -- what the reference's
+ * toy-MC users run as a double loop, every simulated dataset (blueice/model.py:69-91 + set_data) evaluated at every hypothesis
+ * (the loops of blueice/inference.py:392-443), P x T likelihood calls.  Here the points are ordered by grid cell and taken four
+ * at a time: the points of a pass that share a grid cell share one pass over its 2^d S template rows (hypotheses that differ
+ * in their rates only always do), and ONE pass over the datasets' non-empty-bin lists serves all four -- their log mu tiles sit
+ * side by side in LDS.  Same values as P calls of bi_eval_datasets to rounding (the partial sums are grouped by tiles of 4096
+ * instead of 8192 bins); every result is a sum in a fixed order, so a call is bitwise reproducible.
+ *   z [P][d], rate_scale [P][S] or NULL; out [P][t1 - t0], row p = point p; status [P] or NULL: a point outside the anchor box
+ *   or with unphysical rates has BI_ST_OUT_OF_BOUNDS / BI_ST_UNPHYSICAL and a row of -inf (likelihood.py:345-347, 397-415).
+ * Data that the multi-point kernels do not cover (dense counts only, fewer than 64 datasets, counts that fit no list format)
+ * are answered point by point through bi_eval_datasets; not available with Beeston-Barlow.  P <= 65535.
+ * _device: out_dev [P][t1 - t0] in HBM (the send buffer of a gather when the hypotheses are dealt over GPUs). */
+int bi_eval_datasets_points(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
+                            double* out, int32_t* status /*[P] or NULL*/);
+int bi_eval_datasets_points_device(bi_ctx* ctx, int64_t P, const double* z, const double* rate_scale, int64_t t0, int64_t t1,
+                                   double* out_dev, int32_t* status /*[P] or NULL*/);
+
 /* ---- compatibility mode: materialise what the morpher closures return ---------------------
  * `ps_interpolator(zs)` / `mus_interpolator(zs)` / `n_model_events_interpolator(zs)`
  * (pdf_morphers.py:70) and `full_output=True` (likelihood.py:424-425).
@@ -394,6 +411,10 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     by histogram cell before their densities are gathered, so the gathers stream through the histograms; the
  *                     tensor's columns are then in that order, which only sums over events can see -- bi_interpolate and
  *                     bi_eval_full return per-event values in the caller's order (1, default; read-only `events_sorted`)
+ *   toy_points_pp     bi_eval_datasets_points: parameter points per pass over the datasets' lists: 0 = by the batch (4; 2 for a
+ *                     call of two points), 2, 4, or 1 = point by point through bi_eval_datasets.  toy_points_lanes: lanes per
+ *                     (dataset, tile) run of its kernel, 0 = the measured default, or 2 / 4 / 8.  Read-only n_toy_points_passes
+ *                     (passes made so far) and tmm_entry_bytes (entry width of the 4096-bin tile lists as built, 0 = none)
  *   toy_fast_call     bi_eval_datasets, bits: 1 = the point's descriptors travel in the kernel arguments (no copy ahead of the launch),
  *                     2 = the tiled kernel's partial sums are finished 64 datasets per block, tiles split over its four waves,
  *                     4 = results of up to 4 MB: the call polls a completion word behind them instead of synchronising the

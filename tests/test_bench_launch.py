@@ -72,6 +72,43 @@ def test_host_threads_are_shared_among_the_ranks():
     assert abs(pc3['evals_per_s']['1'] - 1e4 / 0.14e-3) < 1e-3
 
 
+def _fake_rccl(tmp_path):
+    """tests/native/fake_rccl.c as a shared library: the entry points blueice_amd/comm.py binds, no GPU behind them."""
+    so = str(tmp_path / 'libfake_rccl.so')
+    res = subprocess.run(['gcc', '-O1', '-shared', '-fPIC', '-Wall', '-Werror', '-o', so, os.path.join(ROOT, 'tests', 'native', 'fake_rccl.c')],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return so
+
+
+def test_the_line_says_what_rccl_saw(tmp_path):
+    """The first 8-GPU run must verify itself ("Next round" 6): the line carries the number of ranks RCCL
+    itself reports (ncclCommCount), every rank's GPU as RCCL sees it (ncclCommCuDevice), the gather that ran and the reason for
+    a fallback; and `--backend rccl` given explicitly ends non-zero when the socket fallback had to be taken."""
+    so = _fake_rccl(tmp_path)
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--dry', '--backend', 'rccl'], env=_clean_env(BLUEICE_AMD_RCCL=so),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cfg = _json_line(res.stdout)['config']
+    assert cfg['backend_requested'] == 'rccl' and cfg['gather_kind'] == 'rccl' and cfg['rccl_ranks'] == 4
+    assert cfg['rank_devices'] == [0, 1, 2, 3] and cfg['rank_devices_source'] == 'ncclCommCuDevice'
+    assert cfg['gather_fallback_reason'] is None and cfg['rccl_version'] == 99999
+    # ncclCommInitRank fails on one rank: every rank falls back together, the line says why -- and the command fails,
+    # because RCCL was asked for by name
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry', '--backend', 'rccl'],
+                         env=_clean_env(BLUEICE_AMD_RCCL=so, FAKE_RCCL_INIT='fail', FAKE_RCCL_BAD_RANK='1'), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 4, (res.returncode, res.stderr[-2000:])
+    cfg = _json_line(res.stdout)['config']
+    assert cfg['gather_kind'] == 'socket' and cfg['rccl_ranks'] is None and 'ncclCommInitRank failed' in cfg['gather_fallback_reason']
+    assert cfg['rank_devices'] == [0, 1] and cfg['rank_devices_source'] == 'launcher'
+    # the same failure without --backend: the agreed fallback is allowed, the line still says it happened
+    res = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry'],
+                         env=_clean_env(BLUEICE_AMD_RCCL=so, FAKE_RCCL_INIT='fail', FAKE_RCCL_BAD_RANK='1'), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cfg = _json_line(res.stdout)['config']
+    assert cfg['gather_kind'] == 'socket' and 'ncclCommInitRank failed' in cfg['gather_fallback_reason']
+
+
 def test_a_failing_rank_fails_the_command():
     """Without a GPU every rank dies in DeviceContext(): the command must end non-zero and say why -- never print a line."""
     try:

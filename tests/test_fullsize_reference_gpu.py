@@ -125,6 +125,46 @@ def test_c3_ten_thousand_toys(c2):
         ctx.eval(z_eval, r, dataset=[17])
 
 
+def test_c3_ten_thousand_toys_at_several_hypotheses(c2):
+    """configs[2] over several parameter points in ONE call (bi_eval_datasets_points; the reference's double loop of
+    blueice/inference.py:392-443 around blueice/model.py:69-91): 10^4 device-drawn toys x 6 hypotheses -- four rate hypotheses
+    in one grid cell (one shared pass over its templates), two more in other cells -- against the oracle on fetched toys and
+    against the single-point call."""
+    from oracle import blueice_oracle as orc
+    m, ctx = c2
+    T = 10000
+    z, r = m.default_point()
+    ctx.set_param('sparse', 1)
+    ctx.generate_toys(z, r, T, seed=2025)
+    P = 6
+    zs = np.repeat(z[None, :], P, axis=0)
+    rs = np.repeat(r[None, :], P, axis=0)
+    rs[:4, 0] *= (0.5, 1.0, 1.5, 2.0)                       # a signal-strength scan: same cell
+    zs[4] = np.clip(z + 0.9, -2, 2)                          # two more hypotheses in other cells
+    zs[5] = np.clip(z - 1.1, -2, 2)
+    before = ctx.get_param('n_toy_points_passes')
+    ll, st = ctx.eval_datasets_points(zs, rs)
+    assert ctx.get_param('n_toy_points_passes') == before + 2 and ctx.get_param('tmm_entry_bytes') == 2
+    assert ll.shape == (P, T) and not st.any() and np.all(np.isfinite(ll))
+    picks = [0, 1, 2500, 4999, 7777, T - 1]
+    fetched = {t: ctx.download_counts(t) for t in picks}
+    for p in range(P):
+        cell = m.cell_model(zs[p])
+        for t in picks:
+            want = orc.loglikelihood(cell, fetched[t], zs[p], rs[p])
+            assert abs(ll[p, t] - want) <= RTOL * abs(want), (p, t, ll[p, t], want)
+    for p in (0, 3, 5):
+        one, _ = ctx.eval_datasets(zs[p], rs[p])
+        np.testing.assert_allclose(ll[p], one, rtol=1e-13, atol=0)
+    part, _ = ctx.eval_datasets_points(zs, rs, 1200, 9100)
+    np.testing.assert_array_equal(part, ll[:, 1200:9100])
+    buf = ctx.device_alloc(8 * P * T)
+    st_dev = ctx.eval_datasets_points_device(buf.ptr, zs, rs)
+    assert not st_dev.any()
+    np.testing.assert_array_equal(buf.to_host(np.float64, P * T).reshape(P, T), ll)
+    buf.free()
+
+
 @pytest.mark.parametrize('sparse', [1, 0])
 def test_c4_million_point_scan(c2, sparse):
     """configs[3] on one GPU: 10^6 parameter points over the C2 model in one call (device planner; non-empty-bin form,

@@ -135,6 +135,56 @@ def test_two_ranks_equal_single_process(kind, tmp_path):
         assert blob == b'id-of-rank-0'
 
 
+def _toy_points_worker(kind, rank, world, port, rdzv, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from blueice_amd.sharding import sharded_eval_toys_points
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    comm = _comm(kind, rank, world, port, rdzv)
+    try:
+        m = SyntheticModel.named('mini3')
+        dense = m.dense_model()
+        toys = np.stack([m.counts(dense=True, dataset=t) for t in range(6)])
+        z, r = m.random_points(11, seed=9)
+        z[4:8] = z[3]                                      # five hypotheses that differ in their rates only: one grid cell
+        seen = []
+
+        def eval_points(zz, rr):                           # the oracle in the role of bi_eval_datasets_points: -> [n, T]
+            seen.append(zz.copy())
+            return np.stack([orc.loglikelihood_batch(dense, toys, np.tile(zz[i], (6, 1)), np.tile(rr[i], (6, 1)), dataset=np.arange(6))
+                             for i in range(len(zz))])
+
+        out = sharded_eval_toys_points(eval_points, m.anchor_z, z, r, 6, comm)
+        q.put((rank, out, np.concatenate(seen) if seen else np.zeros((0, m.d))))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize('kind', ['socket', 'gloo'])
+def test_toy_hypotheses_dealt_over_two_ranks(kind, tmp_path):
+    """The multi-hypothesis toy-MC call sharded over ranks ("Next round" 1): every rank holds all datasets, the
+    HYPOTHESES are dealt by grid cell, one gather of [n, T] blocks -- every rank ends with the full [P, T] matrix, each hypothesis
+    was evaluated exactly once, and the hypotheses of one cell went to one rank."""
+    from blueice_amd.sharding import cell_ids
+    from blueice_amd.synthetic import SyntheticModel
+    from oracle import blueice_oracle as orc
+    got = sorted(_run_ranks(_toy_points_worker, kind, 2, tmp_path), key=lambda g: g[0])
+    m = SyntheticModel.named('mini3')
+    dense = m.dense_model()
+    toys = np.stack([m.counts(dense=True, dataset=t) for t in range(6)])
+    z, r = m.random_points(11, seed=9)
+    z[4:8] = z[3]
+    want = np.stack([orc.loglikelihood_batch(dense, toys, np.tile(z[i], (6, 1)), np.tile(r[i], (6, 1)), dataset=np.arange(6)) for i in range(11)])
+    for rank, out, _ in got:
+        np.testing.assert_array_equal(out, want)
+    evaluated = np.concatenate([g[2] for g in got])
+    assert len(evaluated) == 11 and 4 <= len(got[0][2]) <= 7          # each exactly once, shares balanced
+    hot = cell_ids(m.anchor_z, z[3:4])[0]
+    owners = [rank for rank, _, zs in got if len(zs) and (cell_ids(m.anchor_z, zs) == hot).any()]
+    assert len(owners) == 1                                            # the rate scan of one cell stays on one rank
+
+
 def test_three_socket_ranks(tmp_path):
     """An odd world size through the package's own communicator (unequal shares, star gather)."""
     from blueice_amd.synthetic import SyntheticModel

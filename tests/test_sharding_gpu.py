@@ -113,6 +113,11 @@ ctx = DeviceContext(0)
 comm = connect(ctx, backend='rccl', rank=0, world=1)
 assert comm.kind == 'rccl', getattr(comm, 'fallback_reason', '')
 print('RCCL version', comm.version)
+# the communicator's own account of itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): what a run reports
+assert (comm.n_ranks, comm.user_rank, comm.device) == (1, 0, 0), (comm.n_ranks, comm.user_rank, comm.device)
+from blueice_amd.comm import describe
+d = describe(comm, 'rccl')
+assert d['rccl_ranks'] == 1 and d['rank_devices'] == [0] and d['rank_devices_source'] == 'ncclCommCuDevice' and d['gather_fallback_reason'] is None, d
 m.upload(ctx)
 ctx.upload_counts(m.counts(dense=True))
 z, r = m.random_points(100, seed=8)
