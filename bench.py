@@ -287,7 +287,9 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     full = ranks.full_buffer(P) if device_deal else None
     seen = dict(bytes=0, share=[P, P])
 
-    def step(w, resident=None):
+    def step(w, resident=None, fetch=True):
+        """fetch = False: the full result vector stays in HBM (where a device-side consumer -- the batched fit engine, a reduction
+        -- reads it); only the plan's status word comes back.  The caller's own copy is one more D2H of 8 P bytes."""
         z, r = w
         if device_deal:
             # (host points: H2D of the points first)  geometry, sort, this rank's items
@@ -296,13 +298,13 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
             word = plan.status()
             recv = ranks.gather_on_device(stride)
             plan.unsort(recv.ptr, stride, full.ptr)
-            out = full.to_host(np.float64, P)
+            out = full.to_host(np.float64, P) if fetch else None
             seen['share'] = [plan.n_valid // world, -(-plan.n_valid // world)]
         elif world == 1:
             plan = ctx.plan_resident(P, resident[0], resident[1]) if resident else ctx.plan(z, r)
             plan.run(send.ptr)
             word = plan.status()
-            out = send.to_host(np.float64, P)
+            out = send.to_host(np.float64, P) if fetch else None
         else:
             deal = deal_points_by_cell(model.anchor_z, z, world)
             mine = deal[rank]
@@ -344,14 +346,25 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
         for w, h in zip(work[1:], held[1:]):
             out_res = step(w, h)
         ranks.barrier()
+        elapsed_fetch = ranks.max_over_ranks(time.perf_counter() - t0)
+        # ... and with the full vector LEFT in HBM on every rank (status word checked): inputs and outputs on the device, the
+        # form a device-side consumer of a scan sees -- the leg's `value`; the rate with the caller's own host copy beside it
+        step(work[0], held[0], fetch=False)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for w, h in zip(work[1:], held[1:]):
+            step(w, h, fetch=False)
+        ranks.barrier()
         elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+        kept = (full if device_deal else send).to_host(np.float64, P)
+        assert np.array_equal(kept, out_res), '%s: the vector left in HBM differs from the one fetched' % label
         if ctx.bb_source >= 0:      # (small Beeston-Barlow batches of host arrays are planned on the host: other item sizes, other block counts)
             assert np.allclose(out_res, out, rtol=1e-12, atol=0), '%s: resident points and host points disagree' % label
         else:
             assert np.array_equal(out_res, out), '%s: resident points and host points disagree' % label
     # where a step's time goes: one more step with HIP events around every kernel launch of this rank
     ctx.profile(True)
-    step(work[-1], held[-1] if can_reside else None)
+    step(work[-1], held[-1] if can_reside else None, fetch=not can_reside)
     _, kernel_ms = ctx.profile_read()
     ctx.profile(False)
     kernel_ms = ranks.max_over_ranks(kernel_ms)
@@ -370,8 +383,11 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     assert np.all(np.isfinite(out)), '%s: non-finite values in the gathered scan' % label
     return dict(workload=label, scaling='strong', points=P, steps=steps, value=P * steps / elapsed, unit='evals/s',
                 ms_per_step=elapsed / steps * 1e3,
-                inputs=('points resident in HBM when the clock starts (bi_plan_points_resident); results copied to the host inside' if can_reside
+                inputs=('points resident in HBM when the clock starts (bi_plan_points_resident); the full result vector is left in HBM on '
+                        'every rank, its status word read back' if can_reside
                         else 'host arrays (the device planner refused the batch: host planner, H2D inside the clock)'),
+                value_results_to_host=(P * steps / elapsed_fetch) if can_reside else None,
+                ms_per_step_results_to_host=(elapsed_fetch / steps * 1e3) if can_reside else None,
                 value_host_points=P * steps / elapsed_host, ms_per_step_host_points=elapsed_host / steps * 1e3,
                 points_per_rank_min_max=seen['share'],
                 dealing=('device planner sort, inside the step' if device_deal else

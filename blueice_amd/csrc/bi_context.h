@@ -43,6 +43,8 @@ struct bi_plan {
     int64_t n_groups = 0;
     int scan_cb = 4;              // its strip width in 16-bin blocks
     DevBuf grp_first, grp_items;
+    std::vector<int64_t> h_grp_first;   // host copies of cut group tables (device planner: their upload is asynchronous)
+    std::vector<int32_t> h_grp_items;
     bool valid = false;           // split dense scan: classes hold the non-empty-bin pass, k_scan_valid checks every bin
     int valid_nslots = 0;         // its waves per group
     DevBuf bad;                   // [items][16] flags it raises
@@ -169,6 +171,7 @@ struct bi_ctx {
     int64_t n_grad_mfma_launches = 0;
     int64_t scan_xcd = 1;                        // k_scan_sorted: how the (group, block) pairs are dealt to the 8 XCDs (0 launch order, 1 contiguous ranges, 2 group g -> XCD g mod 8)
     int64_t scan_share_slow = 1;                 // parameter: k_scan_sorted deals the items of mixed-count strips over all waves of the cell
+    int64_t scan_chunk = 1;                      // parameter: few groups with long item lists are cut into chunks of items, each a group of its own
     int64_t scan_waves_per_cu = 0;               // scan kernels: 0 = the planner sizes the split by occupancy; > 0 forces that many waves per CU
     int64_t keep_rows = -1;                      // single dense evaluations in a repeated cell: rows that keep the default cache policy (-1: as many as fit the Infinity Cache, 0: none)
     int64_t last_single_cell = -1, last_single_ds = -1;

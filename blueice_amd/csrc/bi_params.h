@@ -70,6 +70,7 @@ const ParamDef kParams[] = {
     {"grad_slices", kParamRW, BI_P_GET(c->grad_slices), BI_P_RANGE(0, 4096, grad_slices, "grad_slices in [0, 4096]")},
     {"scan_xcd", kParamRW, BI_P_GET(c->scan_xcd), BI_P_RANGE(0, 2, scan_xcd, "scan_xcd: 0 launch order, 1 contiguous ranges, 2 one XCD per group")},
     {"scan_share_slow", kParamRW, BI_P_GET(c->scan_share_slow), BI_P_FLAG(scan_share_slow)},
+    {"scan_chunk", kParamRW, BI_P_GET(c->scan_chunk), BI_P_FLAG(scan_chunk)},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},
     {"scan_split", kParamRW, BI_P_GET(c->scan_split), BI_P_FLAG(scan_split)},
     {"scan_pow", kParamRW, BI_P_GET(c->scan_pow), BI_P_SET(c->scan_pow = v ? 1 : 0; c->sorted_epoch = -1)},

@@ -108,68 +108,76 @@ struct PlanMeta {
     int bb_source;             // -1, or the Beeston-Barlow source: streams [corner][s != bb], then its ps rows, then the n_model rows
     const double* nm_tot;      // Beeston-Barlow: [A] per-anchor totals of the Monte-Carlo counts (N(z) is linear in the weights)
     const double* rowmin;      // [n_rows] smallest entry of every template row (can some bin have U_b == 0 at a point?)
+    uint64_t bad_key;          // the sort key of rejected points: A * T, one above every (cell, dataset) key -- the radix sort then
+                               // walks only the bits of A * T (C2: 7 of them, ONE pass instead of the eight of a 64-bit key)
 };
 
-constexpr uint64_t kBadKey = ~0ull;
+// The scalar half of likelihood.py:345-415 for ONE point: bounds, cell, the per-axis interpolation coordinates t [d], status.
+// Shared by k_plan_geometry (keys) and k_plan_fill (descriptors): the same operations in the same order, so what the second
+// kernel rebuilds is what the first one judged.
+__device__ __forceinline__ int32_t plan_point_cell(const PlanMeta& m, const double* __restrict__ zrow, int64_t zstride, int64_t ds,
+                                                   double (&t)[kMaxDim], int64_t& cell) {
+    cell = 0;
+    if (ds < 0 || ds >= m.T) return BI_ST_BAD_DATASET;
+    for (int i = 0; i < m.d; ++i) {
+        const double* g = m.grid + m.grid_off[i];
+        const int n = m.n_anchor[i];
+        const double zi = zrow[i * zstride];
+        if (!(g[0] <= zi && zi <= g[n - 1])) return BI_ST_OUT_OF_BOUNDS;
+        int k = 0;
+        double ti = 0.0;
+        if (n > 1) {
+            if (zi == g[n - 1]) {
+                k = n - 2;
+            } else {
+                while (k + 1 < n && g[k + 1] <= zi) ++k;   // last anchor with g[k] <= z
+                k = min(k, n - 2);
+            }
+            ti = (zi - g[k]) / (g[k + 1] - g[k]);
+        }
+        t[i] = ti;
+        cell += (int64_t)k * m.astride[i];
+    }
+    return 0;
+}
 
-// per point: bounds, cell, corner weights, rates, early exits (the scalar half of likelihood.py:345-415)
+// corner weight ((1 * w_0) * w_1) ... in itertools.product order (scipy's _evaluate_linear)
+__device__ __forceinline__ double plan_corner_weight(const PlanMeta& m, const double (&t)[kMaxDim], int corner) {
+    double wc = 1.0;
+    for (int i = 0; i < m.de; ++i) {
+        const double ti = t[m.eff_axes[i]];
+        wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? ti : (1 - ti));
+    }
+    return wc;
+}
+
+// per point: status and sort key.  Weights and rates are NOT written out (round 4 wrote 96 bytes per point here and gathered
+// them back through the sort's permutation in k_plan_fill: 0.3 of that kernel's 0.5 ms): the fill kernel rebuilds them from
+// the point's 56 bytes of z and rate_scale.
 __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t P, const double* __restrict__ z,
                                                             const double* __restrict__ rate_scale,
                                                             const int64_t* __restrict__ dataset,
-                                                            double* __restrict__ wts, double* __restrict__ rates,
                                                             uint64_t* __restrict__ keys, int64_t* __restrict__ idx,
                                                             int32_t* __restrict__ status, unsigned long long* __restrict__ n_inf) {
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (p >= P) return;
     idx[p] = p;
-    int32_t st = 0;
     const int64_t ds = dataset ? dataset[p] : 0;
-    if (ds < 0 || ds >= m.T) st = BI_ST_BAD_DATASET;
     double t[kMaxDim];
     int64_t cell = 0;
+    int32_t st = plan_point_cell(m, z + p * m.d, 1, ds, t, cell);
     if (!st) {
-        for (int i = 0; i < m.d; ++i) {
-            const double* g = m.grid + m.grid_off[i];
-            const int n = m.n_anchor[i];
-            const double zi = z[p * m.d + i];
-            if (!(g[0] <= zi && zi <= g[n - 1])) { st = BI_ST_OUT_OF_BOUNDS; break; }
-            int k = 0;
-            double ti = 0.0;
-            if (n > 1) {
-                if (zi == g[n - 1]) {
-                    k = n - 2;
-                } else {
-                    while (k + 1 < n && g[k + 1] <= zi) ++k;   // last anchor with g[k] <= z
-                    k = min(k, n - 2);
-                }
-                ti = (zi - g[k]) / (g[k + 1] - g[k]);
-            }
-            t[i] = ti;
-            cell += (int64_t)k * m.astride[i];
-        }
-    }
-    if (!st) {
-        double* w = wts + p * m.nc;
-        for (int corner = 0; corner < m.nc; ++corner) {
-            double wc = 1.0;
-            for (int i = 0; i < m.de; ++i) {
-                const double ti = t[m.eff_axes[i]];
-                wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? ti : (1 - ti));
-            }
-            w[corner] = wc;
-        }
-        double* r = rates + p * m.S;
-        bool any_fin = false, phys = true;
+        bool any_fin = false, phys = true, inf_rate = false;
         double tot = 0.0;
         for (int s = 0; s < m.S; ++s) {
             double v = 0.0;
             for (int corner = 0; corner < m.nc; ++corner) {
-                const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * w[corner];
+                const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * plan_corner_weight(m, t, corner);
                 v = v + term;
             }
             if (rate_scale) v *= rate_scale[p * m.S + s];
-            r[s] = v;
             any_fin |= (v < __builtin_inf());
+            inf_rate |= (v == __builtin_inf() || v == -__builtin_inf());
             tot += v;
             if (!m.any_allow_neg) { if (!(v >= 0 && v < __builtin_inf())) phys = false; }
             else if (!(0 <= v) && !m.allow_neg[s]) phys = false;
@@ -178,21 +186,19 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
         if (!phys) st = BI_ST_UNPHYSICAL;
         // an infinite rate that passes (a source may go negative: likelihood.py:403-415) is answered on the host, the way
         // the reference evaluates it (inf_rate_value): such a batch is not for this planner
-        if (phys && m.any_allow_neg && n_inf)
-            for (int s = 0; s < m.S; ++s)
-                if (r[s] == __builtin_inf() || r[s] == -__builtin_inf()) { atomicAdd(n_inf, 1ull); break; }
+        if (phys && m.any_allow_neg && n_inf && inf_rate) atomicAdd(n_inf, 1ull);
     }
     status[p] = st;
-    keys[p] = st ? kBadKey : (uint64_t)(cell * m.T + ds);
+    keys[p] = st ? m.bad_key : (uint64_t)(cell * m.T + ds);
 }
 
 // number of valid (sorted-to-the-front) points
-__global__ void k_plan_count_valid(const uint64_t* __restrict__ keys, int64_t P, int64_t* __restrict__ out) {
+__global__ void k_plan_count_valid(const uint64_t* __restrict__ keys, int64_t P, uint64_t bad_key, int64_t* __restrict__ out) {
     if (threadIdx.x || blockIdx.x) return;
-    int64_t lo = 0, hi = P;   // first index with key == kBadKey
+    int64_t lo = 0, hi = P;   // first index with the key of rejected points
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] != kBadKey) lo = mid + 1; else hi = mid;
+        if (keys[mid] != bad_key) lo = mid + 1; else hi = mid;
     }
     out[0] = lo;
 }
@@ -207,38 +213,79 @@ __global__ __launch_bounds__(kThreads) void k_plan_item_heads(const int64_t* __r
     if (i < n) ihead[i] = ((i - gstart[i]) % G == 0) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ keys,
-                                                        const int64_t* __restrict__ idx, const int64_t* __restrict__ gstart,
-                                                        const int64_t* __restrict__ item_incl, const double* __restrict__ wts,
-                                                        const double* __restrict__ rates, int64_t* __restrict__ rowoff,
-                                                        double* __restrict__ coef, int64_t* __restrict__ cnt_off,
-                                                        int32_t* __restrict__ tiles, int64_t* __restrict__ perm,
-                                                        double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum,
-                                                        int64_t* __restrict__ rowoff_full /* split scans, else NULL */,
-                                                        double* __restrict__ aux /* Beeston-Barlow: [items][G][2], else NULL */,
-                                                        unsigned long long* __restrict__ n_zero_u /* Beeston-Barlow, else NULL */) {
+// One thread per sorted position.  The block first fetches its points' z and rate_scale rows TOGETHER into LDS -- lanes walk the
+// (point, component) pairs, so the d (or S) doubles of a point are fetched by adjacent lanes and a load instruction touches a
+// third (a quarter) of the lines it would with one point per lane --, every thread then rebuilds its point's corner weights and
+// rates there ([index][thread]: dynamic indices without scratch, no bank conflicts), and writes the descriptors: the
+// coefficients of an item are [stream][slot], so the 16 threads of an item write whole 128-byte lines.  Padding slots of a
+// group's last item are written here too (perm = -1, a copy of the last point's coefficients): no memset precedes the kernel.
+// LDS doubles per thread: d + S (inputs) + nc (weights) + S (rates).
+__global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ keys,
+                            const int64_t* __restrict__ idx, const int64_t* __restrict__ gstart,
+                            const int64_t* __restrict__ item_incl, const double* __restrict__ z,
+                            const double* __restrict__ rate_scale, int64_t* __restrict__ rowoff,
+                            double* __restrict__ coef, int64_t* __restrict__ cnt_off,
+                            int32_t* __restrict__ tiles, int64_t* __restrict__ perm,
+                            double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum,
+                            int64_t* __restrict__ rowoff_full /* split scans, else NULL */,
+                            double* __restrict__ aux /* Beeston-Barlow: [items][G][2], else NULL */,
+                            unsigned long long* __restrict__ n_zero_u /* Beeston-Barlow, else NULL */) {
     // (the items' tile counts are summed per block first: one atomic per work item on ONE address -- 62 500 of them for a
     //  10^6-point scan -- was half of this kernel's 0.5 ms)
     __shared__ unsigned long long s_tiles;
-    if (threadIdx.x == 0) s_tiles = 0ull;
+    extern __shared__ double s_pf[];
+    const int BD = blockDim.x, tx = threadIdx.x;
+    double* __restrict__ s_z = s_pf;                              // [d][BD]
+    double* __restrict__ s_rs = s_z + (size_t)m.d * BD;            // [S][BD]   rate scales, then the rates
+    double* __restrict__ s_w = s_rs + (size_t)m.S * BD;            // [nc][BD]
+    int64_t* __restrict__ s_idx = reinterpret_cast<int64_t*>(s_w + (size_t)m.nc * BD);   // [BD]
+    if (tx == 0) s_tiles = 0ull;
+    const int64_t i0 = (int64_t)blockIdx.x * BD;
+    const int64_t i = i0 + tx;
+    const int live = (int)min<int64_t>(BD, n - i0);              // sorted positions of this block
+    if (tx < live) s_idx[tx] = idx[i];
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    for (int e = tx; e < live * m.d; e += BD) {
+        const int q = e / m.d, comp = e - q * m.d;
+        s_z[comp * BD + q] = z[s_idx[q] * m.d + comp];
+    }
+    for (int e = tx; e < live * m.S; e += BD) {
+        const int q = e / m.S, comp = e - q * m.S;
+        s_rs[comp * BD + q] = rate_scale ? rate_scale[s_idx[q] * m.S + comp] : 1.0;
+    }
+    __syncthreads();
     [&]() {
     if (i >= n) return;
-    const int64_t p = idx[i];
+    const int64_t p = s_idx[tx];
     const int G = m.G;
     const int g = (int)((i - gstart[i]) % G);
     const int64_t item = item_incl[i] - 1;
     const bool last_of_group = i + 1 == n || gstart[i + 1] == i + 1;
-    const int64_t ds = (int64_t)(keys[i] % (uint64_t)m.T), cell = (int64_t)(keys[i] / (uint64_t)m.T);
+    const int64_t ds = (int64_t)(keys[i] % (uint64_t)m.T);
     const bool bb = m.bb_source >= 0;
     const int n0 = bb ? m.nc * (m.S - 1) : m.nc * m.S;
     const int NS = bb ? n0 + 2 * m.nc : n0;
     const int64_t row_stride = m.sparse ? m.c_np[ds] : m.Bp;
     const int64_t row_base = m.sparse ? m.c_off[ds] : 0;
-    const double* w = wts + p * m.nc;
-    const double* r = rates + p * m.S;
-    double zsum = 0.0, rsum = 0.0;
+    // the point's geometry again (plan_point_cell: what k_plan_geometry judged valid), weights and rates into LDS
+    double t[kMaxDim];
+    int64_t cell = 0;
+    (void)plan_point_cell(m, s_z + tx, BD, ds, t, cell);
+    for (int corner = 0; corner < m.nc; ++corner) s_w[corner * BD + tx] = plan_corner_weight(m, t, corner);
+    double rsum = 0.0;
+    for (int s = 0; s < m.S; ++s) {
+        double v = 0.0;
+        for (int corner = 0; corner < m.nc; ++corner) {
+            const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * s_w[corner * BD + tx];
+            v = v + term;
+        }
+        if (rate_scale) v *= s_rs[s * BD + tx];
+        s_rs[s * BD + tx] = v;
+        rsum += v;
+    }
+#define W_(c) s_w[(c) * BD + tx]
+#define R_(s) s_rs[(s) * BD + tx]
+    double zsum = 0.0;
     // the unused slots of a group's last work item repeat its last point (their results are dropped: perm = -1): with
     // coefficients of zero their expectations would be zero, and the product forms of the scan kernels would have to leave
     // their fast path for the whole item
@@ -246,11 +293,11 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
     int k = 0;
     for (int corner = 0; corner < m.nc; ++corner) {
         const int64_t a = cell + m.corner_off[corner];
-        const double wc = w[corner];
+        const double wc = W_(corner);
 #pragma unroll 4
         for (int s = 0; s < m.S; ++s) {                     // (unrolled: the Tz loads of a corner go out together)
             if (bb && s == m.bb_source) continue;
-            const double cf = wc * r[s];
+            const double cf = wc * R_(s);
             const double tz = m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0);
             for (int gg = g; gg < g_end; ++gg) coef[(item * NS + k) * G + gg] = cf;
             if (m.sparse || m.linear_outside) zsum += cf * tz;
@@ -268,35 +315,36 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
         for (int corner = 0; corner < m.nc; ++corner) {
             const int64_t a = cell + m.corner_off[corner];
             for (int gg = g; gg < g_end; ++gg) {
-                coef[(item * NS + n0 + corner) * G + gg] = w[corner];
-                coef[(item * NS + n0 + m.nc + corner) * G + gg] = w[corner];
+                coef[(item * NS + n0 + corner) * G + gg] = W_(corner);
+                coef[(item * NS + n0 + m.nc + corner) * G + gg] = W_(corner);
             }
             if (g == 0) {
                 rowoff[item * NS + n0 + corner] = (a * m.S + m.bb_source) * m.Bp;
                 rowoff[item * NS + n0 + m.nc + corner] = a * m.Bp;
             }
-            const double term = m.nm_tot[a] * w[corner];
+            const double term = m.nm_tot[a] * W_(corner);
             Ntot = Ntot + term;
         }
         for (int gg = g; gg < g_end; ++gg) {
-            aux[(item * G + gg) * 2 + 0] = r[m.bb_source] / Ntot;
+            aux[(item * G + gg) * 2 + 0] = R_(m.bb_source) / Ntot;
             aux[(item * G + gg) * 2 + 1] = Ntot;
         }
         // can some bin have U_b == 0 at this point (bb_zero_u_possible, bi_single.h)?  Then the reference's first-root
         // assertion hangs on the last bits of N, which only the host planner's extra pass reproduces (bb_exact_totals)
         bool zero_u = true;
         for (int s = 0; s < m.S && zero_u; ++s) {
-            if (s == m.bb_source || !(r[s] > 0.0)) continue;
+            if (s == m.bb_source || !(R_(s) > 0.0)) continue;
             bool positive = true;
             for (int corner = 0; corner < m.nc && positive; ++corner) {
-                if (!(w[corner] > 0.0)) continue;
+                if (!(W_(corner) > 0.0)) continue;
                 positive = m.rowmin[(cell + m.corner_off[corner]) * m.S + s] > 0.0;
             }
             if (positive) zero_u = false;
         }
         if (zero_u && n_zero_u) atomicAdd(n_zero_u, 1ull);
     }
-    for (int s = 0; s < m.S; ++s) rsum += r[s];
+#undef W_
+#undef R_
     if (g == 0) {
         cnt_off[item] = m.sparse ? m.cnt_off[ds] : ds * m.Bp;
         tiles[item] = (int32_t)(row_stride / kTile);
@@ -304,9 +352,13 @@ __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanMeta m, int64_t n, c
     }
     slot_lg[item * G + g] = m.unbinned ? rsum : m.lgsum[ds] + zsum;
     perm[item * G + g] = m.share_order ? i : p;
+    for (int gg = g + 1; gg < g_end; ++gg) {            // the padding slots behind a group's last point
+        slot_lg[item * G + gg] = 0.0;
+        perm[item * G + gg] = -1;
+    }
     }();
     __syncthreads();
-    if (threadIdx.x == 0 && s_tiles) atomicAdd(tile_sum, s_tiles);
+    if (tx == 0 && s_tiles) atomicAdd(tile_sum, s_tiles);
 }
 
 // group bookkeeping for the scan kernel: flag[i] = 1 at the first sorted position of every (cell, dataset) group
@@ -381,6 +433,7 @@ PlanMeta plan_meta_of(const bi_ctx* c, bool sparse) {
     m.nm_tot = (const double*)c->pt_nm_tot.p;
     m.bb_source = c->bb_source;
     m.G = c->bb_source >= 0 ? (int)std::min<int64_t>(c->max_group, c->bb_max_group) : kDevG;
+    m.bad_key = (uint64_t)c->A * (uint64_t)std::max<int64_t>(c->T, 1);
     return m;
 }
 
@@ -632,14 +685,14 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
 
     bi_plan* plan = new bi_plan();
     plan->P = P; plan->sparse = sparse; plan->epoch = c->epoch; plan->device_planned = true; plan->no_reuse = false;
-    DevBuf d_z, d_rs, d_ds, d_wts, d_rates, d_keys, d_keys2, d_idx, d_idx2, d_a, d_b, d_tmp, d_scal;
-    auto cleanup = [&]() { dev_free(d_z); dev_free(d_rs); dev_free(d_ds); dev_free(d_wts); dev_free(d_rates); dev_free(d_keys);
+    DevBuf d_z, d_rs, d_ds, d_keys, d_keys2, d_idx, d_idx2, d_a, d_b, d_tmp, d_scal;
+    auto cleanup = [&]() { dev_free(d_z); dev_free(d_rs); dev_free(d_ds); dev_free(d_keys);
                            dev_free(d_keys2); dev_free(d_idx); dev_free(d_idx2); dev_free(d_a); dev_free(d_b); dev_free(d_tmp); dev_free(d_scal); };
     auto abort_plan = [&](int code) { cleanup(); free_plan_buffers(plan); delete plan; return code; };
     const size_t nP = (size_t)P;
     // resident: z / rate_scale / dataset ARE device arrays (bi_plan_points_resident) and are read where they lie
-    if ((!resident && (rc = dev_alloc(c, d_z, nP * std::max(d, 1) * sizeof(double)))) || (rc = dev_alloc(c, d_wts, nP * nc * sizeof(double))) ||
-        (rc = dev_alloc(c, d_rates, nP * S * sizeof(double))) || (rc = dev_alloc(c, d_keys, nP * 8)) || (rc = dev_alloc(c, d_keys2, nP * 8)) ||
+    if ((!resident && (rc = dev_alloc(c, d_z, nP * std::max(d, 1) * sizeof(double)))) ||
+        (rc = dev_alloc(c, d_keys, nP * 8)) || (rc = dev_alloc(c, d_keys2, nP * 8)) ||
         (rc = dev_alloc(c, d_idx, nP * 8)) || (rc = dev_alloc(c, d_idx2, nP * 8)) || (rc = dev_alloc(c, d_a, nP * 8)) ||
         (rc = dev_alloc(c, d_b, nP * 8)) || (rc = dev_alloc(c, d_scal, 64)) ||
         (rc = dev_alloc(c, plan->status, nP * sizeof(int32_t))) || (rc = dev_alloc(c, plan->out, nP * sizeof(double))))
@@ -666,11 +719,12 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     int64_t* scal = (int64_t*)d_scal.p;
     HIP_TRY(c, hipMemsetAsync(scal, 0, 64, c->stream));
     hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
-                       (double*)d_wts.p, (double*)d_rates.p, (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p,
-                       (unsigned long long*)(scal + 5));
-    // sort (key, point) pairs: keys are cell * T + dataset, rejected points carry the largest key
+                       (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p, (unsigned long long*)(scal + 5));
+    // sort (key, point) pairs: keys are cell * T + dataset < A * T, rejected points carry A * T -- the radix sort walks only the
+    // bits that can differ (C2: 7 bits, one pass over the pairs; round 4 sorted all 64 bits of a key whose rejected points were ~0)
     size_t tmp_bytes = 0;
-    int end_bit = 64;
+    int end_bit = 1;
+    while (end_bit < 64 && (m.bad_key >> end_bit) != 0) ++end_bit;
     (void)prim_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                     (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     size_t scan_bytes = 0, scan_bytes2 = 0;
@@ -681,7 +735,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     e = prim_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                   (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
-    hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, scal);
+    hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, m.bad_key, scal);
     int64_t h_scal[3] = {0, 0, 0}, h_inf = 0;
     e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_inf, scal + 5, 8, hipMemcpyDeviceToHost, c->stream);
@@ -766,20 +820,29 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                             (rc = dev_alloc(c, k.pflags, ni * k.nbx * G * sizeof(unsigned))))) ||
             (split && (rc = dev_alloc(c, k.rowoff_full, ni * NS * 8))))
             return abort_plan(rc);
-        e = hipMemsetAsync(k.coef.p, 0, ni * NS * G * 8, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(k.perm.p, 0xFF, ni * G * 8, c->stream);     // -1: padding slots
-        if (e == hipSuccess) e = hipMemsetAsync(k.slot_lg.p, 0, ni * G * 8, c->stream);
-        if (e == hipSuccess && bb) e = hipMemsetAsync(k.aux.p, 0, ni * G * 16, c->stream);
-        if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
-        hipLaunchKernelGGL(k_plan_fill, dim3(vblk), dim3(kThreads), 0, c->stream, m, n_valid, keys_s,
-                           idx_s, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, (const double*)d_wts.p,
-                           (const double*)d_rates.p, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
+        // (no memset of the descriptor arrays: the fill kernel writes every slot of every item, padding slots included --
+        //  256 MB of zeros for a 10^6-point scan used to go first)
+        {
+            // threads per block by the LDS its per-thread arrays take: d + 2 S + nc doubles and the point's index per thread
+            const size_t per_thread = (size_t)(d + 2 * S + nc) * sizeof(double) + sizeof(int64_t);
+            int bd = kThreads;
+            while (bd > 64 && per_thread * bd > (size_t)64 * 1024) bd >>= 1;
+            const size_t lds = per_thread * bd;
+            if (lds > (size_t)48 * 1024) e = hipFuncSetAttribute((const void*)k_plan_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
+            hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)((n_valid + bd - 1) / bd)), dim3((unsigned)bd), lds, c->stream, m, n_valid, keys_s,
+                           idx_s, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, z_dev,
+                           rs_dev, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
                            (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
                            split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr, bb ? (double*)k.aux.p : (double*)nullptr,
                            bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr);
+        }
         e = hipGetLastError();
+        bool tables_done = false;
         auto group_tables = [&]() -> int {
             int rc2;
+            if (tables_done) return BI_OK;
+            tables_done = true;
             if ((rc2 = dev_alloc(c, plan->grp_first, (size_t)n_groups * 8)) || (rc2 = dev_alloc(c, plan->grp_items, (size_t)n_groups * 4)))
                 return rc2;
             hipLaunchKernelGGL(k_plan_group_first, dim3(vblk), dim3(kThreads), 0, c->stream, (const int64_t*)d_b.p, (const int64_t*)d_idx.p,
@@ -789,8 +852,18 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                                grad_mode ? (unsigned long long*)(scal + 3) : (unsigned long long*)nullptr);
             return BI_OK;
         };
-        // (gradient batches: the group tables go out before the read-back, so that their largest group travels with it)
-        if (e == hipSuccess && grad_mode && (rc = group_tables())) return abort_plan(rc);
+        // (the group tables go out before the read-back, so that a gradient batch's largest group and -- for the scan kernels --
+        //  the tables themselves travel with it: every host synchronisation of the planner is ~35 us of a call)
+        const bool tables_early = grad_mode || split || scan_ok;
+        if (e == hipSuccess && tables_early && (rc = group_tables())) return abort_plan(rc);
+        std::vector<int64_t> h_grp_first;
+        std::vector<int32_t> h_grp_items;
+        if (e == hipSuccess && (split || scan_ok) && c->scan_chunk && n_groups <= 4096) {
+            h_grp_first.resize((size_t)n_groups);
+            h_grp_items.resize((size_t)n_groups);
+            e = hipMemcpyAsync(h_grp_first.data(), plan->grp_first.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_grp_items.data(), plan->grp_items.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream);
+        }
         int64_t h_zero_u = 0, h_max = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
@@ -882,18 +955,48 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                 if (cost_of(b) <= 1.01 * best_cost && (strips + 4 * b - 1) / (4 * b) >= 8) { best_b = b; break; }
             return best_b * 4;
         };
+        // Few groups with long item lists -- a rank's share of a dealt scan: 8 of C2's 64 cells with ~1000 work items each --
+        // cannot fill the chip by their strips alone: a group's waves split its STRIPS, every wave walks ALL its items, and a
+        // group gives at most strips / 16 blocks (8 cells x 9 blocks = 72 blocks for 256 CUs: the share of one of 8 ranks took
+        // 2.1 ms where an eighth of the whole scan is 1.3).  So the item lists are cut as well: chunks of a group's items
+        // (multiples of four: the kernels work quads of items) become groups of their own -- same rows, other items, other
+        // partial slots; nothing changes for the kernels.  The tables are small (one entry per group): read back, cut, sent again.
+        auto chunk_groups = [&](int64_t strips, int resident) -> int {
+            if (h_grp_items.empty() || n_groups < 1) return BI_OK;          // (tables of more than 4096 groups are not cut: plenty of blocks)
+            const int64_t capacity = (int64_t)c->prop.multiProcessorCount * std::max(1, resident);
+            const int64_t b_cap = std::max<int64_t>(1, strips / 16);
+            if (b_cap * n_groups >= 2 * capacity) return BI_OK;
+            const int64_t pieces = (3 * capacity + b_cap * n_groups - 1) / (b_cap * n_groups);
+            const int64_t longest = *std::max_element(h_grp_items.begin(), h_grp_items.end());
+            const int64_t chunk = std::max<int64_t>(16, ((longest + pieces - 1) / pieces + 3) / 4 * 4);
+            if (chunk >= longest) return BI_OK;
+            std::vector<int64_t>& first2 = plan->h_grp_first;                 // (kept with the plan: the upload below is asynchronous)
+            std::vector<int32_t>& items2 = plan->h_grp_items;
+            first2.clear();
+            items2.clear();
+            for (int64_t g = 0; g < n_groups; ++g)
+                for (int64_t o = 0; o < h_grp_items[(size_t)g]; o += chunk) {
+                    first2.push_back(h_grp_first[(size_t)g] + o);
+                    items2.push_back((int32_t)std::min<int64_t>(chunk, h_grp_items[(size_t)g] - o));
+                }
+            if ((int64_t)first2.size() > 65535) return BI_OK;
+            int rc2;
+            if ((rc2 = dev_upload(c, plan->grp_first, first2)) || (rc2 = dev_upload(c, plan->grp_items, items2))) return rc2;
+            n_groups = (int64_t)first2.size();
+            return BI_OK;
+        };
         if (split) {
             if ((rc = group_tables()) || (rc = dev_alloc(c, plan->bad, ni * kDevG * sizeof(unsigned)))) return abort_plan(rc);
+            plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
+            if ((rc = chunk_groups((int64_t)n_tiles * (kTile / 64), scan_resident_blocks(true, 4, NS)))) return abort_plan(rc);
             plan->valid = true;
             plan->n_groups = n_groups;
             plan->scan_cb = 4;
             plan->valid_nslots = (int)waves_per_group((int64_t)n_tiles * (kTile / 64), scan_resident_blocks(true, 4, NS),
                                                       (int64_t)1 << 40);       // (the pass keeps no per-wave partial sums)
             c->last_valid_nslots = plan->valid_nslots;
-            plan->bytes += (int64_t)sizeof(double) * NS * c->B * n_groups;     // every cell's rows once more, in full
             plan->launches += 1;
-            e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+            if ((e = hipGetLastError()) != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
         }
         if (scan_ok) {
             if ((rc = group_tables())) return abort_plan(rc);
@@ -911,14 +1014,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             // every wave owns one partial slot per item: the split is bounded by the memory the slots may take (1 GiB)
             const int64_t slot_cap = std::max<int64_t>(4, ((int64_t)1 << 30) / std::max<int64_t>(1, (int64_t)ni * kDevG * (int64_t)sizeof(double)));
             const int resident = scan_resident_blocks(false, strip_cb, NS, plan->by_count);
+            if ((rc = chunk_groups(max_tiles * (kTile / (16 * strip_cb)), resident))) return abort_plan(rc);
+            plan->n_groups = n_groups;
             k.nbx = (int)waves_per_group(max_tiles * (kTile / (16 * strip_cb)), resident, slot_cap, plan->by_count);
             c->last_scan_nslots = k.nbx;
             c->last_scan_resident = resident;
             dev_free(k.partial);
             dev_free(k.pflags);                     // the scan kernel raises no per-block flags (k_finish_scan reads none)
             if ((rc = dev_alloc(c, k.partial, ni * k.nbx * kDevG * sizeof(double)))) return abort_plan(rc);
-            e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
+            if ((e = hipGetLastError()) != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning groups: %s", hipGetErrorString(e)));
             plan->launches = 1;
         }
     }

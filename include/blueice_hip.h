@@ -422,6 +422,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   scan_share_slow   k_scan_sorted: a strip whose 64 bins do not carry one count (two runs meet, the end of the data) is worked item by
  *                     item, ~25 times the cost of a uniform strip; with 1 (default) the items of such strips are dealt over ALL waves
  *                     of the cell instead of staying with the wave that owns the strip
+ *   scan_chunk        matrix-core scans over few grid cells with long lists of work items (a rank's share of a dealt scan): the
+ *                     item lists are cut into chunks, each worked as a group of its own, so that the chip is filled (1, default)
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows
  *   scan_split        scans with sparse = 0 over mostly empty data: non-empty-bin pass + validity pass of every bin on the
  *                     matrix cores (k_scan_valid) instead of the per-bin terms in every bin (1)
