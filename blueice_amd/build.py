@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # one translation unit per heavy kernel family (csrc/bi_common.h says which), compiled side by side
-UNITS = ('blueice_hip', 'tu_morph', 'tu_scan', 'tu_scan_sorted', 'tu_grad', 'tu_prim')
+UNITS = ('blueice_hip', 'tu_morph', 'tu_scan', 'tu_scan_sorted', 'tu_grad', 'tu_scan_bb', 'tu_prim')
 HDR = os.path.join(os.path.dirname(_HERE), 'include', 'blueice_hip.h')
 OUT_DIR = os.path.join(_HERE, 'lib')
 OBJ_DIR = os.path.join(_HERE, 'lib', 'obj')

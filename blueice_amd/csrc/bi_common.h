@@ -6,6 +6,7 @@
 //     tu_scan.hip         k_scan_mfma, k_scan_valid                                          bi_k_scan.h
 //     tu_scan_sorted.hip  k_scan_sorted                                                      bi_scan_sorted.h
 //     tu_grad.hip         k_grad_mfma, k_morph_bbgrad                                        bi_k_grad_mfma.h, bi_k_bbgrad.h
+//     tu_scan_bb.hip      k_scan_bb (Beeston-Barlow scans on the matrix cores)               bi_k_scan_bb.h
 //     tu_prim.hip         the rocPRIM sorts and scans (instantiated once, behind plain functions)
 // gfx950 only; no kernel is defined in two translation units.
 #pragma once
@@ -79,3 +80,7 @@ int occupancy_scan(bool valid, int cb, int kg, bool mask);
 int occupancy_scan_sorted(int KG, bool mask);
 // k_grad_mfma<KG, MASK>
 void launch_grad_mfma(bi_ctx* c, int NS, dim3 grid, const GradMfmaArgs& a);
+// k_scan_bb<KGT>: Beeston-Barlow scans on the matrix cores; scan_bb_variant: the KGT for (streams into U, corners), 0 = none fits
+int scan_bb_variant(int n0, int nc);
+void launch_scan_bb(bi_ctx* c, int kgt, dim3 grid, const BbScanArgs& a);
+int occupancy_scan_bb(int kgt);

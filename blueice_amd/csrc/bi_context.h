@@ -45,6 +45,7 @@ struct bi_plan {
     DevBuf grp_first, grp_items;
     std::vector<int64_t> h_grp_first;   // host copies of cut group tables (device planner: their upload is asynchronous)
     std::vector<int32_t> h_grp_items;
+    int bb_kgt = 0;               // Beeston-Barlow batch on the matrix cores (k_scan_bb<bb_kgt>): items of 16 points, group tables
     bool valid = false;           // split dense scan: classes hold the non-empty-bin pass, k_scan_valid checks every bin
     int valid_nslots = 0;         // its waves per group
     DevBuf bad;                   // [items][16] flags it raises
@@ -198,6 +199,9 @@ struct bi_ctx {
     int64_t n_mail_resets = 0;                   // how often the mailbox had to be emptied after a collector gave up
     std::vector<void*> user_allocs;              // bi_device_alloc buffers still alive: freed with the context
     int64_t bb_max_group = 8;                    // points per Beeston-Barlow work item (16: one wave per SIMD, accumulators partly in AGPRs)
+    int64_t scan_bb = 1;                         // parameter: device-planned Beeston-Barlow batches on the matrix cores (k_scan_bb)
+    int64_t scan_bb_min = 64;                    // ... from this many points on
+    int64_t n_bb_scan_launches = 0;              // read-only
     int64_t device_plan_min = 512;               // batches at least this large are planned on the device
 
     // the events of the last bi_simulate_events into this context: coordinates [k][N], source index [N]

@@ -84,6 +84,24 @@ struct ValidArgs {
     int n_strips;               // strips of 16 CB bins per full row
 };
 
+// k_scan_bb (bi_k_scan_bb.h): Beeston-Barlow scans on the matrix cores
+struct BbScanArgs {
+    const double* ps;           // template rows
+    const double* nm;           // Monte-Carlo count rows of the Beeston-Barlow source
+    const double* counts;
+    const int64_t* rowoff;      // [items][NS]   (rows of a group = rows of its first item)
+    const double* coef;         // [items][NS][16]: n0 streams into U, nc into P, nc into a
+    const double* aux;          // [items][16][2]  (p_cal, N) per point
+    const int64_t* item_cnt;    // [items] element offset of the item's counts row
+    const int64_t* grp_first;   // [groups] first item of the group
+    const int32_t* grp_items;   // [groups] items in the group
+    double* partial;            // [items][gridDim.x][16]
+    unsigned* pflags;           // [items][gridDim.x][16]
+    int64_t B;
+    int n0, nc;
+    int n_tiles;                // tiles of 16 bins covering [0, B)
+};
+
 // k_grad_mfma (bi_k_grad_mfma.h)
 struct GradMfmaArgs {
     const double* ps;

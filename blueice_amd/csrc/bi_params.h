@@ -71,6 +71,8 @@ const ParamDef kParams[] = {
     {"scan_xcd", kParamRW, BI_P_GET(c->scan_xcd), BI_P_RANGE(0, 2, scan_xcd, "scan_xcd: 0 launch order, 1 contiguous ranges, 2 one XCD per group")},
     {"scan_share_slow", kParamRW, BI_P_GET(c->scan_share_slow), BI_P_FLAG(scan_share_slow)},
     {"scan_chunk", kParamRW, BI_P_GET(c->scan_chunk), BI_P_FLAG(scan_chunk)},
+    {"scan_bb", kParamRW, BI_P_GET(c->scan_bb), BI_P_FLAG(scan_bb)},
+    {"scan_bb_min", kParamRW, BI_P_GET(c->scan_bb_min), BI_P_RANGE(1, (int64_t)1 << 40, scan_bb_min, "scan_bb_min >= 1")},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},
     {"scan_split", kParamRW, BI_P_GET(c->scan_split), BI_P_FLAG(scan_split)},
     {"scan_pow", kParamRW, BI_P_GET(c->scan_pow), BI_P_SET(c->scan_pow = v ? 1 : 0; c->sorted_epoch = -1)},
@@ -101,6 +103,7 @@ const ParamDef kParams[] = {
     BI_P_RO("n_scan_launches", c->n_scan_launches),
     BI_P_RO("n_toy_polled", c->n_toy_polled),
     BI_P_RO("n_toy_points_passes", c->n_toy_points_passes),
+    BI_P_RO("n_bb_scan_launches", c->n_bb_scan_launches),
     BI_P_RO("tmm_entry_bytes", c->tmm_ok ? c->tmm_width : 0),
     BI_P_RO("tm_entry_bytes", c->tm_width),
     BI_P_RO("events_sorted", c->ev_sorted ? 1 : 0),

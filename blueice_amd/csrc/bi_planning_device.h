@@ -681,6 +681,10 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     // Beeston-Barlow with `bb_exact = 1` wants N(z) in numpy's summation order for every point: the host planner's extra pass
     if (bb && c->bb_exact == 1) return kPlanNeedsHost;
     PlanMeta m = plan_meta_of(c, sparse);                    // (split scans switch m.sparse on below)
+    // Beeston-Barlow batches of at least scan_bb_min points: work items of 16 points for the matrix-core kernel (k_scan_bb), if a
+    // variant holds the model's streams; smaller batches keep items of bb_max_group points for k_morph_reduce<G, true>
+    const int bb_kgt = (bb && c->scan_bb && !grad_mode && !c->unbinned && P >= c->scan_bb_min) ? scan_bb_variant(nc * (S - 1), nc) : 0;
+    if (bb_kgt) m.G = 16;
     const int G = m.G;
 
     bi_plan* plan = new bi_plan();
@@ -811,6 +815,14 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         int64_t nbx = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (4 * slots + n_items - 1) / n_items));
         if (n_items == 1) nbx = std::min<int64_t>(max_tiles, slots);
         if (c->xcd_affine && n_items > 1 && nbx > 4 && nbx < max_tiles) nbx = std::min<int64_t>(max_tiles, (nbx + 7) / 8 * 8);
+        if (bb_kgt != 0 && n_groups <= 65535) {
+            // k_scan_bb: a block = four work items of a group over a range of 16-bin tiles; about three rounds of the resident blocks
+            // over all quads, every block at least 64 tiles
+            const int64_t quads = (n_items + 3) / 4 + n_groups;
+            const int resident = std::max(1, occupancy_scan_bb(bb_kgt));
+            const int64_t tiles16 = (c->B + 15) / 16;
+            nbx = std::max<int64_t>(1, std::min<int64_t>({(3 * (int64_t)c->prop.multiProcessorCount * resident + quads - 1) / quads, (tiles16 + 63) / 64, (int64_t)65535}));
+        }
         k.nbx = (int)nbx;
         const size_t ni = (size_t)n_items;
         if ((rc = dev_alloc(c, k.rowoff, ni * NS * 8)) || (rc = dev_alloc(c, k.coef, ni * NS * G * 8)) || (rc = dev_alloc(c, k.aux, ni * G * 16)) ||
@@ -849,12 +861,13 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                                (const int64_t*)d_keys.p, n_valid, (int64_t*)plan->grp_first.p);
             hipLaunchKernelGGL(k_plan_group_items, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
                                (const int64_t*)plan->grp_first.p, n_groups, n_items, (int32_t*)plan->grp_items.p,
-                               grad_mode ? (unsigned long long*)(scal + 3) : (unsigned long long*)nullptr);
+                               (grad_mode || bb_kgt) ? (unsigned long long*)(scal + 3) : (unsigned long long*)nullptr);
             return BI_OK;
         };
         // (the group tables go out before the read-back, so that a gradient batch's largest group and -- for the scan kernels --
         //  the tables themselves travel with it: every host synchronisation of the planner is ~35 us of a call)
-        const bool tables_early = grad_mode || split || scan_ok;
+        const bool bb_scan = bb_kgt != 0 && n_groups <= 65535;
+        const bool tables_early = grad_mode || split || scan_ok || bb_scan;
         if (e == hipSuccess && tables_early && (rc = group_tables())) return abort_plan(rc);
         std::vector<int64_t> h_grp_first;
         std::vector<int32_t> h_grp_items;
@@ -867,7 +880,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         int64_t h_zero_u = 0, h_max = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && grad_mode) e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && (grad_mode || bb_scan)) e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
         // Beeston-Barlow points at which some bin can have U_b == 0: the reference's first-root assertion then hangs on the
@@ -880,6 +893,12 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             plan->n_groups = n_groups;
             plan->max_group_items = h_max;
             plan->max_item_tiles = (int)max_tiles;
+        }
+        if (bb_scan) {
+            plan->bb_kgt = bb_kgt;
+            plan->n_groups = n_groups;
+            plan->max_group_items = h_max;
+            plan->launches = 1;
         }
         // A group's strips are spread over W = 4 b waves (b blocks); a block lasts as long as its busiest wave, ceil(strips / W)
         // strips, and the blocks of all groups run in ceil(b * n_groups / resident blocks) rounds -- the last of which is

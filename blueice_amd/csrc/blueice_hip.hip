@@ -588,8 +588,32 @@ int bi_run_plan(bi_ctx* c, bi_plan* plan, double* out_dev) {
                            c->stream, (const double*)k.partial.p, k.nbx, k.n_items, (const int64_t*)k.perm.p,
                            (const double*)k.slot_lg.p, out);
     }
+    if (plan->bb_kgt && !plan->classes.empty()) {
+        // Beeston-Barlow batch on the matrix cores: one launch over (tile ranges, groups, quads of a group's items), then the
+        // ordinary finish of the per-block partial sums and status bits
+        bi_plan::Class& k = plan->classes[0];
+        BbScanArgs ba{};
+        ba.ps = a.ps; ba.nm = a.nm; ba.counts = a.counts;
+        ba.rowoff = (const int64_t*)k.rowoff.p; ba.coef = (const double*)k.coef.p; ba.aux = (const double*)k.aux.p;
+        ba.item_cnt = (const int64_t*)k.item_cnt.p;
+        ba.grp_first = (const int64_t*)plan->grp_first.p; ba.grp_items = (const int32_t*)plan->grp_items.p;
+        ba.partial = (double*)k.partial.p; ba.pflags = (unsigned*)k.pflags.p;
+        ba.B = c->B; ba.n0 = a.n0; ba.nc = a.n1; ba.n_tiles = (int)((c->B + 15) / 16);
+        const int64_t quads = std::max<int64_t>(1, (plan->max_group_items + 3) / 4);
+        {
+            EventScope ev(c);
+            ++c->n_bb_scan_launches;
+            launch_scan_bb(c, plan->bb_kgt, dim3((unsigned)k.nbx, (unsigned)plan->n_groups, (unsigned)quads), ba);
+        }
+        const int64_t n_slots = k.n_items * k.G;
+        const int lanes = k.nbx > 64 ? kThreads : 64;
+        const int per_block = kThreads / lanes;
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(kThreads), 0, c->stream,
+                           (const double*)k.partial.p, (const unsigned*)k.pflags.p, k.nbx, k.G, lanes, n_slots, (const int64_t*)k.perm.p,
+                           (const double*)k.slot_lg.p, out, (int32_t*)plan->status.p);
+    }
     for (auto& k : plan->classes) {
-        if (plan->use_scan) break;
+        if (plan->use_scan || plan->bb_kgt) break;
         for (int64_t i0 = 0; i0 < k.n_items; i0 += 65535) {
             const int64_t ni = std::min<int64_t>(65535, k.n_items - i0);
             LaunchArgs b = a;

@@ -422,6 +422,11 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *   scan_share_slow   k_scan_sorted: a strip whose 64 bins do not carry one count (two runs meet, the end of the data) is worked item by
  *                     item, ~25 times the cost of a uniform strip; with 1 (default) the items of such strips are dealt over ALL waves
  *                     of the cell instead of staying with the wave that owns the strip
+ *   scan_bb, scan_bb_min   Beeston-Barlow batches planned on the device (no bin can have U_b == 0, at least scan_bb_min = 64
+ *                     points) run on the fp64 matrix cores: four 16-point work items of a grid cell share the rows of a bin
+ *                     tile through LDS, U, P and a are three chains of matrix products, the per-bin roots and Poisson terms follow
+ *                     on the vector ALU in the reference's operation order (k_scan_bb; 1, default; 0 = k_morph_reduce<bb_max_group,
+ *                     true> as for small batches).  Read-only n_bb_scan_launches
  *   scan_chunk        matrix-core scans over few grid cells with long lists of work items (a rank's share of a dealt scan): the
  *                     item lists are cut into chunks, each worked as a group of its own, so that the chip is filled (1, default)
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows

@@ -83,6 +83,29 @@ def test_c5_cell_beeston_barlow_equals_the_reference():
     ctx = DeviceContext(0)
     m.upload(ctx, threads=8)
     _compare(ctx, m, case, modes=(0,))
+    # the same reference scalars through the matrix-core Beeston-Barlow scan kernel (k_scan_bb, csrc/bi_k_scan_bb.h: batches of at
+    # least 64 points planned on the device; variant <20, 4>: 80 streams into U, 16 corners): each golden point rides in a batch of
+    # 96 points of the cell -- and must come out as the reference has it, its status 0
+    for dense in (False, True):
+        key = 'dense' if dense else 'sparse'
+        calls = [c for c in case['calls'] if c['data'] == key]
+        ctx.upload_counts(m.counts(dense=dense))
+        z, r = m.random_points(96, seed=77)
+        for j, c in enumerate(calls):
+            z[7 * j + 3], r[7 * j + 3] = c['z'], c['mult']
+        ctx.set_param('device_plan_min', 1)
+        before = ctx.get_param('n_bb_scan_launches')
+        got, st = ctx.eval(z, r)
+        assert ctx.get_param('n_bb_scan_launches') == before + 1
+        ctx.set_param('scan_bb', 0)
+        vec, st_v = ctx.eval(z, r)                       # the vector kernel (k_morph_reduce<8, true>) on the same batch
+        ctx.set_param('scan_bb', 1)
+        ctx.set_param('device_plan_min', 512)
+        assert ctx.get_param('n_bb_scan_launches') == before + 1
+        np.testing.assert_array_equal(st, st_v)
+        np.testing.assert_allclose(got, vec, rtol=1e-12, atol=0)
+        for j, c in enumerate(calls):
+            assert st[7 * j + 3] == 0 and abs(got[7 * j + 3] - c['ll']) <= RTOL * abs(c['ll']), (key, c['label'], got[7 * j + 3], c['ll'])
     ctx.close()
 
 
