@@ -129,6 +129,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// exchange for a transposing reduction: returns a' * b' where a' = [a | b](lower halves / even rows), b' = the others
+#define BI_SWAP_MUL(SWAP, a, b, out)                                                                               \
+    do {                                                                                                           \
+        const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);                       \
+        const auto lo = SWAP((unsigned)ua, (unsigned)ub, false, false);                                            \
+        const auto hi = SWAP((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);                            \
+        out = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) *                                    \
+              __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);                                     \
+    } while (0)
+// (used by k_scan_sorted and k_grad_mfma: four items' products over the four 16-lane rows of a wave, row q keeping item q --
+//  BI_SWAP_MUL(permlane32_swap, p0, p2, x); BI_SWAP_MUL(permlane32_swap, p1, p3, y); BI_SWAP_MUL(permlane16_swap, x, y, P))
+
 // a lane's double as a wave-uniform (scalar) value
 __device__ __forceinline__ double lane_value(double v, int src_lane) {
     const unsigned long long u = __double_as_longlong(v);

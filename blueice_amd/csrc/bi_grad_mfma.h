@@ -164,7 +164,7 @@ int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     DevBuf d_pll, d_pg, d_ll, d_grad;
     auto cleanup = [&]() { dev_free(d_pll); dev_free(d_pg); dev_free(d_ll); dev_free(d_grad); bi_plan_destroy(c, plan); };
     hipError_t e = hipSuccess;
-    std::vector<double> h_ll((size_t)P), h_grad((size_t)P * (d + S));
+    bool have_results = false;                       // (results go straight into the caller's arrays: one pass over 8 P (1 + d + S) bytes less)
     if (!plan->classes.empty() && plan->classes[0].n_items > 0) {
         bi_plan::Class& k = plan->classes[0];
         const int kg = NS <= 4 ? 1 : (NS <= 8 ? 2 : (NS <= 16 ? 4 : 8));
@@ -207,8 +207,9 @@ int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
                                rate_scale ? (const double*)plan->keep_rs.p : (const double*)nullptr, (double*)d_ll.p, (double*)d_grad.p);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(h_ll.data(), d_ll.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_grad.data(), d_grad.p, h_grad.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ll, d_ll.p, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(grad, d_grad.p, (size_t)P * (d + S) * 8, hipMemcpyDeviceToHost, c->stream);
+        have_results = e == hipSuccess;
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_st.data(), plan->status.p, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream);
     // (on an error part way the kernels already queued still write into the buffers cleanup() hands back to the recycle
@@ -219,12 +220,9 @@ int eval_grad_mfma(bi_ctx* c, int64_t P, const double* z, const double* rate_sca
     if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_eval_grad (matrix-core path): %s", hipGetErrorString(e));
     for (int64_t p = 0; p < P; ++p) {
         if (status) status[p] = h_st[(size_t)p];
-        if (h_st[(size_t)p]) {
+        if (h_st[(size_t)p] || !have_results) {      // rejected points (and a batch without a single valid one): -inf, no slopes
             ll[p] = ninf;
             for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = qnan;
-        } else {
-            ll[p] = h_ll[(size_t)p];
-            for (int j = 0; j < d + S; ++j) grad[p * (d + S) + j] = h_grad[(size_t)p * (d + S) + j];
         }
     }
     return BI_OK;

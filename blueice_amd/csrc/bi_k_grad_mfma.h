@@ -4,6 +4,19 @@
 
 namespace {
 
+// Round 5.  What the kernel spent per 16-bin block of four items, beside its 64 MFMAs, was 7.4 vector instructions per MFMA on
+// a chip where none of them executes beside an fp64 MFMA (40 TFLOP/s, 0.51 of the matrix peak).  Three changes:
+//   * the rows are loaded ONCE: product 2 needs them with the streams along the lanes (B operand), product 1 with the bins
+//     along the lanes (A operand) -- the second layout is the first one transposed through a wave-private 4 KB of LDS (rows of 17
+//     doubles: conflict-free in both directions) instead of a second, gathering load of the same lines;
+//   * f = n / mu for a lane's four bins from ONE reciprocal: with q = mu0 mu1 mu2 mu3 already there for the logarithm,
+//     n / mu0 = mu1 (mu2 mu3) (n / q), ...: a reciprocal with two Newton steps and seven multiplications instead of four times
+//     seven instructions (relative error a few ulp; the slopes are held to 1e-8);
+//   * ONE logarithm per four items and block: a lane's product q_j belongs to item j's point, the four rows of the wave hold other
+//     bins of the same points, so the items' products are multiplied over the rows by the transposing reduction of
+//     k_scan_sorted (row j keeps item j) and every row takes the logarithm of another item;
+//   and the range tests are one integer minimum over the high words (negative numbers, zeros, subnormals and nans compare low
+//   or fail the window test) instead of two compares per element.
 template <int KG, bool MASK>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_grad_mfma(GradMfmaArgs a) {
     constexpr int NB = KG >= 4 ? KG / 4 : 1;       // blocks of 16 streams (product 2's N dimension)
@@ -11,12 +24,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
     const int grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kq = lane >> 4, col = lane & 15;
-    // (product 2 reads the rows of streams 0 .. 16 NB - 1 -- more than the 4 KG of product 1 when KG < 4: every index is
-    //  clamped to a valid row here, and the rows of streams beyond NS are zeroed where they are loaded)
-    constexpr int NRO = 4 * KG > NSP ? 4 * KG : NSP;
-    constexpr bool MASK_B2 = MASK || NSP != 4 * KG;
-    __shared__ int64_t s_rowoff[NRO];
-    if (threadIdx.x < NRO) s_rowoff[threadIdx.x] = a.rowoff[a.grp_first[grp] * a.NS + min((int)threadIdx.x, a.NS - 1)];
+    __shared__ int64_t s_rowoff[4 * KG];
+    // the transposition buffer of each wave: [stream][bin] with rows of 17 doubles
+    constexpr int kTrRow = 17;
+    __shared__ double s_tr[kThreads / 64][4 * KG * kTrRow];
+    if (threadIdx.x < 4 * KG) s_rowoff[threadIdx.x] = a.rowoff[a.grp_first[grp] * a.NS + min((int)threadIdx.x, a.NS - 1)];
     log_table_load();
     const int wx = blockIdx.x * 4 + wave;
     const int quad = wx / a.n_slices, slice = wx % a.n_slices;
@@ -27,6 +39,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
     const int NS = a.NS;
     const double* __restrict__ cnt = a.counts + a.item_cnt[item0];
     const int n_blocks = a.item_tiles[item0] * (kTile / 16);
+    double* __restrict__ tr = s_tr[wave];
 
     // the four items' value coefficients: B operand of product 1 (k = kq <-> stream 4 kg + kq, column = point)
     double cf[4][KG];
@@ -36,10 +49,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) cf[j][kg] = c[min(kg * 4 + kq, NS - 1) * 16 + col];
     }
-    // (the group's row offsets are read from LDS block by block: as loop invariants they would hold 2 (KG + NB) registers)
+    // (the group's row offsets are read from LDS block by block: as loop invariants they would hold 2 KG registers)
 
     bi_double4 g[4][NB];
-    double ll[4];
+    double ll[4];                                  // item by item (the careful path): partial sums per lane
+    double llc = 0.0;                              // the product form: lane (j, col) carries item j, point col
     bool bad[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -52,26 +66,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int blk = slice; blk < n_blocks; blk += a.n_slices) {
         const int64_t bin0 = (int64_t)blk * 16;
         double b1[KG], b2[4][NB], n4[4];
-        int kqo = kq, colo = col;
-        asm volatile("" : "+v"(kqo), "+v"(colo));          // (opaque: keeps the LDS reads inside the loop)
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));                      // (opaque: keeps the LDS reads inside the loop)
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const double v = a.ps[s_rowoff[kg * 4 + kqo] + bin0 + col];
             b1[kg] = (MASK && kg * 4 + kq >= NS) ? 0.0 : v;
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int64_t row = s_rowoff[nb * 16 + colo];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = a.ps[row + bin0 + 4 * r + kq];
-                b2[r][nb] = (MASK_B2 && nb * 16 + col >= NS) ? 0.0 : v;
-            }
-        }
-#pragma unroll
         for (int r = 0; r < 4; ++r) n4[r] = cnt[bin0 + 4 * r + kq];
+        // the second layout: element (stream s, bin b) sits in lane (s & 3, b), register s >> 2; product 2 wants it in lane
+        // (b & 3, s & 15), register (b >> 2, s >> 4).  Through this wave's own LDS rows (the wave's LDS operations complete in order)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) tr[(kg * 4 + kq) * kTrRow + col] = b1[kg];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                b2[r][nb] = (nb * 16 + col < 4 * KG) ? tr[min(nb * 16 + col, 4 * KG - 1) * kTrRow + 4 * r + kq] : 0.0;
+        __builtin_amdgcn_wave_barrier();                   // (the next block's writes stay behind these reads)
         // the block's counts, known once for the four items: one count in all 16 bins (the rule in count order) lets a
-        // lane take ONE logarithm of the product of its four expectations; anything unusual is flagged
+        // lane take the product of its four expectations; anything unusual is flagged
         const double n_first = lane_value(n4[0], 0);
         const bool uniform = __builtin_amdgcn_ballot_w64(n4[0] == n_first && n4[1] == n_first && n4[2] == n_first && n4[3] == n_first) == ~0ull &&
                              n_first > 0.0 && n_first == floor(n_first);
@@ -80,13 +98,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int r = 0; r < 4; ++r) odd_lane |= n4[r] != n4[r] || n4[r] < 0.0 || n4[r] != floor(n4[r]);
         const bool odd = __builtin_amdgcn_ballot_w64(odd_lane) != 0ull;
 
-        // The four items in PAIRS: two chains of product 1 interleaved, then -- where the block takes the product form for
-        // both items, the rule -- ONE straight-line epilogue for the two (two logarithms and eight reciprocals in flight
-        // together: with two waves per SIMD a single item's dependent chains leave the vector unit waiting on itself), then
-        // the two items' product 2.  Anything unusual falls back to the item-by-item epilogue with scipy's values for
-        // every argument.  (9 % of the kernel at 131 072 points.)
+        // item by item, scipy's values for every argument: what the product form cannot take
         auto careful = [&](int j, const bi_double4& mu, double (&f)[4]) {
             bool done = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bad[j] |= !(mu[r] >= 0.0);
             if (uniform) {
                 const bool ok = mu[0] > kProdFloor && mu[1] > kProdFloor && mu[2] > kProdFloor && mu[3] > kProdFloor;
                 const double q = (mu[0] * mu[1]) * (mu[2] * mu[3]);
@@ -120,6 +136,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
             for (int r = 0; r < 4; ++r) f[r] = n4[r] != 0.0 ? n4[r] / mu[r] : 0.0;
         };
+        // The four items in PAIRS: two chains of product 1 interleaved, the pair's f = n / mu, its product 2.  Where the block
+        // takes the product form, the rule, the pair's lane products wait in qs for the one logarithm of the four items.
+        double qs[4] = {1.0, 1.0, 1.0, 1.0};
+        bool any_product = false;
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
             bi_double4 mu0 = bi_double4{0.0, 0.0, 0.0, 0.0}, mu1 = bi_double4{0.0, 0.0, 0.0, 0.0};
@@ -128,33 +148,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
                 mu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp][kg], mu0, 0, 0, 0);
                 mu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp + 1][kg], mu1, 0, 0, 0);
             }
-            // sum_b n log mu over the lane's four bins of its point, and f = n / mu for product 2
-            bool neg0 = false, neg1 = false, ok = uniform;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                neg0 |= !(mu0[r] >= 0.0);
-                neg1 |= !(mu1[r] >= 0.0);
-                ok &= mu0[r] > kProdFloor && mu1[r] > kProdFloor;
-            }
-            bad[jp] |= neg0;
-            bad[jp + 1] |= neg1;
-            const double q0 = (mu0[0] * mu0[1]) * (mu0[2] * mu0[3]), q1 = (mu1[0] * mu1[1]) * (mu1[2] * mu1[3]);
+            // every factor above 2^-127 (one integer minimum over the eight high words: negative numbers, zeros and subnormals
+            // compare low), each lane product inside (2^-255, 2^255) (nan and inf fail): the four-row products are then normal
+            // numbers, and so are the reciprocals
+            const int m0 = min(min(__double2hiint(mu0[0]), __double2hiint(mu0[1])), min(__double2hiint(mu0[2]), __double2hiint(mu0[3])));
+            const int m1 = min(min(__double2hiint(mu1[0]), __double2hiint(mu1[1])), min(__double2hiint(mu1[2]), __double2hiint(mu1[3])));
+            const double pa0 = mu0[0] * mu0[1], pb0 = mu0[2] * mu0[3], pa1 = mu1[0] * mu1[1], pb1 = mu1[2] * mu1[3];
+            const double q0 = pa0 * pb0, q1 = pa1 * pb1;
+            const bool ok = min(m0, m1) >= 0x38000000 && q0 > 0x1p-255 && q0 < 0x1p255 && q1 > 0x1p-255 && q1 < 0x1p255;
             double f0[4], f1[4];
-            if (__builtin_amdgcn_ballot_w64(ok && pos_normal(q0) && pos_normal(q1)) == ~0ull) {
-                // (one positive count, every mu a normal number above 2^-127: n / mu as n times a reciprocal refined by two
-                //  Newton steps -- relative error < 2^-50, the slopes are held to 1e-8 --, 7 instructions instead of 15)
-                ll[jp] += n_first * bin_log_fast(q0);
-                ll[jp + 1] += n_first * bin_log_fast(q1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double r0 = __builtin_amdgcn_rcp(mu0[r]), r1 = __builtin_amdgcn_rcp(mu1[r]);
-                    r0 = __builtin_fma(__builtin_fma(-mu0[r], r0, 1.0), r0, r0);
-                    r1 = __builtin_fma(__builtin_fma(-mu1[r], r1, 1.0), r1, r1);
-                    r0 = __builtin_fma(__builtin_fma(-mu0[r], r0, 1.0), r0, r0);
-                    r1 = __builtin_fma(__builtin_fma(-mu1[r], r1, 1.0), r1, r1);
-                    f0[r] = n_first * r0;
-                    f1[r] = n_first * r1;
-                }
+            if (uniform && __builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+                qs[jp] = q0;
+                qs[jp + 1] = q1;
+                any_product = true;
+                // n / q by a reciprocal refined with two Newton steps, then n / mu_r = (the other three factors) (n / q)
+                double r0 = __builtin_amdgcn_rcp(q0), r1 = __builtin_amdgcn_rcp(q1);
+                r0 = __builtin_fma(__builtin_fma(-q0, r0, 1.0), r0, r0);
+                r1 = __builtin_fma(__builtin_fma(-q1, r1, 1.0), r1, r1);
+                r0 = __builtin_fma(__builtin_fma(-q0, r0, 1.0), r0, r0);
+                r1 = __builtin_fma(__builtin_fma(-q1, r1, 1.0), r1, r1);
+                r0 *= n_first;
+                r1 *= n_first;
+                const double ta0 = pb0 * r0, tb0 = pa0 * r0, ta1 = pb1 * r1, tb1 = pa1 * r1;
+                f0[0] = mu0[1] * ta0; f0[1] = mu0[0] * ta0; f0[2] = mu0[3] * tb0; f0[3] = mu0[2] * tb0;
+                f1[0] = mu1[1] * ta1; f1[1] = mu1[0] * ta1; f1[2] = mu1[3] * tb1; f1[3] = mu1[2] * tb1;
             } else {
                 careful(jp, mu0, f0);
                 careful(jp + 1, mu1, f1);
@@ -168,16 +185,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
                     g[jp + 1][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[r], b2[r][nb], g[jp + 1][nb], 0, 0, 0);
                 }
         }
+        if (any_product) {                                 // (wave-uniform) row j <- item j's product over the four rows; one logarithm
+            double x, y, P;
+            BI_SWAP_MUL(__builtin_amdgcn_permlane32_swap, qs[0], qs[2], x);
+            BI_SWAP_MUL(__builtin_amdgcn_permlane32_swap, qs[1], qs[3], y);
+            BI_SWAP_MUL(__builtin_amdgcn_permlane16_swap, x, y, P);
+            llc += n_first * bin_log_fast(P);
+        }
     }
 
-    // partial sums of this slice: ll per point (the four rows of a wave hold different bins of the same points), G as it lies
+    // partial sums of this slice: ll per point (the four rows of a wave hold different bins of the same points; the product
+    // form's sums sit in row j for item j), G as it lies
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (i0 + j >= n_items) break;
         const int64_t slot = (item0 + i0 + j) * a.n_slices + slice;
         double t = bad[j] ? __builtin_nan("") : ll[j];
         t = rows4_sum(t);
-        if (kq == 0) a.part_ll[slot * 16 + col] = t;
+        if (kq == j) a.part_ll[slot * 16 + col] = t + llc;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll

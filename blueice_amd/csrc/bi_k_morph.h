@@ -30,6 +30,10 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
         double acc[G][2];
 #pragma unroll
         for (int g = 0; g < G; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
+        // the tile's counts go out FIRST: behind the stream loop their load was the one latency of a tile that nothing covered
+        // (a block of the single-point call lives for two tiles: ~1 us of its 40)
+        double2 nv;
+        if constexpr (MODE == 2 || MODE == 3) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
 
         int k0 = 0;
         if constexpr (NT && G == 1 && MODE != 2 && MODE != 3) {
@@ -88,8 +92,6 @@ __device__ __forceinline__ void morph_tiles(const LaunchArgs& a, const int64_t* 
                 acc[g][1] = fma(c, v.y, acc[g][1]);
             }
         }
-        double2 nv;
-        if constexpr (MODE == 2 || MODE == 3) { nv.x = nv.y = 0.0; } else { nv = *reinterpret_cast<const double2*>(cnt + bin0); }
         if (tab_pending) {
             if (threadIdx.x < 128) s_log_table[threadIdx.x] = tab;
             __syncthreads();

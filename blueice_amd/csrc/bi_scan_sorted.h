@@ -27,16 +27,6 @@
 
 namespace {
 
-// exchange for a transposing reduction: returns a' * b' where a' = [a | b](lower halves / even rows), b' = the others
-#define BI_SWAP_MUL(SWAP, a, b, out)                                                                               \
-    do {                                                                                                           \
-        const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);                       \
-        const auto lo = SWAP((unsigned)ua, (unsigned)ub, false, false);                                            \
-        const auto hi = SWAP((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);                            \
-        out = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) *                                    \
-              __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);                                     \
-    } while (0)
-
 // log(x * 2^k_adjust) for positive normal x, Horner steps with their constants in scalar registers (the compiler's own
 // selection copies each constant into a fresh vector register pair first: seven moves per logarithm)
 __device__ __forceinline__ double fma_sc(double x, double p, double c) {
@@ -394,6 +384,5 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 #undef BI_LOAD_ROWS
 #undef BI_SCALE_ROWS
 }
-#undef BI_SWAP_MUL
 
 }  // namespace
