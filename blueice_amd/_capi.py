@@ -78,6 +78,8 @@ SIGNATURES = {
     'bi_memcpy_to_host': (C.c_int, [_p, _p, _p, _i64]),
     'bi_memcpy_to_device': (C.c_int, [_p, _p, _p, _i64]),
     'bi_selftest_log': (C.c_int, [_p, _i64, _p, _p]),
+    'bi_selftest_sort': (C.c_int, [_p, C.c_int, _i64, _p, _p, C.c_int, C.c_int, _p, _p]),
+    'bi_selftest_scan': (C.c_int, [_p, C.c_int, _i64, _p, _i64, _p]),
     'bi_measure_read_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p]),
     'bi_measure_stream_bandwidth': (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     'bi_measure_copy_bandwidth': (C.c_int, [_p, _i64, C.c_int, _p]),

@@ -1,7 +1,7 @@
-// bi_prim.h -- the device-wide sorts and scans the library uses, as plain functions: rocPRIM is instantiated once, in
-// tu_prim.hip (each rocPRIM algorithm brings a kernel per architecture it knows, 13 of them -- ~1000 of the library's ~1250
-// kernel symbols and a third of the code object came from including it in the main translation unit).  Same argument order
-// and temporary-storage protocol as rocprim:: (tmp == nullptr: only the size is returned in `bytes`).
+// bi_prim.h -- the device-wide sorts and scans the library uses, as plain functions: hand-written for gfx950 in tu_prim.hip
+// (rounds 1-4 instantiated rocPRIM there: a kernel per architecture it knows for every algorithm -- ~1000 of the library's ~1250
+// kernel symbols and 10 of its 12 MB).  Same argument order and temporary-storage protocol as rocprim:: (tmp == nullptr: only
+// the size is returned in `bytes`).  Sorts are stable; every result depends on the input alone (fixed summation order).
 #pragma once
 
 hipError_t prim_sort_pairs(void* tmp, size_t& bytes, const double* keys_in, double* keys_out, const int32_t* vals_in, int32_t* vals_out,

@@ -478,7 +478,13 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
     int n_items = 0;
     bool shared_anchor = false;           // two items read rows of the same anchor model (neighbouring cells share corners): then
     std::vector<char> anchor_used((size_t)c->A, 0);   // the default cache policy wins over the nontemporal hint
+    // the passes are worked in groups of kPassGroup (two): the log mu rows and the per-tile partial sums of a group live in
+    // scratch buffers that the next group reuses (stream order) -- 32 hypotheses x 10^4 datasets would otherwise want 0.6 GB of
+    // partial sums at once, beyond what the context's recycle cache parks
+    constexpr int kPassGroup = 2;
+    std::vector<int> item_begin((size_t)n_pass + 1, 0);
     for (int ps = 0; ps < n_pass; ++ps) {
+        item_begin[(size_t)ps] = n_items;
         const int v0 = ps * PP, v1 = std::min(n_valid, v0 + PP);
         int v = v0;
         while (v < v1) {
@@ -499,7 +505,7 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
                 }
             // a pass's last columns without a point repeat nothing: they stay zero (log 0 = -inf in the table, never read back)
             const bool last_item_of_short_pass = (w == v1) && (v1 - v0 < PP);
-            meta.insert(meta.end(), {ps, v - v0, last_item_of_short_pass ? PP - (v - v0) : w - v, 0});
+            meta.insert(meta.end(), {ps % kPassGroup, v - v0, last_item_of_short_pass ? PP - (v - v0) : w - v, 0});
             for (int q = v; q < w; ++q) {
                 colmap[((size_t)ps * PP + (q - v0)) * 2 + 0] = n_items;
                 colmap[((size_t)ps * PP + (q - v0)) * 2 + 1] = valid[(size_t)q].idx;
@@ -513,21 +519,25 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             v = w;
         }
     }
+    item_begin[(size_t)n_pass] = n_items;
+    int max_group_items = 1;
+    for (int g0 = 0; g0 < n_pass; g0 += kPassGroup)
+        max_group_items = std::max(max_group_items, item_begin[(size_t)std::min(n_pass, g0 + kPassGroup)] - item_begin[(size_t)g0]);
     const double ninf = -std::numeric_limits<double>::infinity();
     const bool host_out = !out_dev && (size_t)P * n * sizeof(double) <= ((size_t)4 << 20);
     DevBuf d_out, d_lm, d_part, d_mu;
     auto cleanup = [&]() { dev_free(d_out); dev_free(d_lm); dev_free(d_part); dev_free(d_mu); };
     const int n_tiles = n_tiles_of(c);
     const int64_t slots = (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu;
-    const int nmu = n_items > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (slots + n_items - 1) / n_items)) : 1;
+    const int nmu = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (slots + max_group_items - 1) / max_group_items));   // blocks per item of a log mu launch
     PackedUpload pu;
     std::vector<std::pair<const void*, size_t>> parts = {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)},
                                                         {meta.data(), meta.size() * sizeof(int32_t)}, {colmap.data(), colmap.size() * sizeof(int32_t)},
                                                         {bad_rows.data(), bad_rows.size() * sizeof(int32_t)}};
     const size_t mu_bytes = (size_t)std::max(n_items, 1) * nmu * PP * sizeof(double);
     if ((rc = packed_upload(c, parts, host_out ? (size_t)P * n * sizeof(double) : 0, pu)) ||
-        (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)n_pass * c->Bp * PP * sizeof(double)))) ||
-        (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)n_pass * n_tl * n * PP * sizeof(double)))) ||
+        (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)std::min(n_pass, kPassGroup) * c->Bp * PP * sizeof(double)))) ||
+        (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)std::min(n_pass, kPassGroup) * n_tl * n * PP * sizeof(double)))) ||
         (rc = dev_alloc(c, d_mu, 2 * ((mu_bytes + 63) / 64 * 64))) ||
         (!host_out && !out_dev && (rc = dev_alloc(c, d_out, (size_t)P * n * sizeof(double))))) {
         cleanup();
@@ -546,24 +556,45 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         a.pflags = (unsigned*)((char*)d_mu.p + (mu_bytes + 63) / 64 * 64);
         a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles; a.chunks = (int)c->tile_chunks;
         const bool nt = c->nt_loads == 1 || (c->nt_loads == 2 && !shared_anchor);
-        const dim3 lgrid((unsigned)nmu, (unsigned)n_items);
-        {
-            EventScope ev(c);
-#define BI_LM(PPv)                                                                                                                      \
-    do {                                                                                                                                \
-        if (nt) hipLaunchKernelGGL((k_morph_logmu_multi<PPv, true>), lgrid, dim3(kThreads), 0, c->stream, a, pu.dev<int32_t>(2), (double*)d_lm.p); \
-        else hipLaunchKernelGGL((k_morph_logmu_multi<PPv, false>), lgrid, dim3(kThreads), 0, c->stream, a, pu.dev<int32_t>(2), (double*)d_lm.p);   \
-    } while (0)
-            if (PP == 2) BI_LM(2); else BI_LM(4);
-#undef BI_LM
-        }
-        // the dot kernel: one round of blocks per pass where the passes are few, the datasets split over blockIdx.y so that a
-        // pass fills the chip once (one resident block per CU: 128 KB of LDS each)
+        // the dot kernel: the datasets split over blockIdx.y so that a pass fills the chip once where it can (one resident block per
+        // CU: 128 KB of LDS each)
         const size_t lds = (size_t)(kDotTileMulti + 1) * PP * sizeof(double);
         const int variant = (c->tmm_width == 2 ? 0 : 2) + (PP == 4 ? 0 : 1);     // {W2 PP4, W2 PP2, W4 PP4, W4 PP2}
         const int lanes = (int)c->toy_points_lanes;
-        const void* fn = nullptr;
-        // L x AHEAD x (16 / W) entry slots per run; a run holds ~38 entries at configs[2] (tiles of 4096 bins)
+        const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((n + 255) / 256, (int64_t)c->prop.multiProcessorCount / n_tl), (n + 262143) / 262144});
+        if (host_out && c->poll_result && !c->profiling && (c->toy_fast_call & 4)) {
+            if ((rc = dev_alloc(c, c->toy_blocks_done, 64))) { cleanup(); return rc; }
+            if (!c->toy_blocks_done_zeroed) {
+                e = hipMemsetAsync(c->toy_blocks_done.p, 0, 64, c->stream);
+                c->toy_blocks_done_zeroed = true;
+            }
+            done_word = (unsigned long long*)((char*)pu.host_out() + ((size_t)P * n * sizeof(double) + 63) / 64 * 64);
+            seq = ++c->toy_seq;
+            *(volatile unsigned long long*)done_word = 0ull;
+        }
+        for (int g0 = 0; g0 < n_pass && e == hipSuccess; g0 += kPassGroup) {
+            const int np = std::min(kPassGroup, n_pass - g0);
+            const int ib = item_begin[(size_t)g0], ie = item_begin[(size_t)(g0 + np)];
+            const bool last = g0 + np == n_pass;
+            LaunchArgs b = a;
+            b.rowoff = a.rowoff + (int64_t)ib * NS;
+            b.coef = a.coef + (int64_t)ib * NS * PP;
+            b.partial = a.partial + (int64_t)ib * nmu * PP;
+            b.pflags = a.pflags + (int64_t)ib * nmu * PP;
+            const int32_t* meta_dev = pu.dev<int32_t>(2) + 4 * ib;
+            const dim3 lgrid((unsigned)nmu, (unsigned)(ie - ib));
+            {
+                EventScope ev(c);
+#define BI_LM(PPv)                                                                                                                      \
+    do {                                                                                                                                \
+        if (nt) hipLaunchKernelGGL((k_morph_logmu_multi<PPv, true>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p); \
+        else hipLaunchKernelGGL((k_morph_logmu_multi<PPv, false>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p);   \
+    } while (0)
+                if (PP == 2) BI_LM(2); else BI_LM(4);
+#undef BI_LM
+            }
+            const void* fn = nullptr;
+            // L x AHEAD x (16 / W) entry slots per run; a run holds ~38 entries at configs[2] (tiles of 4096 bins)
 #define BI_DM(Lv, Av, Wv, PPv)                                                                                             \
     do {                                                                                                                   \
         fn = (const void*)k_dataset_dot_multi<Lv, Av, Wv, PPv, kDotTileMulti>;                                            \
@@ -575,34 +606,25 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
                                c->B, c->Bp, t0, n, (double*)d_part.p);                                                     \
         }                                                                                                                  \
     } while (0)
-        const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((n + 255) / 256, (int64_t)c->prop.multiProcessorCount / n_tl), (n + 262143) / 262144});
-        const dim3 dgrid((unsigned)n_tl, by, (unsigned)n_pass);
-        if (variant == 0) { if (lanes == 2) BI_DM(2, 3, 2, 4); else if (lanes == 8) BI_DM(8, 1, 2, 4); else BI_DM(4, 2, 2, 4); }
-        else if (variant == 1) { if (lanes == 2) BI_DM(2, 3, 2, 2); else if (lanes == 8) BI_DM(8, 1, 2, 2); else BI_DM(4, 2, 2, 2); }
-        else if (variant == 2) { if (lanes == 4) BI_DM(4, 3, 4, 4); else BI_DM(8, 2, 4, 4); }
-        else { if (lanes == 4) BI_DM(4, 3, 4, 2); else BI_DM(8, 2, 4, 2); }
+            const dim3 dgrid((unsigned)n_tl, by, (unsigned)np);
+            if (variant == 0) { if (lanes == 2) BI_DM(2, 3, 2, 4); else if (lanes == 8) BI_DM(8, 1, 2, 4); else BI_DM(4, 2, 2, 4); }
+            else if (variant == 1) { if (lanes == 2) BI_DM(2, 3, 2, 2); else if (lanes == 8) BI_DM(8, 1, 2, 2); else BI_DM(4, 2, 2, 2); }
+            else if (variant == 2) { if (lanes == 4) BI_DM(4, 3, 4, 4); else BI_DM(8, 2, 4, 4); }
+            else { if (lanes == 4) BI_DM(4, 3, 4, 2); else BI_DM(8, 2, 4, 2); }
 #undef BI_DM
-        c->n_toy_points_passes += n_pass;
-        if (e == hipSuccess && host_out && c->poll_result && !c->profiling && (c->toy_fast_call & 4)) {
-            if ((rc = dev_alloc(c, c->toy_blocks_done, 64))) { (void)hipStreamSynchronize(c->stream); cleanup(); return rc; }
-            if (!c->toy_blocks_done_zeroed) {
-                e = hipMemsetAsync(c->toy_blocks_done.p, 0, 64, c->stream);
-                c->toy_blocks_done_zeroed = true;
-            }
-            done_word = (unsigned long long*)((char*)pu.host_out() + ((size_t)P * n * sizeof(double) + 63) / 64 * 64);
-            seq = ++c->toy_seq;
-            *(volatile unsigned long long*)done_word = 0ull;
-        }
-        if (e == hipSuccess) {
-            EventScope ev(c);
-            const dim3 fgrid((unsigned)((n + 63) / 64), (unsigned)n_pass);
+            if (e == hipSuccess) {
+                EventScope ev(c);
+                const dim3 fgrid((unsigned)((n + 63) / 64), (unsigned)np);
+                // (the completion word is published by the LAST group's finish: the stream runs the groups in order)
 #define BI_FM(PPv)                                                                                                          \
     hipLaunchKernelGGL((k_dataset_finish_multi<PPv>), fgrid, dim3(kThreads), 0, c->stream, (const double*)d_part.p, n_tl,   \
-                       pu.dev<int32_t>(3), (const double*)a.partial, (const unsigned*)a.pflags, nmu, (const double*)c->lgsum.p, \
-                       t0, n, res, n, (unsigned*)c->toy_blocks_done.p, done_word, seq)
-            if (PP == 2) BI_FM(2); else BI_FM(4);
+                       pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, \
+                       (const double*)c->lgsum.p, t0, n, res, n, (unsigned*)c->toy_blocks_done.p, last ? done_word : (unsigned long long*)nullptr, seq)
+                if (PP == 2) BI_FM(2); else BI_FM(4);
 #undef BI_FM
+            }
         }
+        c->n_toy_points_passes += n_pass;
     }
     if (e == hipSuccess && !bad_rows.empty())
         hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, res, n, pu.dev<int32_t>(4), (int)bad_rows.size(), n, ninf);

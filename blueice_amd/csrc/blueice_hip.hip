@@ -2008,6 +2008,63 @@ int bi_selftest_log(bi_ctx* c, int64_t n, const double* x, double* out) {
     return BI_OK;
 }
 
+// the library's own device-wide primitives (tu_prim.hip) on caller data: kind of sort 0 (uint64 keys, int64 values), 1 (int64, int32),
+// 2 (double, int32); kind of scan 0 inclusive max int64, 1 inclusive sum int64, 2 inclusive sum double, 3 exclusive sum int64 (+ init)
+int bi_selftest_sort(bi_ctx* c, int kind, int64_t n, const void* keys, const void* vals, int begin_bit, int end_bit, void* keys_out, void* vals_out) {
+    if (!c || n < 0 || kind < 0 || kind > 2 || begin_bit < 0 || end_bit > 64 || begin_bit > end_bit || (n > 0 && (!keys || !vals || !keys_out || !vals_out)))
+        return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t vb = kind == 0 ? 8 : 4, nn = (size_t)std::max<int64_t>(n, 1);
+    DevBuf dk, dv, dk2, dv2, dt;
+    auto drop = [&]() { dev_free(dk); dev_free(dv); dev_free(dk2); dev_free(dv2); dev_free(dt); };
+    size_t tb = 0;
+    if (kind == 0) (void)prim_sort_pairs(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
+    else if (kind == 1) (void)prim_sort_pairs(nullptr, tb, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
+    else (void)prim_sort_pairs(nullptr, tb, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
+    int rc;
+    if ((rc = dev_alloc(c, dk, nn * 8)) || (rc = dev_alloc(c, dv, nn * vb)) || (rc = dev_alloc(c, dk2, nn * 8)) || (rc = dev_alloc(c, dv2, nn * vb)) ||
+        (rc = dev_alloc(c, dt, std::max<size_t>(tb, 256)))) { drop(); return rc; }
+    hipError_t e = n ? hipMemcpyAsync(dk.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess && n) e = hipMemcpyAsync(dv.p, vals, (size_t)n * vb, hipMemcpyHostToDevice, c->stream);
+    size_t t2 = dt.bytes;
+    if (e == hipSuccess) {
+        if (kind == 0) e = prim_sort_pairs(dt.p, t2, (const uint64_t*)dk.p, (uint64_t*)dk2.p, (const int64_t*)dv.p, (int64_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
+        else if (kind == 1) e = prim_sort_pairs(dt.p, t2, (const int64_t*)dk.p, (int64_t*)dk2.p, (const int32_t*)dv.p, (int32_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
+        else e = prim_sort_pairs(dt.p, t2, (const double*)dk.p, (double*)dk2.p, (const int32_t*)dv.p, (int32_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
+    }
+    if (e == hipSuccess && n) e = hipMemcpyAsync(keys_out, dk2.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(vals_out, dv2.p, (size_t)n * vb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); else (void)hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_selftest_sort: %s", hipGetErrorString(e));
+    return BI_OK;
+}
+
+int bi_selftest_scan(bi_ctx* c, int kind, int64_t n, const void* in, int64_t init, void* out) {
+    if (!c || n < 0 || kind < 0 || kind > 3 || (n > 0 && (!in || !out))) return BI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    DevBuf di, dout, dt;
+    auto drop = [&]() { dev_free(di); dev_free(dout); dev_free(dt); };
+    size_t tb = 0;
+    (void)prim_exclusive_scan_sum(nullptr, tb, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)n, c->stream);   // (all kinds: 8-byte elements, the same size)
+    int rc;
+    if ((rc = dev_alloc(c, di, nn * 8)) || (rc = dev_alloc(c, dout, nn * 8)) || (rc = dev_alloc(c, dt, std::max<size_t>(tb, 256)))) { drop(); return rc; }
+    hipError_t e = n ? hipMemcpyAsync(di.p, in, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    size_t t2 = dt.bytes;
+    if (e == hipSuccess) {
+        if (kind == 0) e = prim_inclusive_scan_max(dt.p, t2, (const int64_t*)di.p, (int64_t*)dout.p, (size_t)n, c->stream);
+        else if (kind == 1) e = prim_inclusive_scan_sum(dt.p, t2, (const int64_t*)di.p, (int64_t*)dout.p, (size_t)n, c->stream);
+        else if (kind == 2) e = prim_inclusive_scan_sum(dt.p, t2, (const double*)di.p, (double*)dout.p, (size_t)n, c->stream);
+        else e = prim_exclusive_scan_sum(dt.p, t2, (const int64_t*)di.p, (int64_t*)dout.p, init, (size_t)n, c->stream);
+    }
+    if (e == hipSuccess && n) e = hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); else (void)hipStreamSynchronize(c->stream);
+    drop();
+    if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_selftest_scan: %s", hipGetErrorString(e));
+    return BI_OK;
+}
+
 // ---- measurement ---------------------------------------------------------------------------
 
 int bi_measure_read_bandwidth(bi_ctx* c, int nontemporal, int blocks_per_cu, int reps, double* gb_per_s) {

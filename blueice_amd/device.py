@@ -357,12 +357,18 @@ class DeviceContext:
                                                       ptr(status)))
         return int(status[0])
 
-    def eval_datasets_points(self, z, rate_scale=None, t0=0, t1=None):
+    def eval_datasets_points(self, z, rate_scale=None, t0=0, t1=None, out=None):
         """P parameter points against datasets [t0, t1) in one call (the toy-MC form over several hypotheses: the points of a
-        pass share the passes over the templates and over the datasets' lists) -> (ll [P, t1 - t0], status [P])."""
+        pass share the passes over the templates and over the datasets' lists) -> (ll [P, t1 - t0], status [P]).
+        `out`: a C-contiguous float64 array of that shape to write into (a loop that reuses it saves the page faults of a
+        fresh 8 P T-byte array per call: 0.1 ms at 32 x 10^4)."""
         t1 = self.T if t1 is None else int(t1)
         P, z, rate_scale, _ = self._point_args(z, rate_scale, None)
-        out = np.empty((P, max(t1 - int(t0), 0)), dtype=np.float64)
+        shape = (P, max(t1 - int(t0), 0))
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %s" % (shape,))
         status = np.zeros(P, dtype=np.int32)
         self._check(self._lib.bi_eval_datasets_points(self._h, P, ptr(z), ptr(rate_scale), int(t0), t1, ptr(out), ptr(status)))
         return out, status

@@ -344,6 +344,14 @@ int bi_memcpy_to_device(bi_ctx* ctx, void* dst_dev, const void* src_host, int64_
 /* self-test of the device logarithm used in the per-bin terms: out[i] = log(x[i]) as the kernels compute it */
 int bi_selftest_log(bi_ctx* ctx, int64_t n, const double* x, double* out);
 
+/* self-tests of the library's own device-wide primitives (csrc/tu_prim.hip: the stable radix sort of (64-bit key, value) pairs over
+ * the key bits [begin_bit, end_bit) and the scans behind the device planner, the list builders and toy generation), on caller data:
+ *   sort kind 0: uint64 keys, int64 values | 1: int64 keys, int32 values | 2: double keys (numpy's sort order, -nan < -inf ... +inf < +nan), int32 values
+ *   scan kind 0: inclusive running maximum of int64 | 1: inclusive sum of int64 | 2: inclusive sum of double | 3: exclusive sum of int64, from `init` */
+int bi_selftest_sort(bi_ctx* ctx, int kind, int64_t n, const void* keys, const void* vals, int begin_bit, int end_bit, void* keys_out,
+                     void* vals_out);
+int bi_selftest_scan(bi_ctx* ctx, int kind, int64_t n, const void* in, int64_t init, void* out);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * While enabled, every morph+reduce launch is bracketed by HIP events on the context stream;
  * bi_profile_read drains them: number of launches and summed GPU time in milliseconds.
