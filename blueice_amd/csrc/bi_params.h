@@ -71,6 +71,7 @@ const ParamDef kParams[] = {
     {"scan_xcd", kParamRW, BI_P_GET(c->scan_xcd), BI_P_RANGE(0, 2, scan_xcd, "scan_xcd: 0 launch order, 1 contiguous ranges, 2 one XCD per group")},
     {"scan_share_slow", kParamRW, BI_P_GET(c->scan_share_slow), BI_P_FLAG(scan_share_slow)},
     {"scan_chunk", kParamRW, BI_P_GET(c->scan_chunk), BI_P_FLAG(scan_chunk)},
+    {"plan_tables", kParamRW, BI_P_GET(c->plan_tables), BI_P_FLAG(plan_tables)},
     {"scan_bb", kParamRW, BI_P_GET(c->scan_bb), BI_P_FLAG(scan_bb)},
     {"scan_bb_min", kParamRW, BI_P_GET(c->scan_bb_min), BI_P_RANGE(1, (int64_t)1 << 40, scan_bb_min, "scan_bb_min >= 1")},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},

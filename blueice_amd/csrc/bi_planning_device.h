@@ -213,6 +213,87 @@ __global__ __launch_bounds__(kThreads) void k_plan_item_heads(const int64_t* __r
     if (i < n) ihead[i] = ((i - gstart[i]) % G == 0) ? 1 : 0;
 }
 
+// ---- group structure from per-key tables (few distinct keys: A * T + 1 <= 65 536) --------------------------------------------
+// The sorted keys fall into at most A * T runs.  Where a run starts is found by comparing neighbours (k_plan_key_bounds); what
+// the fill kernel needs per sorted position -- its group's start, its work item, its slot -- then follows from three small
+// tables over the KEYS, built by one block (k_plan_key_tables): this rank's window [lo, hi) of the valid points, each key's run
+// clipped to it, the items and groups before it.  No device-wide scan over the points, one host round trip for the counts.
+__global__ __launch_bounds__(kThreads) void k_plan_key_bounds(const uint64_t* __restrict__ keys, int64_t P, int64_t* __restrict__ kstart) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < P && (i == 0 || keys[i] != keys[i - 1])) kstart[keys[i]] = i;
+}
+
+// scal: [0] valid points in all, [1] work items of this share, [3] items of its largest group, [6] its groups, [7] / [8] the share's
+// window of the sorted list.  tab_start [K]: start of the key's run inside the window (relative to lo), tab_item [K]: items before it;
+// grp_first / grp_items [<= K]: the group tables.  kstart [K + 1]: first sorted position of every key (-1: absent), index K = rejected.
+__global__ __launch_bounds__(kThreads) void k_plan_key_tables(const int64_t* __restrict__ kstart, int64_t K, int64_t P, int share_rank,
+                                                              int share_world, int G, int64_t* __restrict__ tab_start,
+                                                              int64_t* __restrict__ tab_item, int64_t* __restrict__ grp_first,
+                                                              int32_t* __restrict__ grp_items, int64_t* __restrict__ scal) {
+    __shared__ int64_t s_first[kThreads], s_items[kThreads], s_groups[kThreads];
+    __shared__ int64_t s_lo, s_hi;
+    const int t = threadIdx.x;
+    const int64_t n_valid = kstart[K] >= 0 ? kstart[K] : P;
+    if (t == 0) {
+        const int64_t base = n_valid / share_world, extra = n_valid % share_world;
+        s_lo = share_rank * base + (share_rank < extra ? share_rank : extra);
+        s_hi = s_lo + base + (share_rank < extra ? 1 : 0);
+    }
+    const int64_t per = (K + kThreads - 1) / kThreads;
+    const int64_t k0 = min((int64_t)t * per, K), k1 = min(k0 + per, K);
+    // the first run that starts in this thread's range of keys (starts ascend with the key)
+    int64_t first = -1;
+    for (int64_t k = k0; k < k1 && first < 0; ++k) first = kstart[k];
+    s_first[t] = first;
+    __syncthreads();
+    const int64_t lo = s_lo, hi = s_hi;
+    // where the run behind this thread's range starts: the next thread with a run, or the end of the valid points
+    int64_t nxt = n_valid;
+    for (int u = t + 1; u < kThreads; ++u)
+        if (s_first[u] >= 0) { nxt = s_first[u]; break; }
+    // backwards over the range: every run ends where the next one starts; its part inside [lo, hi); items and groups of the range
+    int64_t items = 0, groups = 0, largest = 0;
+    for (int64_t k = k1 - 1; k >= k0; --k) {
+        const int64_t s = kstart[k];
+        int64_t s_in = 0, cnt = 0;
+        if (s >= 0) {
+            const int64_t a = min(max(s, lo), hi), b = min(max(nxt, lo), hi);
+            s_in = a - lo;
+            cnt = b - a;
+            nxt = s;
+        }
+        tab_start[k] = s_in;
+        const int64_t it = (cnt + G - 1) / G;
+        tab_item[k] = it;                       // (for now: the run's own items; made a prefix below)
+        items += it;
+        groups += cnt > 0 ? 1 : 0;
+        largest = max(largest, it);
+    }
+    s_items[t] = items;
+    s_groups[t] = groups;
+    __syncthreads();
+    int64_t item_base = 0, grp_base = 0;
+    for (int u = 0; u < t; ++u) { item_base += s_items[u]; grp_base += s_groups[u]; }
+    for (int64_t k = k0; k < k1; ++k) {
+        const int64_t it = tab_item[k];
+        tab_item[k] = item_base;
+        if (it > 0) {
+            grp_first[grp_base] = item_base;
+            grp_items[grp_base] = (int32_t)it;
+            ++grp_base;
+        }
+        item_base += it;
+    }
+    if (largest > 0) atomicMax((unsigned long long*)(scal + 3), (unsigned long long)largest);
+    if (t == kThreads - 1) {
+        scal[0] = n_valid;
+        scal[1] = item_base;
+        scal[6] = grp_base;
+        scal[7] = lo;
+        scal[8] = hi;
+    }
+}
+
 // One thread per sorted position.  The block first fetches its points' z and rate_scale rows TOGETHER into LDS -- lanes walk the
 // (point, component) pairs, so the d (or S) doubles of a point are fetched by adjacent lanes and a load instruction touches a
 // third (a quarter) of the lines it would with one point per lane --, every thread then rebuilds its point's corner weights and
@@ -221,8 +302,9 @@ __global__ __launch_bounds__(kThreads) void k_plan_item_heads(const int64_t* __r
 // group's last item are written here too (perm = -1, a copy of the last point's coefficients): no memset precedes the kernel.
 // LDS doubles per thread: d + S (inputs) + nc (weights) + S (rates).
 __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ keys,
-                            const int64_t* __restrict__ idx, const int64_t* __restrict__ gstart,
-                            const int64_t* __restrict__ item_incl, const double* __restrict__ z,
+                            const int64_t* __restrict__ idx, const int64_t* __restrict__ gstart /* per position, or NULL: tables */,
+                            const int64_t* __restrict__ item_incl, const int64_t* __restrict__ tab_start, const int64_t* __restrict__ tab_item,
+                            const double* __restrict__ z,
                             const double* __restrict__ rate_scale, int64_t* __restrict__ rowoff,
                             double* __restrict__ coef, int64_t* __restrict__ cnt_off,
                             int32_t* __restrict__ tiles, int64_t* __restrict__ perm,
@@ -258,9 +340,19 @@ __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ 
     if (i >= n) return;
     const int64_t p = s_idx[tx];
     const int G = m.G;
-    const int g = (int)((i - gstart[i]) % G);
-    const int64_t item = item_incl[i] - 1;
-    const bool last_of_group = i + 1 == n || gstart[i + 1] == i + 1;
+    int g;
+    int64_t item;
+    bool last_of_group;
+    if (gstart) {                                          // per-position arrays (many distinct keys: the scans' route)
+        g = (int)((i - gstart[i]) % G);
+        item = item_incl[i] - 1;
+        last_of_group = i + 1 == n || gstart[i + 1] == i + 1;
+    } else {                                               // tables over the keys
+        const int64_t in_group = i - tab_start[keys[i]];
+        g = (int)(in_group % G);
+        item = tab_item[keys[i]] + in_group / G;
+        last_of_group = i + 1 == n || keys[i + 1] != keys[i];
+    }
     const int64_t ds = (int64_t)(keys[i] % (uint64_t)m.T);
     const bool bb = m.bb_source >= 0;
     const int n0 = bb ? m.nc * (m.S - 1) : m.nc * m.S;
@@ -698,7 +790,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     if ((!resident && (rc = dev_alloc(c, d_z, nP * std::max(d, 1) * sizeof(double)))) ||
         (rc = dev_alloc(c, d_keys, nP * 8)) || (rc = dev_alloc(c, d_keys2, nP * 8)) ||
         (rc = dev_alloc(c, d_idx, nP * 8)) || (rc = dev_alloc(c, d_idx2, nP * 8)) || (rc = dev_alloc(c, d_a, nP * 8)) ||
-        (rc = dev_alloc(c, d_b, nP * 8)) || (rc = dev_alloc(c, d_scal, 64)) ||
+        (rc = dev_alloc(c, d_b, nP * 8)) || (rc = dev_alloc(c, d_scal, 128)) ||
         (rc = dev_alloc(c, plan->status, nP * sizeof(int32_t))) || (rc = dev_alloc(c, plan->out, nP * sizeof(double))))
         return abort_plan(rc);
     hipError_t e = hipSuccess;
@@ -721,7 +813,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     // [0] n_valid  [1] n_items  [2] sum of tiles  [3] largest group (gradient batches)  [4] Beeston-Barlow points at which some
     // bin can have U_b == 0  [5] points with an infinite rate that the reference evaluates (sources that may go negative)
     int64_t* scal = (int64_t*)d_scal.p;
-    HIP_TRY(c, hipMemsetAsync(scal, 0, 64, c->stream));
+    HIP_TRY(c, hipMemsetAsync(scal, 0, 128, c->stream));
     hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
                        (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p, (unsigned long long*)(scal + 5));
     // sort (key, point) pairs: keys are cell * T + dataset < A * T, rejected points carry A * T -- the radix sort walks only the
@@ -739,16 +831,35 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     e = prim_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
                                   (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
-    hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, m.bad_key, scal);
-    int64_t h_scal[3] = {0, 0, 0}, h_inf = 0;
-    e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
+    // few distinct keys (A * T + 1 <= 65 536: every named configuration): the group structure from per-key tables, one round trip
+    const int64_t K = (int64_t)m.bad_key;
+    const bool by_tables = K <= 65536 && c->plan_tables;
+    DevBuf d_kstart, d_tab_start, d_tab_item;
+    int64_t h_scal[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h_inf = 0;
+    if (by_tables) {
+        if ((rc = dev_alloc(c, d_kstart, (size_t)(K + 1) * 8)) || (rc = dev_alloc(c, d_tab_start, (size_t)K * 8)) || (rc = dev_alloc(c, d_tab_item, (size_t)K * 8)) ||
+            (rc = dev_alloc(c, plan->grp_first, (size_t)K * 8)) || (rc = dev_alloc(c, plan->grp_items, (size_t)K * 4))) {
+            dev_free(d_kstart); dev_free(d_tab_start); dev_free(d_tab_item);
+            return abort_plan(rc);
+        }
+        e = hipMemsetAsync(d_kstart.p, 0xFF, (size_t)(K + 1) * 8, c->stream);
+        hipLaunchKernelGGL(k_plan_key_bounds, dim3(nblk), dim3(kThreads), 0, c->stream, (const uint64_t*)d_keys2.p, P, (int64_t*)d_kstart.p);
+        hipLaunchKernelGGL(k_plan_key_tables, dim3(1), dim3(kThreads), 0, c->stream, (const int64_t*)d_kstart.p, K, P, share_rank, share_world, G,
+                           (int64_t*)d_tab_start.p, (int64_t*)d_tab_item.p, (int64_t*)plan->grp_first.p, (int32_t*)plan->grp_items.p, scal);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_scal, scal, 9 * 8, hipMemcpyDeviceToHost, c->stream);
+    } else {
+        hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, m.bad_key, scal);
+        e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    // (the tables live until the fill kernel has run: freed with the other planning scratch -- stream order keeps them valid)
+    struct TabGuard { DevBuf &a, &b, &c3; ~TabGuard() { dev_free(a); dev_free(b); dev_free(c3); } } tab_guard{d_kstart, d_tab_start, d_tab_item};
     if (e == hipSuccess) e = hipMemcpyAsync(&h_inf, scal + 5, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
     if (h_inf > 0)
         return abort_plan(fail(c, BI_ERR_INVALID, "%lld points carry an infinite rate of a source that may go negative: those are answered on "
                                                   "the host (bi_plan_points / bi_eval with host arrays)", (long long)h_inf));
-    const int64_t n_valid_all = h_scal[0];
+    const int64_t n_valid_all = h_scal[0];           // (table route: the share's window [7], [8] is the same arithmetic as below)
     plan->n_bad = P - n_valid_all;
     // the share of this context: everything, or a contiguous range of the sorted list (the arrays below are windows on it)
     const bool shared = share_world > 1;
@@ -769,6 +880,11 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     m.share_order = shared ? 1 : 0;
     if (n_valid > 0) {
         const unsigned vblk = (unsigned)((n_valid + kThreads - 1) / kThreads);
+        int64_t n_groups = 0;
+        if (by_tables) {
+            h_scal[1] = h_scal[1];                      // n_items, n_groups came with the tables
+            n_groups = h_scal[6];
+        } else {
         hipLaunchKernelGGL(k_plan_heads, dim3(vblk), dim3(kThreads), 0, c->stream, keys_s, n_valid, (int64_t*)d_a.p);
         tb = d_tmp.bytes;
         (void)prim_inclusive_scan_max(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)n_valid, c->stream);  // d_b = group start
@@ -780,11 +896,11 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         tb = d_tmp.bytes;
         (void)prim_inclusive_scan_sum(d_tmp.p, tb, (const int64_t*)d_a.p, (int64_t*)d_idx.p, (size_t)n_valid, c->stream);   // d_idx = group id + 1
         // (the two counts in ONE round trip: every host synchronisation of the planner is ~35 us of a call)
-        int64_t n_groups = 0;
         e = hipMemcpyAsync(h_scal + 1, (const int64_t*)d_keys.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&n_groups, (const int64_t*)d_idx.p + (n_valid - 1), 8, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
+        }
         const int64_t n_items = h_scal[1];
         const bool mostly_empty = c->h_nz_off.size() == (size_t)c->T + 1 && c->h_nz_off.back() <= c->T * c->B / 8;
         const bool scan_shape = c->scan_mfma && !bb && !c->unbinned && c->ps_finite && NS <= 32 && n_groups <= 65535;
@@ -843,14 +959,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             if (lds > (size_t)48 * 1024) e = hipFuncSetAttribute((const void*)k_plan_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
             hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)((n_valid + bd - 1) / bd)), dim3((unsigned)bd), lds, c->stream, m, n_valid, keys_s,
-                           idx_s, (const int64_t*)d_b.p, (const int64_t*)d_keys.p, z_dev,
+                           idx_s, by_tables ? (const int64_t*)nullptr : (const int64_t*)d_b.p, (const int64_t*)d_keys.p,
+                           (const int64_t*)d_tab_start.p, (const int64_t*)d_tab_item.p, z_dev,
                            rs_dev, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
                            (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
                            split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr, bb ? (double*)k.aux.p : (double*)nullptr,
                            bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr);
         }
         e = hipGetLastError();
-        bool tables_done = false;
+        bool tables_done = by_tables;          // (k_plan_key_tables wrote them, and the largest group into scal[3])
         auto group_tables = [&]() -> int {
             int rc2;
             if (tables_done) return BI_OK;

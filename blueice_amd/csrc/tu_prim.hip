@@ -111,6 +111,29 @@ __global__ __launch_bounds__(kPT) void k_scan_apply(const T* __restrict__ in, T*
     }
 }
 
+// up to kSmallScan elements: ONE block does the whole scan (the radix sort's digit histograms: 16 counters per tile -- 7 824 for 10^6
+// pairs; three launches for that were a third of a sorting pass)
+constexpr size_t kSmallScan = 32768;
+template <class T, class Op, bool EXCLUSIVE>
+__global__ __launch_bounds__(kPT) void k_scan_small(const T* __restrict__ in, T* __restrict__ out, size_t n, T init) {
+    __shared__ T sh[kPT];
+    __shared__ T prev[kPT];
+    const size_t per = (n + kPT - 1) / kPT;
+    const size_t lo = (size_t)threadIdx.x * per < n ? (size_t)threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+    T acc = Op::template identity<T>();
+    for (size_t i = lo; i < hi; ++i) acc = Op::apply(acc, in[i]);
+    const T incl = block_scan_inclusive<T, Op>(acc, sh, (T*)nullptr);
+    prev[threadIdx.x] = incl;
+    __syncthreads();
+    T run = threadIdx.x ? prev[threadIdx.x - 1] : Op::template identity<T>();
+    if (EXCLUSIVE) run = Op::apply(init, run);
+    for (size_t i = lo; i < hi; ++i) {
+        const T v = in[i];                  // (read before the write: in == out is allowed)
+        if (EXCLUSIVE) { out[i] = run; run = Op::apply(run, v); }
+        else { run = Op::apply(run, v); out[i] = run; }
+    }
+}
+
 size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 
 template <class T, class Op, bool EXCLUSIVE>
@@ -120,6 +143,10 @@ hipError_t scan_impl(void* tmp, size_t& bytes, const T* in, T* out, T init, size
     if (!tmp) { bytes = need; return hipSuccess; }
     if (bytes < need) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
+    if (n <= kSmallScan) {
+        hipLaunchKernelGGL((k_scan_small<T, Op, EXCLUSIVE>), dim3(1), dim3(kPT), 0, stream, in, out, n, init);
+        return hipGetLastError();
+    }
     T* totals = (T*)tmp;
     hipLaunchKernelGGL((k_scan_tile_totals<T, Op>), dim3((unsigned)nb), dim3(kPT), 0, stream, in, n, totals);
     hipLaunchKernelGGL((k_scan_spine<T, Op>), dim3(1), dim3(kPT), 0, stream, totals, nb);
