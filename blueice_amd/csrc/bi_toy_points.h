@@ -135,8 +135,8 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
 // ---- (2) the datasets' entry lists against the log mu tiles of PP points ----------------------------------------------------
 // k_dataset_dot_tiled's pipeline (rings of offsets and entries in registers, every load unconditional, runs of whole 16-byte
 // groups: see there) with PP accumulators per lane.  blockIdx.x = bin tile of TB bins, blockIdx.y = slice of the datasets,
-// blockIdx.z = pass.  LDS: s_mu[(TB + 1) * PP] (dynamic: more than 64 KB needs the function attribute), bin-major, the
-// pass's PP values of a bin adjacent; the extra slot behind the tile holds 0.0 for the padding entries of four-byte lists.
+// blockIdx.z = pass.  LDS: PP / 2 planes of (TB + 1) 16-byte cells (dynamic: more than 64 KB needs the function attribute); the
+// extra cell behind a plane holds 0.0 for the padding entries.
 // partial [passes][n_tl][n][PP].
 template <int L, int AHEAD, int W, int PP, int TB>
 __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* __restrict__ tm_entries_v, const int64_t* __restrict__ tm_off,
@@ -146,7 +146,12 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
     constexpr int EPL = 16 / W;                                        // entries per lane and load
     static_assert(EPL * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
     static_assert(PP == 2 || PP == 4, "two or four points per pass");
-    constexpr int SH = PP == 4 ? 2 : 1;                               // entry offset (bin * 8) -> LDS byte offset (bin * 8 PP)
+    // LDS layout: planes of 16-byte cells, one cell per bin -- plane 0 holds (point 0, point 1) of every bin, plane 1 (point 2,
+    // point 3) -- so that a wave's 16-byte reads of RANDOM bins spread over all eight 16-byte bank groups (bin & 7).  Round 5's
+    // first layout kept a bin's four values adjacent (32 bytes): each of the two ds_read_b128 of an entry then only ever touched
+    // every other bank group, and the kernel -- bound by LDS bank conflicts, 7.9 conflict cycles per LDS instruction on top of
+    // its 8 -- ran 120 us per pass of four points.
+    constexpr int kPlane = (TB + 1) * 16;                              // bytes per plane (+ the zero cell of the padding entries)
     const entry_t* __restrict__ tm_entries = static_cast<const entry_t*>(tm_entries_v);
     extern __shared__ double s_mu[];
     const int tl = blockIdx.x;
@@ -197,10 +202,11 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
             for (int k = 0; k < kPer; ++k) {
                 const int i2 = (threadIdx.x + k * kDotThreads) * 2;
                 const bool in = i2 < avail;
-                s_mu[i2 * PP + g] = in ? v[g][k].x : 0.0;
-                s_mu[(i2 + 1) * PP + g] = in ? v[g][k].y : 0.0;
+                double* __restrict__ cell = s_mu + (g >> 1) * (kPlane / 8) + (g & 1);
+                cell[i2 * 2] = in ? v[g][k].x : 0.0;
+                cell[(i2 + 1) * 2] = in ? v[g][k].y : 0.0;
             }
-        if (threadIdx.x < PP) s_mu[TB * PP + threadIdx.x] = 0.0;
+        if (threadIdx.x < PP) s_mu[(threadIdx.x >> 1) * (kPlane / 8) + TB * 2 + (threadIdx.x & 1)] = 0.0;
     }
 #pragma unroll
     for (int u = 0; u < kDepth; ++u) load_entries(RA[u], E[u]);
@@ -227,11 +233,11 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
                 // a two-byte entry the bit for it): 0 x 0.0, no select -- and every padding lane of a wave reads the SAME LDS
                 // address, a broadcast that costs the banks one access
                 auto add_entry = [&](uint32_t byte_off, uint32_t cnt, double (&sg)[PP]) {
-                    const double* __restrict__ q8 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_mu) + (byte_off << SH));
+                    const char* __restrict__ q8 = reinterpret_cast<const char*>(s_mu) + (byte_off << 1);    // bin * 16
                     const double nn = (double)cnt;
 #pragma unroll
                     for (int p = 0; p < PP; p += 2) {
-                        const double2 lv = *reinterpret_cast<const double2*>(q8 + p);
+                        const double2 lv = *reinterpret_cast<const double2*>(q8 + (p >> 1) * kPlane);
                         sg[p] = __builtin_fma(nn, lv.x, sg[p]);
                         sg[p + 1] = __builtin_fma(nn, lv.y, sg[p + 1]);
                     }
@@ -558,7 +564,7 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         const bool nt = c->nt_loads == 1 || (c->nt_loads == 2 && !shared_anchor);
         // the dot kernel: the datasets split over blockIdx.y so that a pass fills the chip once where it can (one resident block per
         // CU: 128 KB of LDS each)
-        const size_t lds = (size_t)(kDotTileMulti + 1) * PP * sizeof(double);
+        const size_t lds = (size_t)(kDotTileMulti + 1) * 16 * (PP / 2);            // planes of 16-byte cells (+ the zero cell)
         const int variant = (c->tmm_width == 2 ? 0 : 2) + (PP == 4 ? 0 : 1);     // {W2 PP4, W2 PP2, W4 PP4, W4 PP2}
         const int lanes = (int)c->toy_points_lanes;
         const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((n + 255) / 256, (int64_t)c->prop.multiProcessorCount / n_tl), (n + 262143) / 262144});
