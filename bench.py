@@ -371,6 +371,30 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     if can_reside:
         for bz, br in held:
             bz.free(); br.free()
+    # What ONE rank of an N-rank run does per step, measured here (one process, one GPU): this rank plans and evaluates share N/2 of
+    # N of the same resident points (bi_plan_points_resident with share_world = N) and reads the status word -- everything of a
+    # rank's step except the gather of the N vectors and the scatter into point order.  A direct measurement of what the
+    # predicted_ceiling model guesses from the N = 1 split (the model takes the whole N = 1 "everything else" as fixed per rank).
+    rehearsed = None
+    if world == 1 and can_reside and not refused:
+        rehearsed = {}
+        bz, br = ctx.device_alloc(work[-1][0].nbytes), ctx.device_alloc(work[-1][1].nbytes)
+        bz.from_host(work[-1][0]); br.from_host(work[-1][1])
+        for n_ranks in (2, 4, 8):
+            def share_step():
+                plan = ctx.plan_resident(P, bz, br, None, n_ranks // 2, n_ranks)
+                plan.run(send.ptr)
+                word = plan.status()
+                plan.close()
+                return word
+            share_step()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                share_step()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            rehearsed[str(n_ranks)] = dict(ms_per_step_of_one_share_without_gather=ms, evals_per_s_if_every_rank_does_alike=P / (ms * 1e-3))
+        bz.free(); br.free()
     # consistency on a sample, through a DIFFERENT kernel path (the single-point kernel) on THIS rank: every rank holds
     # the whole tensor, so any rank can check any point, whoever evaluated it
     z, r = work[-1]
@@ -394,7 +418,8 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
                          ('none (one process)' if world == 1 else 'host (deal_points_by_cell), inside the step')),
                 sample_max_rel_diff_vs_single_point_kernel=worst, streamed_bytes_this_rank=int(seen['bytes']), gather=ranks.kind,
                 step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, elapsed / steps * 1e3 - kernel_ms)),
-                predicted_ceiling=predicted_ceiling(P, elapsed / steps * 1e3, kernel_ms, world))
+                predicted_ceiling=predicted_ceiling(P, elapsed / steps * 1e3, kernel_ms, world),
+                rehearsed_share=rehearsed)
 
 
 def toy_leg(ctx, ranks, model, T, steps):
@@ -576,6 +601,25 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
         for _ in range(reps):
             fn()
         per_gpu[str(n_h)] = n_h * T * reps / (time.perf_counter() - t)
+    # what ONE rank of an N-rank run does per step, measured here: the hypotheses dealt to rank 0 of N, evaluated into HBM
+    # (bi_eval_datasets_points_device) -- a rank's whole step except the gather
+    rehearsed = None
+    if world == 1:
+        rehearsed = {}
+        zr, rr = work[0]
+        for n_ranks in (2, 4, 8):
+            mine = deal_points_by_cell(model.anchor_z, zr, n_ranks)[0]
+            if not len(mine):
+                continue
+            zm, rm = np.ascontiguousarray(zr[mine]), np.ascontiguousarray(rr[mine])
+            for _ in range(2):
+                ctx.eval_datasets_points_device(send.ptr, zm, rm)
+            t = time.perf_counter()
+            for _ in range(10):
+                ctx.eval_datasets_points_device(send.ptr, zm, rm)
+            ms = (time.perf_counter() - t) / 10 * 1e3
+            rehearsed[str(n_ranks)] = dict(hypotheses_of_this_share=int(len(mine)), ms_per_step_of_one_share_without_gather=ms,
+                                           evals_per_s_if_every_rank_does_alike=P * T / (ms * 1e-3))
     # algorithmic bytes of a step on this rank: per pass of 4 hypotheses the 2^d*S template rows of every distinct cell in it,
     # its 4 log mu rows written and staged once (8 B each way per bin and hypothesis), one list entry per non-empty bin of every
     # dataset -- once per PASS, not per hypothesis
@@ -604,7 +648,7 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
                 evals_per_s_per_gpu_by_hypotheses_per_call=per_gpu,
                 four_hypotheses_over_one_per_call=per_gpu['4'] / per_gpu['1'],
                 step_split_ms=dict(kernels_busiest_rank=kernel_ms, everything_else=max(0.0, step_ms - kernel_ms)),
-                predicted_ceiling=predicted_ceiling(P * T, step_ms, kernel_ms, world))
+                predicted_ceiling=predicted_ceiling(P * T, step_ms, kernel_ms, world), rehearsed_share=rehearsed)
 
 
 def c5_leg(ctx, ranks, steps=24, threads=8):

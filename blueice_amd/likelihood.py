@@ -786,6 +786,29 @@ class BinnedLogLikelihood(DeviceLogLikelihood):
         return ll + prior if not st else ll
 
 
+    @_needs_data
+    def eval_toys_points(self, points, livetime_days=None, t0=0, t1=None):
+        """Many parameter points against every uploaded / simulated dataset in ONE device call: ll [P, T].
+
+        points: dict parameter name -> array [P] (scalars broadcast; absent parameters take their defaults), as `eval_points`.
+        The toy-MC double loop -- every simulated dataset (`base_model.simulate()` + `set_data`, blueice/model.py:69-91) evaluated
+        at every hypothesis (the loops of blueice/inference.py:392-443) -- as `bi_eval_datasets_points`: the hypotheses of a
+        grid cell share the pass over its templates, four hypotheses the pass over the datasets' lists.  Rows of points outside
+        the anchor box or with unphysical rates are -inf (or raise, under unphysical_behaviour='error'), as the scalar call."""
+        z, scale, prior = self._batch_terms(points, livetime_days)
+        T = (self.ctx.T if t1 is None else t1) - t0
+        if self.model_statistical_uncertainty_handling is not None:      # Beeston-Barlow: mu depends on the data -- dataset by point
+            return np.stack([self.eval_toys(livetime_days, t0, t0 + T, **{k: float(np.broadcast_to(v, (len(z),))[i]) for k, v in points.items()})
+                             for i in range(len(z))])
+        ll, st = self.ctx.eval_datasets_points(z if z.shape[1] else None, scale, t0, t0 + T)
+        bad = st & _capi.ST_UNPHYSICAL
+        if np.any(bad) and self.config.get('unphysical_behaviour') == 'error':
+            raise ValueError("Unphysical rates at %d of %d points" % (int(np.count_nonzero(bad)), len(st)))
+        out = ll + np.asarray(prior, dtype=float).reshape(-1, 1)
+        out[(st & (_capi.ST_OUT_OF_BOUNDS | _capi.ST_UNPHYSICAL)) != 0] = -np.inf
+        return out
+
+
 class UnbinnedLogLikelihood(DeviceLogLikelihood):
     """Extended unbinned likelihood, -sum_s mu_s + sum_events log(sum_s mu_s p_s(x_e)), on the same device
     path (reference: blueice/likelihood.py:528-573, extended_loglikelihood :678-690).  `set_data` scores the

@@ -186,3 +186,28 @@ def test_random_shapes(seed):
         np.testing.assert_allclose(ll, single, rtol=1e-13, atol=0)
     finally:
         ctx.close()
+
+
+def test_through_the_likelihood_class():
+    """`lf.eval_toys_points(points)` -- the reference-style entry: a dict of parameter arrays in, ll [P, T] out -- equals one
+    `lf.eval_toys(**kw)` per hypothesis (priors, defaults and rejected points included)."""
+    import model_zoo
+    ns = model_zoo.namespace_of('blueice_amd')
+    lf, _, _ = model_zoo.d3_small(ns)
+    lf.simulate_toys(200, seed=5, shift=0.2, stretch=-0.3, tilt=0.5, s1_rate_multiplier=2.0)
+    P = 9
+    rng = np.random.default_rng(3)
+    points = dict(shift=rng.uniform(-0.9, 0.9, P), stretch=rng.uniform(-0.9, 0.9, P), tilt=np.full(P, 0.5),
+                  s1_rate_multiplier=np.linspace(0.0, 3.0, P), s0_rate_multiplier=1.3)
+    points['shift'][4] = 99.0                                            # outside the anchor box: a row of -inf
+    got = lf.eval_toys_points(points)
+    assert got.shape == (P, 200) and np.isneginf(got[4]).all()
+    for i in range(P):
+        kw = {k: float(np.broadcast_to(v, (P,))[i]) for k, v in points.items()}
+        want = lf.eval_toys(**kw)
+        if i == 4:
+            assert np.isneginf(want).all()
+        else:
+            np.testing.assert_allclose(got[i], want, rtol=1e-13, atol=0)
+    part = lf.eval_toys_points(points, t0=20, t1=120)
+    np.testing.assert_array_equal(part, got[:, 20:120])
