@@ -620,8 +620,8 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
             ms = (time.perf_counter() - t) / 10 * 1e3
             rehearsed[str(n_ranks)] = dict(hypotheses_of_this_share=int(len(mine)), ms_per_step_of_one_share_without_gather=ms,
                                            evals_per_s_if_every_rank_does_alike=P * T / (ms * 1e-3))
-    # algorithmic bytes of a step on this rank: per pass of 4 hypotheses the 2^d*S template rows of every distinct cell in it,
-    # its 4 log mu rows written and staged once (8 B each way per bin and hypothesis), one list entry per non-empty bin of every
+    # algorithmic bytes of a step on this rank: per group of two passes (8 hypotheses) the 2^d*S template rows of every distinct
+    # cell in it, per pass its 4 log mu rows written and staged once (8 B each way per bin and hypothesis), one list entry per non-empty bin of every
     # dataset -- once per PASS, not per hypothesis
     mine = deals[steps - 1][rank]
     NS = 2 ** model.d * model.S
@@ -629,13 +629,13 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
     n_pass = -(-len(mine) // 4)
     from blueice_amd.sharding import cell_ids
     ids = np.sort(cell_ids(model.anchor_z, work[steps - 1][0][mine]))
-    cells_in_passes = sum(len(np.unique(ids[i:i + 4])) for i in range(0, len(ids), 4))
+    cells_in_passes = sum(len(np.unique(ids[i:i + 8])) for i in range(0, len(ids), 8))
     nbytes = 8.0 * NS * model.B * cells_in_passes + 2 * 8.0 * model.B * len(mine) + float(entry_bytes) * nnz * n_pass
     roof = dict(bound='hbm', unit='GB/s', peak=HBM_PEAK_GBS, bytes_per_call=nbytes, list_entry_bytes=entry_bytes, launches_per_call=int(n_launch),
-                passes=n_pass, cells_in_passes=int(cells_in_passes), kernel_ms_per_call=kernel_ms,
+                passes=n_pass, cells_in_pass_groups=int(cells_in_passes), kernel_ms_per_call=kernel_ms,
                 achieved=nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None,
                 achieved_over_whole_step=nbytes / (step_ms * 1e-3) / 1e9, traffic=None,
-                kernels='k_morph_logmu_multi<4> (HBM-bound), k_dataset_dot_multi<4,2,2,4,4096> (bound by LDS bank conflicts: 64 lanes x 32 '
+                kernels='k_morph_logmu_multi<8> (HBM-bound; a cell\'s rows read once per two passes), k_dataset_dot_multi<4,2,2,4,4096> (bound by LDS bank conflicts: 64 lanes x 32 '
                         'random bytes per entry; profiles/r05_toy_points.json), k_dataset_finish_multi<4>',
                 note='algorithmic bytes per call / summed kernel time of the call (HIP events); what the call is measured by is '
                      'evaluations per second')

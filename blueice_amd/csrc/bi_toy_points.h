@@ -4,17 +4,18 @@
 // blueice/inference.py:392-443 (one likelihood call per hypothesis and dataset) around blueice/model.py:69-91 (simulate, set_data).
 // bi_eval_datasets takes ONE point: P hypotheses were P calls, each streaming the T datasets' non-empty-bin lists (188 MB at
 // BASELINE.json configs[2]) and each paying its own log mu pass (264 MB), its own three launches and its own wait.  Here:
-//   (1) k_morph_logmu_multi<PP>: the points are ordered by grid cell and chopped into PASSES of PP = 4 (or 2) points; the points
-//       of a pass that share a cell share ONE pass over the cell's 2^d S template rows (hypotheses that differ in their rates
-//       only -- the usual signal-strength scan -- always do); log mu is written one row per point, lm[pass][PP][Bp] (coalesced
-//       stores whatever the cells; the dot kernel interleaves the PP rows of its tile as it stages them);
+//   (1) k_morph_logmu_multi<GC>: the points are ordered by grid cell and chopped into PASSES of PP = 4 (or 2) points, the passes
+//       into groups of two; the points of a GROUP (GC = 2 PP) that share a cell share ONE pass over the cell's 2^d S template
+//       rows (hypotheses that differ in their rates only -- the usual signal-strength scan -- always do); log mu is written one
+//       row per point, lm[pass][PP][Bp] (coalesced stores whatever the cells; the dot kernel interleaves the PP rows of its tile
+//       as it stages them);
 //   (2) k_dataset_dot_multi<L, AHEAD, W, PP>: ONE pass over the tile-major entry lists per pass of points: a block stages the
 //       log mu of its bin tile for all PP points side by side in LDS (4096 bins x 4 points x 8 B = 128 KB of the CU's 160 KB) and
 //       an entry's one LDS address yields PP values (PP / 2 ds_read_b128): the 188 MB entry stream, the offsets, the decode and
 //       the run bookkeeping are paid once per PP evaluations of a dataset;
 //   (3) k_dataset_finish_multi: per (point, dataset) the tiles' partial sums in tile order, minus sum mu of the point and
 //       sum lgamma of the dataset -- a fixed order, bitwise reproducible -- into out[point][dataset] in the caller's point order.
-// Algorithmic bytes per call: 8 (2^d S) B per distinct grid cell of a pass + 8 PP B (log mu written and staged once) per pass
+// Algorithmic bytes per call: 8 (2^d S) B per distinct grid cell of a group of passes + 8 PP B (log mu written and staged once) per pass
 // + W bytes per list entry per PASS (not per point).
 // Included by blueice_hip.hip (main translation unit) behind the single-point toy-MC form.
 #pragma once
@@ -24,30 +25,32 @@ namespace {
 constexpr int kDotTileMulti = 4096;          // bins per tile of the multi-point lists: 4096 x 4 points x 8 B = 128 KB of LDS
 constexpr int kToyPointsMaxPP = 4;
 
-// ---- (1) log mu of the points of every pass ------------------------------------------------------------------------------
-// blockIdx.y = work item = the points of ONE pass that lie in ONE grid cell (1 .. PP of them); blockIdx.x strides over the
-// 512-bin tiles in the XCD-aware order of morph_tiles.  coef [items][NS][PP]: column g of the matrix is column g of the pass's
-// table, zero for the columns of the pass that belong to another item (another cell); meta [items][4] = {pass, first column, number
-// of columns, 0}.  Same accumulation order over the streams as k_morph_logmu (fma, k ascending): the same log mu bits.
-// partial / pflags [items][gridDim.x][PP]: sum_b mu_b and the "some mu is negative or nan" flag per column.
-template <int PP, bool NT>
+// ---- (1) log mu of the points of a group of passes ---------------------------------------------------------------------------
+// The table of a group is GC = (passes per group) x PP rows of Bp doubles, row = pass-in-group * PP + column-in-pass.
+// blockIdx.y = work item = the points of ONE group that lie in ONE grid cell (1 .. GC of them: the rows of the cell's anchors are
+// read once for all of them, across the passes of the group); blockIdx.x strides over the 512-bin tiles in the XCD-aware order
+// of morph_tiles.  coef [items][NS][GC]: column g of the matrix is row g of the group's table, zero for the rows that belong to
+// another item (another cell); meta [items][4] = {first row, number of rows, 0, 0}.  Same accumulation order over the streams as
+// k_morph_logmu (fma, k ascending): the same log mu bits.
+// partial / pflags [items][gridDim.x][GC]: sum_b mu_b and the "some mu is negative or nan" flag per row.
+template <int GC, bool NT>
 __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, const int32_t* __restrict__ meta, double* __restrict__ lm) {
     const int item = blockIdx.y;
     const int NS = a.n0;
     const int64_t* __restrict__ rowoff = a.rowoff + (int64_t)item * NS;
-    const double* __restrict__ coef = a.coef + (int64_t)item * NS * PP;
-    const int pass = meta[4 * item], col0 = meta[4 * item + 1], ncol = meta[4 * item + 2];
-    double* __restrict__ out = lm + (int64_t)pass * PP * a.Bp;        // column g of the pass: out + g * Bp
-    double sum[PP];
-    unsigned bad[PP];
+    const double* __restrict__ coef = a.coef + (int64_t)item * NS * GC;
+    const int col0 = meta[4 * item], ncol = meta[4 * item + 1];
+    double* __restrict__ out = lm;                                    // row g of the group's table: out + g * Bp
+    double sum[GC];
+    unsigned bad[GC];
 #pragma unroll
-    for (int g = 0; g < PP; ++g) { sum[g] = 0.0; bad[g] = 0u; }
+    for (int g = 0; g < GC; ++g) { sum[g] = 0.0; bad[g] = 0u; }
     log_table_load();
     const int n_tiles = a.n_tiles;
     const int chunks = (a.chunks > 1 && n_tiles >= 64 * a.chunks) ? a.chunks : 1;
     const int per_chunk = (n_tiles + chunks - 1) / chunks;
     if (ncol == 1) {
-        // (block-uniform) a point alone in its cell: one column -- the other PP - 1 accumulators would be three quarters of the
+        // (block-uniform) a point alone in its cell: one column -- the other GC - 1 accumulators would be most of the
         // kernel's fp64 work for nothing (random cells: 5.1 -> 6.x TB/s); the same operations in the same order
         double s1 = 0.0;
         unsigned b1 = 0u;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
 #pragma unroll 8
             for (int k = 0; k < NS; ++k) {
                 const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
-                const double c = coef[k * PP + col0];
+                const double c = coef[k * GC + col0];
                 m0 = fma(c, v.x, m0);
                 m1 = fma(c, v.y, m1);
             }
@@ -71,29 +74,29 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
             s1 += m0 + m1;
         }
 #pragma unroll
-        for (int g = 0; g < PP; ++g)
+        for (int g = 0; g < GC; ++g)
             if (g == col0) { sum[g] = s1; bad[g] = b1; }
     } else
     for (int lt = blockIdx.x; lt < per_chunk * chunks; lt += gridDim.x) {
         const int tile = chunks > 1 ? (lt % chunks) * per_chunk + lt / chunks : lt;
         if (tile >= n_tiles) continue;
         const int64_t bin0 = (int64_t)tile * kTile + threadIdx.x * kBinsPerThread;
-        double acc[PP][2];
+        double acc[GC][2];
 #pragma unroll
-        for (int g = 0; g < PP; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
+        for (int g = 0; g < GC; ++g) { acc[g][0] = 0.0; acc[g][1] = 0.0; }
 #pragma unroll 8
         for (int k = 0; k < NS; ++k) {
             const double2 v = stream_load<NT>(a.ps + rowoff[k] + bin0);
 #pragma unroll
-            for (int g = 0; g < PP; ++g) {
-                const double c = coef[k * PP + g];
+            for (int g = 0; g < GC; ++g) {
+                const double c = coef[k * GC + g];
                 acc[g][0] = fma(c, v.x, acc[g][0]);
                 acc[g][1] = fma(c, v.y, acc[g][1]);
             }
         }
-        double l[2][PP];
+        double l[2][GC];
 #pragma unroll
-        for (int g = 0; g < PP; ++g) {
+        for (int g = 0; g < GC; ++g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const double m = acc[g][j];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
             sum[g] += acc[g][0] + acc[g][1];
         }
 #pragma unroll
-        for (int g = 0; g < PP; ++g)
+        for (int g = 0; g < GC; ++g)
             if (g >= col0 && g < col0 + ncol) {                       // (block-uniform) the columns of this item
                 double2 w;
                 w.x = l[0][g];
@@ -111,22 +114,22 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
                 *reinterpret_cast<double2*>(out + (int64_t)g * a.Bp + bin0) = w;
             }
     }
-    __shared__ double sh[kThreads / 64][PP];
-    __shared__ unsigned shf[kThreads / 64][PP];
+    __shared__ double sh[kThreads / 64][GC];
+    __shared__ unsigned shf[kThreads / 64][GC];
 #pragma unroll
-    for (int g = 0; g < PP; ++g) {
+    for (int g = 0; g < GC; ++g) {
         const double s = wave_sum(sum[g]);
         const unsigned f = wave_or(bad[g]);
         if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][g] = s; shf[threadIdx.x >> 6][g] = f; }
     }
     __syncthreads();
-    if (threadIdx.x < PP) {
+    if (threadIdx.x < GC) {
         const int g = threadIdx.x;
         double s = sh[0][g];
         unsigned f = shf[0][g];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) { s += sh[w][g]; f |= shf[w][g]; }
-        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * PP + g;
+        const int64_t o = ((int64_t)item * gridDim.x + blockIdx.x) * GC + g;
         a.partial[o] = s;
         a.pflags[o] = f;
     }
@@ -289,12 +292,12 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
 // blockIdx.y = pass, blockIdx.x = 64 datasets; a thread adds the tiles' partial sums of ITS dataset for all PP columns of the
 // pass (the PP values of a (tile, dataset) are adjacent: 16-byte loads, every byte of a line used once), the tiles split over
 // the block's four waves as in k_dataset_finish_tiled -- a fixed order.  colmap [passes][PP][2] = {work item of the log mu
-// kernel, output row} of every column (-1: no point); mu_partial / mu_flags [items][nmu][PP].
+// kernel, output row} of every column (-1: no point); mu_partial / mu_flags [items][nmu][GC], GC = gridDim.y * PP rows of the group.
 // done != NULL: out is pinned host memory; the block that finishes last publishes `seq` there with a system-scope release.
 template <int PP>
 __global__ __launch_bounds__(kThreads) void k_dataset_finish_multi(const double* __restrict__ partial, int n_tl, const int32_t* __restrict__ colmap,
                                                                    const double* __restrict__ mu_partial, const unsigned* __restrict__ mu_flags,
-                                                                   int nmu, const double* __restrict__ lgsum, int64_t t0, int64_t n,
+                                                                   int nmu, int GC, const double* __restrict__ lgsum, int64_t t0, int64_t n,
                                                                    double* __restrict__ out, int64_t out_stride,
                                                                    unsigned* __restrict__ blocks_done, unsigned long long* done,
                                                                    unsigned long long seq) {
@@ -314,19 +317,19 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish_multi(const double*
         f[g] = 0u;
         const int item = cm[2 * g];
         if (item < 0) continue;
-        const double* __restrict__ mp = mu_partial + (int64_t)item * nmu * PP + g;
-        const unsigned* __restrict__ mf = mu_flags + (int64_t)item * nmu * PP + g;
+        const double* __restrict__ mp = mu_partial + (int64_t)item * nmu * GC + pass * PP + g;
+        const unsigned* __restrict__ mf = mu_flags + (int64_t)item * nmu * GC + pass * PP + g;
         double m4[4] = {0.0, 0.0, 0.0, 0.0};
         int b = threadIdx.x;
         for (; b + 3 * kThreads < nmu; b += 4 * kThreads) {
             double vv[4];
             unsigned gg[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { vv[k] = mp[(int64_t)(b + k * kThreads) * PP]; gg[k] = mf[(int64_t)(b + k * kThreads) * PP]; }
+            for (int k = 0; k < 4; ++k) { vv[k] = mp[(int64_t)(b + k * kThreads) * GC]; gg[k] = mf[(int64_t)(b + k * kThreads) * GC]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { m4[k] += vv[k]; f[g] |= gg[k]; }
         }
-        for (; b < nmu; b += kThreads) { m4[0] += mp[(int64_t)b * PP]; f[g] |= mf[(int64_t)b * PP]; }
+        for (; b < nmu; b += kThreads) { m4[0] += mp[(int64_t)b * GC]; f[g] |= mf[(int64_t)b * GC]; }
         m[g] = (m4[0] + m4[1]) + (m4[2] + m4[3]);
     }
     const int64_t t = (int64_t)blockIdx.x * 64 + lane;
@@ -477,21 +480,25 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
     const int PP = (c->toy_points_pp == 2 || (c->toy_points_pp == 0 && n_valid <= 2)) ? 2 : 4;
     const int n_pass = (n_valid + PP - 1) / PP;
 
-    // ---- work items of the log mu kernel: the points of a pass that share a cell ----
+    // ---- work items of the log mu kernel: the points of a GROUP of passes that share a cell ----
+    // the passes are worked in groups of kPassGroup (two): the log mu rows and the per-tile partial sums of a group live in
+    // scratch buffers that the next group reuses (stream order) -- 32 hypotheses x 10^4 datasets would otherwise want 0.6 GB of
+    // partial sums at once, beyond what the context's recycle cache parks.  A work item covers the points of a group in one
+    // cell, across its passes: eight hypotheses of one cell read the cell's anchor rows once, not once per pass.
+    constexpr int kPassGroup = 2;
+    const int GC = PP * kPassGroup;
     std::vector<int64_t> rowoff;
     std::vector<double> coef;
     std::vector<int32_t> meta, colmap((size_t)std::max(n_pass, 1) * PP * 2, -1);
     int n_items = 0;
     bool shared_anchor = false;           // two items read rows of the same anchor model (neighbouring cells share corners): then
     std::vector<char> anchor_used((size_t)c->A, 0);   // the default cache policy wins over the nontemporal hint
-    // the passes are worked in groups of kPassGroup (two): the log mu rows and the per-tile partial sums of a group live in
-    // scratch buffers that the next group reuses (stream order) -- 32 hypotheses x 10^4 datasets would otherwise want 0.6 GB of
-    // partial sums at once, beyond what the context's recycle cache parks
-    constexpr int kPassGroup = 2;
-    std::vector<int> item_begin((size_t)n_pass + 1, 0);
-    for (int ps = 0; ps < n_pass; ++ps) {
-        item_begin[(size_t)ps] = n_items;
-        const int v0 = ps * PP, v1 = std::min(n_valid, v0 + PP);
+    const int n_groups = (n_pass + kPassGroup - 1) / kPassGroup;
+    std::vector<int> item_begin((size_t)n_groups + 1, 0);
+    for (int gr = 0; gr < n_groups; ++gr) {
+        item_begin[(size_t)gr] = n_items;
+        const int v0 = gr * GC, v1 = std::min(n_valid, v0 + GC);
+        const int rows_of_group = std::min(kPassGroup, n_pass - gr * kPassGroup) * PP;   // rows of the table the dot kernel stages
         int v = v0;
         while (v < v1) {
             int w = v + 1;
@@ -499,22 +506,23 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             const PointGeom& g0 = geom[(size_t)valid[(size_t)v].idx];
             const size_t ro = rowoff.size(), co = coef.size();
             rowoff.resize(ro + NS);
-            coef.resize(co + (size_t)NS * PP, 0.0);
+            coef.resize(co + (size_t)NS * GC, 0.0);
             int k = 0;
             for (int corner = 0; corner < nc; ++corner)
                 for (int s = 0; s < S; ++s, ++k) {
                     rowoff[ro + k] = ((g0.cell_anchor + corner_offset(c, corner)) * S + s) * c->Bp;
                     for (int q = v; q < w; ++q) {
                         const int p = valid[(size_t)q].idx;
-                        coef[co + (size_t)k * PP + (q - v0)] = geom[(size_t)p].w[(size_t)corner] * rates[(size_t)p * S + s];
+                        coef[co + (size_t)k * GC + (q - v0)] = geom[(size_t)p].w[(size_t)corner] * rates[(size_t)p * S + s];
                     }
                 }
-            // a pass's last columns without a point repeat nothing: they stay zero (log 0 = -inf in the table, never read back)
-            const bool last_item_of_short_pass = (w == v1) && (v1 - v0 < PP);
-            meta.insert(meta.end(), {ps % kPassGroup, v - v0, last_item_of_short_pass ? PP - (v - v0) : w - v, 0});
+            // the last rows of a group's last pass without a point repeat nothing: they stay zero (log 0 = -inf in the table, never
+            // read back)
+            const bool last_item_of_short_group = (w == v1) && (v1 - v0 < rows_of_group);
+            meta.insert(meta.end(), {v - v0, last_item_of_short_group ? rows_of_group - (v - v0) : w - v, 0, 0});
             for (int q = v; q < w; ++q) {
-                colmap[((size_t)ps * PP + (q - v0)) * 2 + 0] = n_items;
-                colmap[((size_t)ps * PP + (q - v0)) * 2 + 1] = valid[(size_t)q].idx;
+                colmap[(size_t)q * 2 + 0] = n_items;          // [pass][column] flat = the point's place in the cell order
+                colmap[(size_t)q * 2 + 1] = valid[(size_t)q].idx;
             }
             for (int corner = 0; corner < nc; ++corner) {
                 char& used = anchor_used[(size_t)(g0.cell_anchor + corner_offset(c, corner))];
@@ -525,10 +533,9 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             v = w;
         }
     }
-    item_begin[(size_t)n_pass] = n_items;
+    item_begin[(size_t)n_groups] = n_items;
     int max_group_items = 1;
-    for (int g0 = 0; g0 < n_pass; g0 += kPassGroup)
-        max_group_items = std::max(max_group_items, item_begin[(size_t)std::min(n_pass, g0 + kPassGroup)] - item_begin[(size_t)g0]);
+    for (int gr = 0; gr < n_groups; ++gr) max_group_items = std::max(max_group_items, item_begin[(size_t)gr + 1] - item_begin[(size_t)gr]);
     const double ninf = -std::numeric_limits<double>::infinity();
     const bool host_out = !out_dev && (size_t)P * n * sizeof(double) <= ((size_t)4 << 20);
     DevBuf d_out, d_lm, d_part, d_mu;
@@ -540,7 +547,7 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
     std::vector<std::pair<const void*, size_t>> parts = {{rowoff.data(), rowoff.size() * sizeof(int64_t)}, {coef.data(), coef.size() * sizeof(double)},
                                                         {meta.data(), meta.size() * sizeof(int32_t)}, {colmap.data(), colmap.size() * sizeof(int32_t)},
                                                         {bad_rows.data(), bad_rows.size() * sizeof(int32_t)}};
-    const size_t mu_bytes = (size_t)std::max(n_items, 1) * nmu * PP * sizeof(double);
+    const size_t mu_bytes = (size_t)std::max(n_items, 1) * nmu * GC * sizeof(double);
     if ((rc = packed_upload(c, parts, host_out ? (size_t)P * n * sizeof(double) : 0, pu)) ||
         (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)std::min(n_pass, kPassGroup) * c->Bp * PP * sizeof(double)))) ||
         (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)std::min(n_pass, kPassGroup) * n_tl * n * PP * sizeof(double)))) ||
@@ -580,23 +587,23 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         }
         for (int g0 = 0; g0 < n_pass && e == hipSuccess; g0 += kPassGroup) {
             const int np = std::min(kPassGroup, n_pass - g0);
-            const int ib = item_begin[(size_t)g0], ie = item_begin[(size_t)(g0 + np)];
+            const int ib = item_begin[(size_t)(g0 / kPassGroup)], ie = item_begin[(size_t)(g0 / kPassGroup) + 1];
             const bool last = g0 + np == n_pass;
             LaunchArgs b = a;
             b.rowoff = a.rowoff + (int64_t)ib * NS;
-            b.coef = a.coef + (int64_t)ib * NS * PP;
-            b.partial = a.partial + (int64_t)ib * nmu * PP;
-            b.pflags = a.pflags + (int64_t)ib * nmu * PP;
+            b.coef = a.coef + (int64_t)ib * NS * GC;
+            b.partial = a.partial + (int64_t)ib * nmu * GC;
+            b.pflags = a.pflags + (int64_t)ib * nmu * GC;
             const int32_t* meta_dev = pu.dev<int32_t>(2) + 4 * ib;
             const dim3 lgrid((unsigned)nmu, (unsigned)(ie - ib));
             {
                 EventScope ev(c);
-#define BI_LM(PPv)                                                                                                                      \
+#define BI_LM(PPv) /* PPv: rows of a group's table */                                                                                   \
     do {                                                                                                                                \
         if (nt) hipLaunchKernelGGL((k_morph_logmu_multi<PPv, true>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p); \
         else hipLaunchKernelGGL((k_morph_logmu_multi<PPv, false>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p);   \
     } while (0)
-                if (PP == 2) BI_LM(2); else BI_LM(4);
+                if (PP == 2) BI_LM(4); else BI_LM(8);
 #undef BI_LM
             }
             const void* fn = nullptr;
@@ -624,7 +631,7 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
                 // (the completion word is published by the LAST group's finish: the stream runs the groups in order)
 #define BI_FM(PPv)                                                                                                          \
     hipLaunchKernelGGL((k_dataset_finish_multi<PPv>), fgrid, dim3(kThreads), 0, c->stream, (const double*)d_part.p, n_tl,   \
-                       pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, \
+                       pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, GC, \
                        (const double*)c->lgsum.p, t0, n, res, n, (unsigned*)c->toy_blocks_done.p, last ? done_word : (unsigned long long*)nullptr, seq)
                 if (PP == 2) BI_FM(2); else BI_FM(4);
 #undef BI_FM
