@@ -172,6 +172,7 @@ struct bi_ctx {
     int64_t n_grad_mfma_launches = 0;
     int64_t scan_xcd = 1;                        // k_scan_sorted: how the (group, block) pairs are dealt to the 8 XCDs (0 launch order, 1 contiguous ranges, 2 group g -> XCD g mod 8)
     int64_t scan_share_slow = 1;                 // parameter: k_scan_sorted deals the items of mixed-count strips over all waves of the cell
+    int64_t plan_count_sort = 1;                 // parameter: device planner: the one-pass counting sort where the keys take at most 1024 values (0: radix sort)
     int64_t plan_tables = 1;                     // parameter: device planner: group structure from per-key tables where the keys are few (0: scans over the points)
     int64_t scan_chunk = 1;                      // parameter: few groups with long item lists are cut into chunks of items, each a group of its own
     int64_t scan_waves_per_cu = 0;               // scan kernels: 0 = the planner sizes the split by occupancy; > 0 forces that many waves per CU

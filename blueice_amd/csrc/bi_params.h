@@ -72,6 +72,7 @@ const ParamDef kParams[] = {
     {"scan_share_slow", kParamRW, BI_P_GET(c->scan_share_slow), BI_P_FLAG(scan_share_slow)},
     {"scan_chunk", kParamRW, BI_P_GET(c->scan_chunk), BI_P_FLAG(scan_chunk)},
     {"plan_tables", kParamRW, BI_P_GET(c->plan_tables), BI_P_FLAG(plan_tables)},
+    {"plan_count_sort", kParamRW, BI_P_GET(c->plan_count_sort), BI_P_FLAG(plan_count_sort)},
     {"scan_bb", kParamRW, BI_P_GET(c->scan_bb), BI_P_FLAG(scan_bb)},
     {"scan_bb_min", kParamRW, BI_P_GET(c->scan_bb_min), BI_P_RANGE(1, (int64_t)1 << 40, scan_bb_min, "scan_bb_min >= 1")},
     {"scan_sparse_max_items", kParamRW, BI_P_GET(c->scan_sparse_max_items), BI_P_SET(c->scan_sparse_max_items = v < 0 ? 0 : v)},

@@ -821,16 +821,26 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     size_t tmp_bytes = 0;
     int end_bit = 1;
     while (end_bit < 64 && (m.bad_key >> end_bit) != 0) ++end_bit;
-    (void)prim_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
-                                    (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
+    // at most 1024 key values (a profile scan's cells: T = 1): the counting sort, one pass whatever the bits
+    const bool count_sort = m.bad_key + 1 <= 1024 && c->plan_count_sort;
+    if (count_sort)
+        (void)prim_count_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                                    (int64_t*)d_idx2.p, (size_t)P, (uint64_t)m.bad_key + 1, c->stream);
+    else
+        (void)prim_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                              (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
     size_t scan_bytes = 0, scan_bytes2 = 0;
     (void)prim_inclusive_scan_max(nullptr, scan_bytes, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, c->stream);
     (void)prim_inclusive_scan_sum(nullptr, scan_bytes2, (const int64_t*)d_a.p, (int64_t*)d_b.p, (size_t)P, c->stream);
     if ((rc = dev_alloc(c, d_tmp, std::max({tmp_bytes, scan_bytes, scan_bytes2, (size_t)256})))) return abort_plan(rc);
     size_t tb = d_tmp.bytes;
-    e = prim_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
-                                  (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
-    if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "radix sort: %s", hipGetErrorString(e)));
+    if (count_sort)
+        e = prim_count_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                                  (int64_t*)d_idx2.p, (size_t)P, (uint64_t)m.bad_key + 1, c->stream);
+    else
+        e = prim_sort_pairs(d_tmp.p, tb, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int64_t*)d_idx.p,
+                            (int64_t*)d_idx2.p, (size_t)P, 0u, (unsigned)end_bit, c->stream);
+    if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning sort: %s", hipGetErrorString(e)));
     // few distinct keys (A * T + 1 <= 65 536: every named configuration): the group structure from per-key tables, one round trip
     const int64_t K = (int64_t)m.bad_key;
     const bool by_tables = K <= 65536 && c->plan_tables;

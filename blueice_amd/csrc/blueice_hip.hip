@@ -2009,16 +2009,18 @@ int bi_selftest_log(bi_ctx* c, int64_t n, const double* x, double* out) {
 }
 
 // the library's own device-wide primitives (tu_prim.hip) on caller data: kind of sort 0 (uint64 keys, int64 values), 1 (int64, int32),
-// 2 (double, int32); kind of scan 0 inclusive max int64, 1 inclusive sum int64, 2 inclusive sum double, 3 exclusive sum int64 (+ init)
+// 2 (double, int32), 3 (the counting sort: uint64 keys below `end_bit` <= 1024, int64 values); kind of scan 0 inclusive max int64, 1 inclusive sum int64, 2 inclusive sum double, 3 exclusive sum int64 (+ init)
 int bi_selftest_sort(bi_ctx* c, int kind, int64_t n, const void* keys, const void* vals, int begin_bit, int end_bit, void* keys_out, void* vals_out) {
-    if (!c || n < 0 || kind < 0 || kind > 2 || begin_bit < 0 || end_bit > 64 || begin_bit > end_bit || (n > 0 && (!keys || !vals || !keys_out || !vals_out)))
+    if (!c || n < 0 || kind < 0 || kind > 3 || begin_bit < 0 || end_bit > (kind == 3 ? 1024 : 64) || begin_bit > end_bit || (kind == 3 && end_bit < 1) ||
+        (n > 0 && (!keys || !vals || !keys_out || !vals_out)))
         return BI_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t vb = kind == 0 ? 8 : 4, nn = (size_t)std::max<int64_t>(n, 1);
+    const size_t vb = (kind == 0 || kind == 3) ? 8 : 4, nn = (size_t)std::max<int64_t>(n, 1);
     DevBuf dk, dv, dk2, dv2, dt;
     auto drop = [&]() { dev_free(dk); dev_free(dv); dev_free(dk2); dev_free(dv2); dev_free(dt); };
     size_t tb = 0;
     if (kind == 0) (void)prim_sort_pairs(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
+    else if (kind == 3) (void)prim_count_sort_pairs(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)n, (uint64_t)end_bit, c->stream);
     else if (kind == 1) (void)prim_sort_pairs(nullptr, tb, (const int64_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
     else (void)prim_sort_pairs(nullptr, tb, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 64u, c->stream);
     int rc;
@@ -2029,6 +2031,7 @@ int bi_selftest_sort(bi_ctx* c, int kind, int64_t n, const void* keys, const voi
     size_t t2 = dt.bytes;
     if (e == hipSuccess) {
         if (kind == 0) e = prim_sort_pairs(dt.p, t2, (const uint64_t*)dk.p, (uint64_t*)dk2.p, (const int64_t*)dv.p, (int64_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
+        else if (kind == 3) e = prim_count_sort_pairs(dt.p, t2, (const uint64_t*)dk.p, (uint64_t*)dk2.p, (const int64_t*)dv.p, (int64_t*)dv2.p, (size_t)n, (uint64_t)end_bit, c->stream);
         else if (kind == 1) e = prim_sort_pairs(dt.p, t2, (const int64_t*)dk.p, (int64_t*)dk2.p, (const int32_t*)dv.p, (int32_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
         else e = prim_sort_pairs(dt.p, t2, (const double*)dk.p, (double*)dk2.p, (const int32_t*)dv.p, (int32_t*)dv2.p, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, c->stream);
     }

@@ -298,7 +298,114 @@ hipError_t sort_impl(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t
     return hipGetLastError();
 }
 
+
+// ---- counting sort for keys below a small bound (the device planner's cell keys of a profile scan: 126 values) ---------------
+// One pass instead of ceil(bits / 4): a histogram of the KEYS per tile ([key][tile], counters in LDS), its exclusive scan, and a
+// stable scatter in which a wave owns a contiguous quarter of the tile and walks it 64 elements at a time: an element's rank is
+// (its key in earlier tiles, from the scan) + (in earlier waves of the tile) + (earlier in the wave's walk) + (in lower lanes of
+// the same 64, from a match over the key's bits with ballots).  Same order as the radix sort gives (both are stable).
+constexpr int kCsMaxKeys = 1024;
+
+__global__ __launch_bounds__(kPT) void k_csort_hist(const uint64_t* __restrict__ keys, size_t n, int K, size_t n_tiles, int64_t* __restrict__ hist /*[K][n_tiles]*/) {
+    __shared__ unsigned cnt[kCsMaxKeys];
+    for (int i = threadIdx.x; i < K; i += kPT) cnt[i] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kPTile;
+#pragma unroll
+    for (int j = 0; j < kPI; ++j) {
+        const size_t i = base + (size_t)j * kPT + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[min((uint64_t)(K - 1), keys[i])], 1u);      // (integer counts: the order of the additions does not matter)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += kPT) hist[(size_t)i * n_tiles + blockIdx.x] = (int64_t)cnt[i];
+}
+
+template <class V>
+__global__ __launch_bounds__(kPT) void k_csort_scatter(const uint64_t* __restrict__ keys_in, const V* __restrict__ vals_in, size_t n, int K, int nbits,
+                                                       size_t n_tiles, const int64_t* __restrict__ gbase /*[K][n_tiles]: exclusive scan of hist*/,
+                                                       uint64_t* __restrict__ keys_out, V* __restrict__ vals_out) {
+    constexpr int kWaves = kPT / 64, kPerWave = kPTile / kWaves, kRounds = kPerWave / 64;
+    __shared__ unsigned cntw[kWaves][kCsMaxKeys];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int i = t; i < kWaves * kCsMaxKeys; i += kPT) (&cntw[0][0])[i] = 0u;
+    __syncthreads();
+    const size_t wbase = (size_t)blockIdx.x * kPTile + (size_t)wave * kPerWave;
+    uint64_t k[kRounds];
+    unsigned key[kRounds], rank[kRounds];
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+        const size_t i = wbase + (size_t)j * 64 + lane;
+        const bool valid = i < n;
+        k[j] = valid ? keys_in[i] : 0ull;
+        key[j] = (unsigned)min((uint64_t)(K - 1), k[j]);
+        // the lanes of this round that hold my key
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (key[j] >> b) & 1u;
+            const unsigned long long with = __ballot(valid && bit);
+            same &= bit ? with : ~with;
+        }
+        const unsigned long long below = same & ((1ull << lane) - 1ull);
+        const unsigned old = valid ? cntw[wave][key[j]] : 0u;
+        rank[j] = old + (unsigned)__popcll(below);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // every lane has read the counter before the key's first lane moves it on
+        if (valid && below == 0ull) cntw[wave][key[j]] = old + (unsigned)__popcll(same);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    for (int q = t; q < K; q += kPT) {                          // counts per wave -> the key's elements in earlier waves of the tile
+        unsigned run = 0u;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const unsigned c = cntw[w][q]; cntw[w][q] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) {
+        const size_t i = wbase + (size_t)j * 64 + lane;
+        if (i < n) {
+            const size_t dst = (size_t)gbase[(size_t)key[j] * n_tiles + blockIdx.x] + cntw[wave][key[j]] + rank[j];
+            keys_out[dst] = k[j];
+            vals_out[dst] = vals_in[i];
+        }
+    }
+}
+
+template <class V>
+hipError_t csort_impl(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const V* vals_in, V* vals_out, size_t n,
+                      uint64_t key_bound, hipStream_t stream) {
+    const size_t n_tiles = (n + kPTile - 1) / kPTile;
+    if (key_bound < 1 || key_bound > (uint64_t)kCsMaxKeys) return hipErrorInvalidValue;
+    const int K = (int)key_bound;
+    size_t scan_bytes = 0;
+    (void)scan_impl<int64_t, OpSum, true>(nullptr, scan_bytes, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)K * (n_tiles ? n_tiles : 1), stream);
+    const size_t b_hist = align256((size_t)K * (n_tiles ? n_tiles : 1) * sizeof(int64_t));
+    const size_t need = 2 * b_hist + scan_bytes;
+    if (!tmp) { bytes = need; return hipSuccess; }
+    if (bytes < need) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    int nbits = 0;
+    while ((1 << nbits) < K) ++nbits;
+    char* p = (char*)tmp;
+    int64_t* hist = (int64_t*)p; p += b_hist;
+    int64_t* gbase = (int64_t*)p; p += b_hist;
+    hipLaunchKernelGGL(k_csort_hist, dim3((unsigned)n_tiles), dim3(kPT), 0, stream, keys_in, n, K, n_tiles, hist);
+    size_t sb = scan_bytes;
+    hipError_t e = scan_impl<int64_t, OpSum, true>(p, sb, (const int64_t*)hist, gbase, (int64_t)0, (size_t)K * n_tiles, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_csort_scatter<V>), dim3((unsigned)n_tiles), dim3(kPT), 0, stream, keys_in, vals_in, n, K, nbits, n_tiles,
+                       (const int64_t*)gbase, keys_out, vals_out);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+hipError_t prim_count_sort_pairs(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const int64_t* vals_in, int64_t* vals_out,
+                                 size_t n, uint64_t key_bound, hipStream_t stream) {
+    return csort_impl<int64_t>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, key_bound, stream);
+}
 
 hipError_t prim_sort_pairs(void* tmp, size_t& bytes, const double* keys_in, double* keys_out, const int32_t* vals_in, int32_t* vals_out, size_t n,
                            unsigned begin_bit, unsigned end_bit, hipStream_t stream) {

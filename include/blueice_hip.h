@@ -437,6 +437,8 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     true> as for small batches).  Read-only n_bb_scan_launches
  *   plan_tables       device planner: where the (cell, dataset) keys are few (anchors x datasets < 65 536) the group structure of the
  *                     sorted points comes from tables over the KEYS (one small kernel) instead of three scans over the points (1, default)
+ *   plan_count_sort   device planner: keys of at most 1024 values (a profile scan: one dataset, up to 1023 grid cells) are ordered by
+ *                     a one-pass counting sort instead of the radix sort's pass per 4 bits; the same stable order (1, default)
  *   scan_chunk        matrix-core scans over few grid cells with long lists of work items (a rank's share of a dealt scan): the
  *                     item lists are cut into chunks, each worked as a group of its own, so that the chip is filled (1, default)
  *   scan_sparse_max_items   non-empty-bin form: items per grid cell up to which the matrix-core scan kernel takes the compacted rows

@@ -196,6 +196,27 @@ def test_device_planning_equals_host_planning():
     ctx.close()
 
 
+def test_counting_sort_plans_what_the_radix_sort_plans(c2):
+    """A scan over one dataset has at most anchors + 1 key values: the device planner orders them with the one-pass counting sort
+    (plan_count_sort).  Both sorts are stable, so the plans -- and every result bit -- are the same."""
+    m, ctx = c2
+    ctx.set_param('sparse', 1)
+    ctx.upload_counts(m.counts())
+    for P in (1000, 2049, 70001):
+        z, r = m.random_points(P, seed=P)
+        z[::97, 0] = 5.0                  # rejected points sort behind everything
+        r[7::89, 2] = -1.0
+        ctx.set_param('device_plan_min', 1)
+        ctx.set_param('plan_count_sort', 0)
+        a, sa = ctx.eval(z, r)
+        ctx.set_param('plan_count_sort', 1)
+        b, sb = ctx.eval(z, r)
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(a, b)
+        assert np.isneginf(a).sum() >= P // 97
+    ctx.set_param('device_plan_min', 1000)
+
+
 def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
     """Scans with many points per grid cell run on the fp64 matrix cores (k_scan_mfma): same numbers as the
     vector kernel (k_morph_reduce) and as the oracle, including -inf / nan bins."""

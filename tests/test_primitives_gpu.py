@@ -41,6 +41,12 @@ def test_sorts_equal_numpy_stable_sorts(ctx, n):
     order = np.argsort(keys, kind='stable')
     np.testing.assert_array_equal(ko, keys[order])
     np.testing.assert_array_equal(vo, vals[order])
+    for bound in (126, 1, 2, 1000, 1024):          # the counting sort: the same stable order
+        small = rng.integers(0, bound, n).astype(np.uint64)
+        ko, vo = _sort(ctx, 3, small, vals, 0, bound)
+        order = np.argsort(small, kind='stable')
+        np.testing.assert_array_equal(ko, small[order])
+        np.testing.assert_array_equal(vo, vals[order])
     wide = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64)   # all 64 bits
     ko, vo = _sort(ctx, 0, wide, vals)
     order = np.argsort(wide, kind='stable')
