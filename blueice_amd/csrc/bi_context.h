@@ -149,6 +149,8 @@ struct bi_ctx {
     void* bounce_host = nullptr;  // pinned bounce buffer of bi_memcpy_to_host / _to_device for copies of up to kBounceBytes
     size_t pack_host_bytes = 0;
     DevBuf pack_dev;
+    void* plan_host = nullptr;  // pinned: what the device planner reports back (counters, group tables) + the word the host polls for it
+    unsigned long long plan_seq = 0;
     void* slot_host = nullptr;  // pinned staging: descriptors in, {ll, status} out
     size_t slot_host_bytes = 0;
     unsigned long long slot_seq = 0;  // sequence number of single-point calls (the kernel echoes it when done)

@@ -481,6 +481,56 @@ __global__ __launch_bounds__(kThreads) void k_fill_bad_by_status(const int32_t* 
 }
 
 // model / data tables the planning kernels read, mirrored on the device once per model+data epoch
+// ---- what the planner reports back to the host ----------------------------------------------------------------------------------
+// The planner needs a few counters (and, for a rank's share of a dealt scan, the group tables) on the host twice per call.  As
+// hipMemcpyAsync into pageable memory each piece was a staged copy of ~20 us and the wait a stream synchronisation of another
+// ~20; here ONE small kernel writes the pieces through the host mapping of a pinned block and publishes a sequence number behind
+// them (system-scope release), which the host polls -- the same hand-over as the single-evaluation path's result word.
+struct ReportPiece { const uint32_t* src; uint32_t words; uint32_t dst_word; };
+constexpr size_t kPlanHostBytes = 64 * 1024;          // 128 B of counters, 4096 groups x (8 + 4) B, the word at the end
+constexpr size_t kPlanFlagWord = (kPlanHostBytes - 64) / 4;
+
+__global__ __launch_bounds__(kThreads) void k_plan_report(ReportPiece a, ReportPiece b, ReportPiece c3, uint32_t* __restrict__ dst,
+                                                          unsigned long long* flag, unsigned long long seq) {
+    for (uint32_t i = threadIdx.x; i < a.words; i += kThreads) dst[a.dst_word + i] = a.src[i];
+    for (uint32_t i = threadIdx.x; i < b.words; i += kThreads) dst[b.dst_word + i] = b.src[i];
+    for (uint32_t i = threadIdx.x; i < c3.words; i += kThreads) dst[c3.dst_word + i] = c3.src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// launch the report and wait for it; the pieces are then at ((uint32_t*)c->plan_host) + dst_word
+hipError_t plan_report(bi_ctx* c, ReportPiece a, ReportPiece b = ReportPiece{nullptr, 0, 0}, ReportPiece c3 = ReportPiece{nullptr, 0, 0}) {
+    hipError_t e = hipSuccess;
+    if (!c->plan_host) {
+        e = hipHostMalloc(&c->plan_host, kPlanHostBytes, hipHostMallocDefault);
+        if (e != hipSuccess) { c->plan_host = nullptr; return e; }
+        memset(c->plan_host, 0, kPlanHostBytes);
+    }
+    if ((size_t)a.dst_word + a.words > kPlanFlagWord || (size_t)b.dst_word + b.words > kPlanFlagWord || (size_t)c3.dst_word + c3.words > kPlanFlagWord)
+        return hipErrorInvalidValue;
+    unsigned long long* flag = (unsigned long long*)((uint32_t*)c->plan_host + kPlanFlagWord);
+    const unsigned long long seq = ++c->plan_seq;
+    hipLaunchKernelGGL(k_plan_report, dim3(1), dim3(kThreads), 0, c->stream, a, b, c3, (uint32_t*)c->plan_host, flag, seq);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (c->poll_result && !c->profiling) {
+        const volatile unsigned long long* f = flag;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        for (unsigned spin = 0; *f != seq; ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() > t_end) break;      // (a fault upstream: the synchronisation below reports it)
+        }
+        if (*f == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return hipSuccess;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
 int ensure_plan_tables(bi_ctx* c) {
     if (c->plan_tables_epoch == c->epoch) return BI_OK;
     int rc;
@@ -856,16 +906,15 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         hipLaunchKernelGGL(k_plan_key_bounds, dim3(nblk), dim3(kThreads), 0, c->stream, (const uint64_t*)d_keys2.p, P, (int64_t*)d_kstart.p);
         hipLaunchKernelGGL(k_plan_key_tables, dim3(1), dim3(kThreads), 0, c->stream, (const int64_t*)d_kstart.p, K, P, share_rank, share_world, G,
                            (int64_t*)d_tab_start.p, (int64_t*)d_tab_item.p, (int64_t*)plan->grp_first.p, (int32_t*)plan->grp_items.p, scal);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_scal, scal, 9 * 8, hipMemcpyDeviceToHost, c->stream);
     } else {
         hipLaunchKernelGGL(k_plan_count_valid, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)d_keys2.p, P, m.bad_key, scal);
-        e = hipMemcpyAsync(h_scal, scal, 8, hipMemcpyDeviceToHost, c->stream);
     }
     // (the tables live until the fill kernel has run: freed with the other planning scratch -- stream order keeps them valid)
     struct TabGuard { DevBuf &a, &b, &c3; ~TabGuard() { dev_free(a); dev_free(b); dev_free(c3); } } tab_guard{d_kstart, d_tab_start, d_tab_item};
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_inf, scal + 5, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = plan_report(c, ReportPiece{(const uint32_t*)scal, 32, 0});
     if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
+    memcpy(h_scal, c->plan_host, sizeof(h_scal));
+    h_inf = h_scal[5];
     if (h_inf > 0)
         return abort_plan(fail(c, BI_ERR_INVALID, "%lld points carry an infinite rate of a source that may go negative: those are answered on "
                                                   "the host (bi_plan_points / bi_eval with host arrays)", (long long)h_inf));
@@ -998,17 +1047,25 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
         if (e == hipSuccess && tables_early && (rc = group_tables())) return abort_plan(rc);
         std::vector<int64_t> h_grp_first;
         std::vector<int32_t> h_grp_items;
-        if (e == hipSuccess && (split || scan_ok) && c->scan_chunk && n_groups <= 4096) {
-            h_grp_first.resize((size_t)n_groups);
-            h_grp_items.resize((size_t)n_groups);
-            e = hipMemcpyAsync(h_grp_first.data(), plan->grp_first.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_grp_items.data(), plan->grp_items.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream);
-        }
         int64_t h_zero_u = 0, h_max = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && bb) e = hipMemcpyAsync(&h_zero_u, scal + 4, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && (grad_mode || bb_scan)) e = hipMemcpyAsync(&h_max, scal + 3, 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        {
+            // one report: the counters and -- where the item lists may be cut into chunks below -- the group tables
+            const bool want_tables = (split || scan_ok) && c->scan_chunk && n_groups <= 4096;
+            const uint32_t ng = want_tables ? (uint32_t)n_groups : 0u;
+            if (e == hipSuccess)
+                e = plan_report(c, ReportPiece{(const uint32_t*)scal, 32, 0}, ReportPiece{(const uint32_t*)plan->grp_first.p, 2 * ng, 32},
+                                ReportPiece{(const uint32_t*)plan->grp_items.p, ng, 32 + 2 * 4096});
+            if (e == hipSuccess) {
+                const int64_t* hs = (const int64_t*)c->plan_host;
+                h_scal[2] = hs[2];
+                if (bb) h_zero_u = hs[4];
+                if (grad_mode || bb_scan) h_max = hs[3];
+                if (want_tables) {
+                    h_grp_first.assign((const int64_t*)((const uint32_t*)c->plan_host + 32), (const int64_t*)((const uint32_t*)c->plan_host + 32) + ng);
+                    h_grp_items.assign((const int32_t*)c->plan_host + 32 + 2 * 4096, (const int32_t*)c->plan_host + 32 + 2 * 4096 + ng);
+                }
+            }
+        }
         if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning fill: %s", hipGetErrorString(e)));
         // Beeston-Barlow points at which some bin can have U_b == 0: the reference's first-root assertion then hangs on the
         // last bits of N(z), which only the host planner's pass in numpy's summation order reproduces (bb_exact_totals)

@@ -102,6 +102,7 @@ void bi_destroy(bi_ctx* c) {
     if (c->slot_host) (void)hipHostFree(c->slot_host);
     if (c->pack_host) (void)hipHostFree(c->pack_host);
     if (c->bounce_host) (void)hipHostFree(c->bounce_host);
+    if (c->plan_host) (void)hipHostFree(c->plan_host);
     dev_free(c->pack_dev);
     dev_free(c->nz_idx); dev_free(c->nz_n); dev_free(c->nz_off); dev_free(c->ps_c); dev_free(c->cnt_c); dev_free(c->tm_entries); dev_free(c->tm_off); dev_free(c->tmm_entries); dev_free(c->tmm_off);
     dev_free(c->pt_grid); dev_free(c->pt_mus); dev_free(c->pt_coff); dev_free(c->pt_allow); dev_free(c->pt_c_off);
