@@ -741,8 +741,9 @@ int bi_plan_status(bi_ctx* c, bi_plan* plan, int32_t* status_or) {
                                    0, c->stream, (const int32_t*)plan->status.p, plan->P, (int32_t*)d_or.p);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(&any, d_or.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            // (the word comes back through the planner's pinned report block: no copy into pageable memory, no stream synchronisation)
+            if (e == hipSuccess) e = plan_report(c, ReportPiece{(const uint32_t*)d_or.p, 1, 0});
+            if (e == hipSuccess) any = *(const int32_t*)c->plan_host;
             dev_free(d_or);
             if (e != hipSuccess) return fail(c, BI_ERR_HIP, "bi_plan_status: %s", hipGetErrorString(e));
         }
