@@ -169,18 +169,45 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
     if (!st) {
         bool any_fin = false, phys = true, inf_rate = false;
         double tot = 0.0;
-        for (int s = 0; s < m.S; ++s) {
-            double v = 0.0;
-            for (int corner = 0; corner < m.nc; ++corner) {
-                const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * plan_corner_weight(m, t, corner);
-                v = v + term;
-            }
+        auto judge = [&](int s, double v) {
             if (rate_scale) v *= rate_scale[p * m.S + s];
             any_fin |= (v < __builtin_inf());
             inf_rate |= (v == __builtin_inf() || v == -__builtin_inf());
             tot += v;
             if (!m.any_allow_neg) { if (!(v >= 0 && v < __builtin_inf())) phys = false; }
             else if (!(0 <= v) && !m.allow_neg[s]) phys = false;
+        };
+        constexpr int kFastS = 8;
+        if (m.S <= kFastS) {
+            // every corner's weight once (not once per source), the sources' sums side by side in registers: the same products
+            // added in the same order, a quarter of the multiplications (this kernel is bound by its fp64 instructions)
+            double teff[kMaxDim], v[kFastS];
+#pragma unroll
+            for (int i = 0; i < kMaxDim; ++i) teff[i] = i < m.de ? t[m.eff_axes[i]] : 0.0;
+#pragma unroll
+            for (int s = 0; s < kFastS; ++s) v[s] = 0.0;
+            for (int corner = 0; corner < m.nc; ++corner) {
+                double wc = 1.0;
+#pragma unroll
+                for (int i = 0; i < kMaxDim; ++i)
+                    if (i < m.de) wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? teff[i] : (1 - teff[i]));
+                const double* __restrict__ mu = m.mus + (cell + m.corner_off[corner]) * m.S;
+#pragma unroll
+                for (int s = 0; s < kFastS; ++s)
+                    if (s < m.S) { const double term = mu[s] * wc; v[s] = v[s] + term; }
+            }
+#pragma unroll
+            for (int s = 0; s < kFastS; ++s)
+                if (s < m.S) judge(s, v[s]);
+        } else {
+            for (int s = 0; s < m.S; ++s) {
+                double v = 0.0;
+                for (int corner = 0; corner < m.nc; ++corner) {
+                    const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * plan_corner_weight(m, t, corner);
+                    v = v + term;
+                }
+                judge(s, v);
+            }
         }
         if (m.any_allow_neg && (!any_fin || tot < 0)) phys = false;
         if (!phys) st = BI_ST_UNPHYSICAL;

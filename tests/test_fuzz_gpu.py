@@ -392,6 +392,77 @@ def test_toy_evaluation_random_configurations_match_oracle(seed):
 
 
 @pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_toy_points_random_configurations_match_oracle(seed):
+    """bi_eval_datasets_points (P points x T datasets: the toy-MC call over several hypotheses) on random models against the
+    oracle: hypotheses in one cell and in several, rejected points among them, dataset sub-ranges, datasets with invalid counts,
+    both list entry widths, passes of 2 and of 4 points, every lane split of the dot kernel."""
+    from blueice_amd.device import DeviceContext
+    from oracle import blueice_oracle as orc
+    rng = np.random.default_rng(17000 + seed)
+    ctx = DeviceContext(0)
+    multi_runs = 0
+    for rep in range(3):
+        d = int(rng.integers(0, 4))
+        S = int(rng.choice([1, 2, 4, 7]))
+        big = rep != 1                     # large enough for the multi-point kernels (four bin tiles, 64 datasets); else the point-by-point route
+        B = int(rng.choice([12289, 16384, 20001]) if big else rng.choice([1, 40, 1300, 4097, 9000]))
+        model, counts0 = random_case(rng, d, S, B, -1)
+        T = int(rng.choice([64, 97, 130]) if big else rng.choice([1, 3, 17, 70]))
+        if big:      # 12 ... 80 events per dataset and bin tile, drawn from the first anchor's expectation
+            lam = (model['mus'].reshape(-1, S)[0][:, None] * model['ps'].reshape(-1, S, B)[0]).sum(axis=0)
+            lam *= rng.uniform(12, 80) * -(-B // 4096) / lam.sum()
+            counts = rng.poisson(lam, size=(T, B)).astype(float)
+        else:
+            counts = np.stack([rng.poisson(counts0 * rng.uniform(0.3, 3)).astype(float) for _ in range(T)])
+        invalid_count = rng.random() < 0.3
+        if invalid_count:
+            counts[rng.integers(T), rng.integers(B)] = rng.choice([np.nan, -1.0, 2.5])
+        if rng.random() < 0.3:                                          # beyond a two-byte entry: four-byte lists; beyond those
+            huge = float(rng.choice([30000.0, 30000.0, 70000.0]))       # (32 767): point by point
+            counts[rng.integers(T), rng.integers(B)] = huge
+            invalid_count |= huge > 32767
+        if rng.random() < 0.2:
+            counts[rng.integers(T)] = 0.0                               # a dataset without events
+        ctx.upload_model(model['anchor_z'], model['ps'], model['mus'])
+        P = int(rng.choice([2, 3, 5, 8, 9]) if big else rng.choice([1, 2, 5, 13]))
+        z, r = random_points(rng, model, P, S)
+        if d and P > 2 and rng.random() < 0.6:
+            z[1:P // 2 + 1] = z[0]                                       # several hypotheses of one cell, apart in their rates
+        if d and rng.random() < 0.5:
+            z[rng.integers(P), 0] = 77.0                                 # outside the box
+        if rng.random() < 0.3:
+            r[rng.integers(P), 0] = -1.0                                 # unphysical
+        ctx.set_param('sparse', 1)
+        ctx.set_param('dot_entry16', int(rng.random() < 0.8))
+        ctx.upload_counts(counts)
+        ctx.set_param('toy_points_pp', int(rng.choice([0, 0, 2, 4])))
+        ctx.set_param('toy_points_lanes', int(rng.choice([0, 0, 2, 4, 8])))
+        for i in range(2):
+            t0 = int(rng.integers(0, T))
+            t1 = int(rng.integers(t0, T + 1)) if i else T
+            t0 = t0 if i else 0
+            before = ctx.get_param('n_toy_points_passes')
+            got, st = ctx.eval_datasets_points(z if d else None, r, t0, t1)
+            ran_multi = ctx.get_param('n_toy_points_passes') > before
+            multi_runs += ran_multi
+            # (lists with an invalid count go point by point, like ranges of fewer than 64 datasets; rejected points are rows of -inf)
+            if big and not invalid_count and i == 0 and (st == 0).any():
+                assert ran_multi, repr((seed, rep, d, S, B, T, P, st.tolist(), int((counts > 0).sum()), float(np.nanmax(counts)), {k: ctx.get_param(k) for k in ('tmm_entry_bytes', 'toy_points_pp', 'toy_points_lanes', 'dot_entry16', 'sparse')}))
+            assert got.shape == (P, t1 - t0)
+            with np.errstate(all='ignore'):
+                for p in range(P):
+                    for t in range(t0, t1):
+                        w, g = orc.loglikelihood(model, counts[t], z[p], r[p]), got[p, t - t0]
+                        ok = (np.isnan(w) and np.isnan(g)) or g == w or (np.isfinite(w) and abs(g - w) <= RTOL * max(1, abs(w)))
+                        assert ok, (seed, rep, d, S, B, T, P, p, t, g, w, st)
+        ctx.set_param('toy_points_pp', 0)
+        ctx.set_param('toy_points_lanes', 0)
+        ctx.set_param('dot_entry16', 1)
+    ctx.close()
+    print('multi-point kernels used in %d of 6 calls' % multi_runs)
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
 def test_full_output_random_configurations_match_oracle(seed):
     """bi_eval_full / bi_interpolate (full_output=True and the morpher closures, likelihood.py:355-357,424-425) on random
     models with and without Beeston-Barlow: the interpolated tensors bit for bit, the adjusted (mus, ps) and ll to 1e-10."""
