@@ -3,11 +3,14 @@ device-planned batches of >= 64 points in which no bin can have U_b == 0 -- agai
 the same per-bin operations on FMA-interpolated U but reference-order P and a: 1e-12), against the oracle (1e-10), status bits
 equal; every variant family (compile-time segments for 8 and 16 corners, run-time segments otherwise); ragged bin counts,
 rejected points, several grid cells and datasets; batches in which U_b == 0 is possible never reach the kernel."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10
+_FIRST, _COUNT = (int(v) for v in os.environ.get('BLUEICE_FUZZ_SEEDS', '0:0').split(':'))
 
 
 def _model(rng, n_anchor, S, B, T=1):
@@ -100,5 +103,67 @@ def test_batches_with_possible_zero_u_never_reach_the_matrix_core_kernel():
             assert st1[0] == st[i]
             if np.isfinite(one[0]):
                 assert one[0] == got[i]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(_FIRST, _FIRST + _COUNT) if _COUNT else range(6))
+def test_random_models_against_the_oracle(seed):
+    """Random shapes (0 ... 4 shape axes of 1 ... 3 anchors, 2 ... 8 sources, any Beeston-Barlow source, ragged bin counts, 1 ... 3
+    datasets, small and large Monte-Carlo counts, switched-off sources, points on anchors and on the grid's top edge) through the
+    device planner and k_scan_bb: EVERY point against the oracle, status bits included (BLUEICE_FUZZ_SEEDS=first:count)."""
+    from oracle import blueice_oracle as orc
+    from blueice_amd.device import DeviceContext
+    rng = np.random.default_rng(23000 + seed)
+    d = int(rng.integers(0, 5))
+    n_anchor = [int(rng.integers(1, 4)) for _ in range(d)]
+    S = int(rng.integers(2, 9))
+    B = int(rng.choice([1, 15, 16, 17, 90, 512, 700, 1300]))
+    T = int(rng.integers(1, 4))
+    bb = int(rng.integers(0, S))
+    shape = tuple(n_anchor)
+    anchor_z = [np.sort(rng.uniform(-2, 2, n)) for n in n_anchor]
+    ps = rng.random(shape + (S, B)) ** 2 + 1e-3                     # strictly positive: no bin can have U_b == 0
+    ps /= ps.sum(axis=-1, keepdims=True)
+    mus = rng.uniform(5, 60, shape + (S,)) * rng.choice([1.0, 10.0])
+    nm = np.ones(shape + (S, B))
+    nm[..., bb, :] = rng.choice([0.0, 1.0]) + rng.poisson(rng.choice([0.7, 25.0]), shape + (B,))    # (also bins without Monte-Carlo events)
+    model = dict(anchor_z=anchor_z, ps=ps, mus=mus, n_model=nm)
+    lam = (mus.reshape(-1, S)[0][:, None] * ps.reshape(-1, S, B)[0]).sum(axis=0)
+    counts = rng.poisson(lam, size=(T, B)).astype(float)
+    P = int(rng.integers(64, 200))
+    z = np.zeros((P, d))
+    for i, g in enumerate(anchor_z):
+        mode = rng.integers(0, 5, P)
+        z[:, i] = np.where(mode == 0, rng.choice(g, P), np.where(mode == 1, g[-1], rng.uniform(g[0], g[-1], P)))
+    r = rng.uniform(0.3, 2.0, (P, S))
+    off = rng.random((P, S)) < 0.08
+    off[:, bb] = False                                               # (the Beeston-Barlow source switched off: p_cal = 0, left to the vector kernels' tests)
+    off[np.arange(P), (bb + 1) % S] = False                          # one other source stays on: U_b > 0 in every bin
+    r[off] = 0.0
+    ds = rng.integers(0, T, P)
+    if d:
+        z[5, 0] = 99.0
+    r[9, (bb + 1) % S] = -1.0
+    ctx = DeviceContext(0)
+    try:
+        ctx.upload_model(anchor_z, ps, mus, n_model=nm, bb_source=bb)
+        ctx.set_param('sparse', 0)
+        ctx.upload_counts(counts)
+        ctx.set_param('device_plan_min', 1)
+        before = ctx.get_param('n_bb_scan_launches')
+        got, st = ctx.eval(z if d else None, r, dataset=ds)
+        ran = ctx.get_param('n_bb_scan_launches') - before
+        for i in range(P):
+            with np.errstate(all='ignore'):
+                try:
+                    want = orc.loglikelihood(model, counts[ds[i]], z[i], r[i], bb_source=bb)
+                except AssertionError:
+                    assert st[i] & 12, (seed, i, st[i], got[i])      # the reference's assertions on the roots: reported as status bits
+                    continue
+            g = got[i]
+            ok = (np.isnan(want) and np.isnan(g)) or g == want or (np.isfinite(want) and abs(g - want) <= RTOL * max(1.0, abs(want)))
+            assert ok, (seed, d, n_anchor, S, B, T, bb, ran, i, g, want, st[i])
+        print('k_scan_bb launches: %d' % ran)
     finally:
         ctx.close()
