@@ -36,6 +36,8 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC',
          # only the C ABI of include/blueice_hip.h is exported; the launchers between the translation units stay inside
          '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
+# kernel experiments (tools/tune_*): extra compiler arguments, part of the content hash like the others
+FLAGS += os.environ.get('BLUEICE_AMD_EXTRA_FLAGS', '').split()
 
 
 def hipcc():

@@ -17,9 +17,19 @@ namespace {
 //     k_scan_sorted (row j keeps item j) and every row takes the logarithm of another item;
 //   and the range tests are one integer minimum over the high words (negative numbers, zeros, subnormals and nans compare low
 //   or fail the window test) instead of two compares per element.
+// Measured alternatives (tools/probe/grad_variants.sh, 131 072 points of C2, kernel time): as built 3.59 ms; rows and counts
+// fetched one block ahead 4.34 ms (KG = 8 then spills 30 registers); one wave per SIMD (512 registers, no spills) 4.29 ms, with
+// the fetch ahead 4.18 ms -- two waves hide a block's load latency better than either.
+#ifndef BI_GRAD_PREFETCH
+#define BI_GRAD_PREFETCH 0
+#endif
+#ifndef BI_GRAD_WAVES
+#define BI_GRAD_WAVES 2
+#endif
 template <int KG, bool MASK>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_grad_mfma(GradMfmaArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BI_GRAD_WAVES))) void k_grad_mfma(GradMfmaArgs a) {
     constexpr int NB = KG >= 4 ? KG / 4 : 1;       // blocks of 16 streams (product 2's N dimension)
+    constexpr bool kPrefetch = BI_GRAD_PREFETCH;
     constexpr int NSP = 16 * NB;
     const int grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -63,18 +73,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int nb = 0; nb < NB; ++nb) g[j][nb] = bi_double4{0.0, 0.0, 0.0, 0.0};
     }
 
-    for (int blk = slice; blk < n_blocks; blk += a.n_slices) {
-        const int64_t bin0 = (int64_t)blk * 16;
-        double b1[KG], b2[4][NB], n4[4];
+    // (kPrefetch: the rows and counts of a block fetched one block ahead, every load unconditional -- the last block twice)
+    double b1n[KG], n4n[4];
+    auto fetch = [&](int blk) {
+        const int64_t bin0 = (int64_t)min(blk, n_blocks - 1) * 16;
         int kqo = kq;
         asm volatile("" : "+v"(kqo));                      // (opaque: keeps the LDS reads inside the loop)
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const double v = a.ps[s_rowoff[kg * 4 + kqo] + bin0 + col];
-            b1[kg] = (MASK && kg * 4 + kq >= NS) ? 0.0 : v;
-        }
+        for (int kg = 0; kg < KG; ++kg) b1n[kg] = a.ps[s_rowoff[kg * 4 + kqo] + bin0 + col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) n4[r] = cnt[bin0 + 4 * r + kq];
+        for (int r = 0; r < 4; ++r) n4n[r] = cnt[bin0 + 4 * r + kq];
+    };
+    if (kPrefetch && slice < n_blocks) fetch(slice);
+    for (int blk = slice; blk < n_blocks; blk += a.n_slices) {
+        double b1[KG], b2[4][NB], n4[4];
+        if (!kPrefetch) fetch(blk);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) b1[kg] = (MASK && kg * 4 + kq >= NS) ? 0.0 : b1n[kg];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n4[r] = n4n[r];
+        if (kPrefetch) fetch(blk + a.n_slices);
         // the second layout: element (stream s, bin b) sits in lane (s & 3, b), register s >> 2; product 2 wants it in lane
         // (b & 3, s & 15), register (b >> 2, s >> 4).  Through this wave's own LDS rows (the wave's LDS operations complete in order)
 #pragma unroll

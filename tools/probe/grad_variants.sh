@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): k_grad_mfma built four ways (rows fetched a block ahead or not, one or two waves per SIMD),
+# bi_eval_grad over 131 072 points of C2 each -> gpurun_out/grad_variants.txt.  Leaves the library built with the LAST variant on
+# the box only (the box is scratch).
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+: > gpurun_out/grad_variants.txt
+for v in "-DBI_GRAD_PREFETCH=0" "-DBI_GRAD_PREFETCH=1" "-DBI_GRAD_PREFETCH=1 -DBI_GRAD_WAVES=1" "-DBI_GRAD_PREFETCH=0 -DBI_GRAD_WAVES=1"; do
+  BLUEICE_AMD_EXTRA_FLAGS="$v" python -c "import blueice_amd.build as b; b.build()" > /dev/null 2>&1
+  echo "== $v" >> gpurun_out/grad_variants.txt
+  BLUEICE_AMD_EXTRA_FLAGS="$v" python tools/profile/grad_only.py 4 >> gpurun_out/grad_variants.txt 2>&1
+done
+cat gpurun_out/grad_variants.txt
