@@ -153,10 +153,11 @@ class Ranks:
     def report(self):
         """What the JSON line says about the gather (collective: every rank calls it)."""
         from blueice_amd.comm import describe
+        # backend_explicit: --backend was given (a fallback then ends the run non-zero); else RCCL is preferred and a fallback allowed
         if self.comm is None:
-            return dict(backend_requested=self.requested, gather_kind='none (one process)', rccl_ranks=None, rccl_version=None,
-                        rank_devices=[self.ctx.device], rank_devices_source='this process', gather_fallback_reason=None)
-        return describe(self.comm, self.requested, local_device=self.ctx.device)
+            return dict(backend_requested=self.requested, backend_explicit=self.strict, gather_kind='none (one process)', rccl_ranks=None,
+                        rccl_version=None, rank_devices=[self.ctx.device], rank_devices_source='this process', gather_fallback_reason=None)
+        return dict(describe(self.comm, self.requested, local_device=self.ctx.device), backend_explicit=self.strict)
 
     def fallback_taken(self):
         return self.strict and self.comm is not None and self.requested == 'rccl' and self.comm.kind != 'rccl'
