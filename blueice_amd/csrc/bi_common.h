@@ -42,7 +42,7 @@ namespace {
 struct EventScope {
     bi_ctx* c;
     size_t idx = (size_t)-1;
-    explicit EventScope(bi_ctx* ctx) : c(ctx) {
+    explicit EventScope(bi_ctx* ctx) : c(ctx) {       // (kernels on the context's second stream are only launched when profiling is off)
         if (!c->profiling) return;
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;

@@ -121,6 +121,9 @@ struct bi_ctx {
     int tmm_width = 4;
     int64_t toy_points_pp = 0;                // parameter: points per pass of that call (0 = by the batch: 4, or 2 for two points; 1 = point by point)
     int64_t toy_points_lanes = 0;             // parameter: lanes per (dataset, tile) run of its kernel (0 = measured default)
+    int64_t toy_points_overlap = 0;           // parameter: the log mu pass and the finish of neighbouring pass groups run on a second stream beside the dot kernel (measured: no gain)
+    hipStream_t stream2 = nullptr;            // ... that stream and its events (created on first use)
+    hipEvent_t tp_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t n_toy_points_passes = 0;          // read-only: passes over the entry lists the multi-point kernel has made
     int64_t dot_tiled = 1;                    // parameter: 0 = always the row kernel
     int64_t score_sorted = 1;                 // parameter: bi_score_events / bi_simulate_events order the events by cell before the gathers

@@ -59,6 +59,7 @@ const ParamDef kParams[] = {
          c->toy_points_pp = v;
          return BI_OK;
      }},
+    {"toy_points_overlap", kParamRW, BI_P_GET(c->toy_points_overlap), BI_P_FLAG(toy_points_overlap)},
     {"toy_points_lanes", kParamRW, BI_P_GET(c->toy_points_lanes),
      [](bi_ctx* c, int64_t v) -> int {
          if (v != 0 && v != 2 && v != 4 && v != 8) return fail(c, BI_ERR_INVALID, "toy_points_lanes: 0 = default, or 2 / 4 / 8");

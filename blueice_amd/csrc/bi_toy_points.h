@@ -548,9 +548,20 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
                                                         {meta.data(), meta.size() * sizeof(int32_t)}, {colmap.data(), colmap.size() * sizeof(int32_t)},
                                                         {bad_rows.data(), bad_rows.size() * sizeof(int32_t)}};
     const size_t mu_bytes = (size_t)std::max(n_items, 1) * nmu * GC * sizeof(double);
+    // Two groups in flight (toy_points_overlap = 1, more than one group, no per-kernel timing): the dot kernel is bound by LDS, the
+    // log mu pass and the finish by HBM -- the next group's log mu pass and the last group's finish run on the context's second
+    // (low-priority) stream BESIDE the dot kernel (a block of which leaves 32 KB of LDS and half the wave slots of its CU), each on
+    // its own half of the scratch buffers.  OFF by default: measured on 32 hypotheses x 10^4 toys of C2 the kernels do run side by
+    // side (rocprofv3 trace), but each slows the other by what it gains -- the dot kernel 200 -> 245-310 us beside a 105 us finish
+    // and a 120 us log mu pass (60 and 52 us alone): 1.37-1.41 ms per call against 1.33-1.39 in sequence
+    // (tools/probe/toy_points_overlap.py).  The same bits either way.
+    const bool overlap = c->toy_points_overlap && n_groups > 1 && !c->profiling;
+    const int n_buf = overlap ? 2 : 1;
+    const size_t lm_group = (size_t)std::min(n_pass, kPassGroup) * c->Bp * PP;                 // doubles per group
+    const size_t part_group = (size_t)std::min(n_pass, kPassGroup) * n_tl * n * PP;
     if ((rc = packed_upload(c, parts, host_out ? (size_t)P * n * sizeof(double) : 0, pu)) ||
-        (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)std::min(n_pass, kPassGroup) * c->Bp * PP * sizeof(double)))) ||
-        (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)std::min(n_pass, kPassGroup) * n_tl * n * PP * sizeof(double)))) ||
+        (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)n_buf * lm_group * sizeof(double)))) ||
+        (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)n_buf * part_group * sizeof(double)))) ||
         (rc = dev_alloc(c, d_mu, 2 * ((mu_bytes + 63) / 64 * 64))) ||
         (!host_out && !out_dev && (rc = dev_alloc(c, d_out, (size_t)P * n * sizeof(double))))) {
         cleanup();
@@ -585,28 +596,62 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             seq = ++c->toy_seq;
             *(volatile unsigned long long*)done_word = 0ull;
         }
-        for (int g0 = 0; g0 < n_pass && e == hipSuccess; g0 += kPassGroup) {
-            const int np = std::min(kPassGroup, n_pass - g0);
-            const int ib = item_begin[(size_t)(g0 / kPassGroup)], ie = item_begin[(size_t)(g0 / kPassGroup) + 1];
-            const bool last = g0 + np == n_pass;
+        hipStream_t sA = c->stream, sB = c->stream;
+        hipEvent_t *ev_lm = c->tp_ev, *ev_dot = c->tp_ev + 2, *ev_fin = c->tp_ev + 4;
+        if (overlap) {
+            if (!c->stream2) {                 // the lowest priority: the dot kernel's blocks go first wherever both could
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo);
+            }
+            for (int k = 0; k < 7 && e == hipSuccess; ++k)
+                if (!c->tp_ev[k]) e = hipEventCreateWithFlags(&c->tp_ev[k], hipEventDisableTiming);
+            if (e == hipSuccess) {
+                sB = c->stream2;
+                e = hipEventRecord(c->tp_ev[6], sA);                       // the descriptors' upload (and whatever ran before) first
+                if (e == hipSuccess) e = hipStreamWaitEvent(sB, c->tp_ev[6], 0);
+            }
+        }
+        const void* fn = nullptr;
+        auto launch_logmu = [&](int gr) {
+            const int ib = item_begin[(size_t)gr], ie = item_begin[(size_t)gr + 1];
             LaunchArgs b = a;
             b.rowoff = a.rowoff + (int64_t)ib * NS;
             b.coef = a.coef + (int64_t)ib * NS * GC;
             b.partial = a.partial + (int64_t)ib * nmu * GC;
             b.pflags = a.pflags + (int64_t)ib * nmu * GC;
             const int32_t* meta_dev = pu.dev<int32_t>(2) + 4 * ib;
+            double* lm = (double*)d_lm.p + (size_t)(gr % n_buf) * lm_group;
             const dim3 lgrid((unsigned)nmu, (unsigned)(ie - ib));
-            {
-                EventScope ev(c);
-#define BI_LM(PPv) /* PPv: rows of a group's table */                                                                                   \
-    do {                                                                                                                                \
-        if (nt) hipLaunchKernelGGL((k_morph_logmu_multi<PPv, true>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p); \
-        else hipLaunchKernelGGL((k_morph_logmu_multi<PPv, false>), lgrid, dim3(kThreads), 0, c->stream, b, meta_dev, (double*)d_lm.p);   \
+            EventScope ev(c);
+#define BI_LM(GCv) /* GCv: rows of a group's table */                                                                          \
+    do {                                                                                                                       \
+        if (nt) hipLaunchKernelGGL((k_morph_logmu_multi<GCv, true>), lgrid, dim3(kThreads), 0, sB, b, meta_dev, lm);            \
+        else hipLaunchKernelGGL((k_morph_logmu_multi<GCv, false>), lgrid, dim3(kThreads), 0, sB, b, meta_dev, lm);             \
     } while (0)
-                if (PP == 2) BI_LM(4); else BI_LM(8);
+            if (PP == 2) BI_LM(4); else BI_LM(8);
 #undef BI_LM
+        };
+        if (e == hipSuccess) {
+            launch_logmu(0);
+            if (overlap) e = hipEventRecord(ev_lm[0], sB);
+        }
+        for (int gr = 0; gr < n_groups && e == hipSuccess; ++gr) {
+            const int g0 = gr * kPassGroup;
+            const int np = std::min(kPassGroup, n_pass - g0);
+            const bool last = gr + 1 == n_groups;
+            const double* lm = (const double*)d_lm.p + (size_t)(gr % n_buf) * lm_group;
+            double* part = (double*)d_part.p + (size_t)(gr % n_buf) * part_group;
+            if (!last) {                       // the next group's log mu rows: beside this group's dot kernel when the streams differ
+                if (overlap && gr >= 1) e = hipStreamWaitEvent(sB, ev_dot[(gr + 1) % 2], 0);      // (its half of the table: read by group gr - 1)
+                if (e == hipSuccess && overlap) {
+                    launch_logmu(gr + 1);
+                    e = hipEventRecord(ev_lm[(gr + 1) % 2], sB);
+                }
             }
-            const void* fn = nullptr;
+            if (e == hipSuccess && overlap) e = hipStreamWaitEvent(sA, ev_lm[gr % 2], 0);
+            if (e == hipSuccess && overlap && gr >= 2) e = hipStreamWaitEvent(sA, ev_fin[gr % 2], 0);   // (its half of the partial sums: read by group gr - 2's finish)
+            if (e != hipSuccess) break;
             // L x AHEAD x (16 / W) entry slots per run; a run holds ~38 entries at configs[2] (tiles of 4096 bins)
 #define BI_DM(Lv, Av, Wv, PPv)                                                                                             \
     do {                                                                                                                   \
@@ -614,9 +659,9 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
         if (e == hipSuccess) {                                                                                             \
             EventScope ev(c);                                                                                              \
-            hipLaunchKernelGGL((k_dataset_dot_multi<Lv, Av, Wv, PPv, kDotTileMulti>), dgrid, dim3(kDotThreads), lds, c->stream, \
-                               (const void*)c->tmm_entries.p, (const int64_t*)c->tmm_off.p, c->T, n_tl, (const double*)d_lm.p, \
-                               c->B, c->Bp, t0, n, (double*)d_part.p);                                                     \
+            hipLaunchKernelGGL((k_dataset_dot_multi<Lv, Av, Wv, PPv, kDotTileMulti>), dgrid, dim3(kDotThreads), lds, sA,     \
+                               (const void*)c->tmm_entries.p, (const int64_t*)c->tmm_off.p, c->T, n_tl, lm,                \
+                               c->B, c->Bp, t0, n, part);                                                                  \
         }                                                                                                                  \
     } while (0)
             const dim3 dgrid((unsigned)n_tl, by, (unsigned)np);
@@ -625,17 +670,28 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             else if (variant == 2) { if (lanes == 4) BI_DM(4, 3, 4, 4); else BI_DM(8, 2, 4, 4); }
             else { if (lanes == 4) BI_DM(4, 3, 4, 2); else BI_DM(8, 2, 4, 2); }
 #undef BI_DM
+            if (e == hipSuccess && overlap) {
+                e = hipEventRecord(ev_dot[gr % 2], sA);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sB, ev_dot[gr % 2], 0);
+            }
             if (e == hipSuccess) {
                 EventScope ev(c);
                 const dim3 fgrid((unsigned)((n + 63) / 64), (unsigned)np);
-                // (the completion word is published by the LAST group's finish: the stream runs the groups in order)
+                // (the completion word is published by the LAST group's finish: the second stream runs the finishes in order, and a
+                //  group's finish follows its dot kernel)
 #define BI_FM(PPv)                                                                                                          \
-    hipLaunchKernelGGL((k_dataset_finish_multi<PPv>), fgrid, dim3(kThreads), 0, c->stream, (const double*)d_part.p, n_tl,   \
+    hipLaunchKernelGGL((k_dataset_finish_multi<PPv>), fgrid, dim3(kThreads), 0, sB, (const double*)part, n_tl,              \
                        pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, GC, \
                        (const double*)c->lgsum.p, t0, n, res, n, (unsigned*)c->toy_blocks_done.p, last ? done_word : (unsigned long long*)nullptr, seq)
                 if (PP == 2) BI_FM(2); else BI_FM(4);
 #undef BI_FM
+                if (overlap) e = hipEventRecord(ev_fin[gr % 2], sB);
             }
+            if (e == hipSuccess && !overlap && !last) launch_logmu(gr + 1);
+        }
+        if (e == hipSuccess && overlap) {      // what follows on the context's stream follows the finishes
+            e = hipStreamWaitEvent(sA, ev_fin[(n_groups - 1) % 2], 0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sA, ev_fin[n_groups % 2], 0);
         }
         c->n_toy_points_passes += n_pass;
     }
@@ -665,7 +721,7 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         ++c->n_toy_polled;
     }
     if (e == hipSuccess && (!arrived || (seq & 255ull) == 0)) e = hipStreamSynchronize(c->stream);
-    else if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);
+    else if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); if (c->stream2) (void)hipStreamSynchronize(c->stream2); }
     if (done_word && !arrived) c->toy_blocks_done_zeroed = false;
     if (e == hipSuccess && host_out) memcpy(out, res, (size_t)P * n * sizeof(double));
     cleanup();

@@ -112,6 +112,9 @@ void bi_destroy(bi_ctx* c) {
     for (auto& q : c->cache) (void)hipFree(q.p);  // last: the dev_free calls above may have parked buffers
     c->cache.clear();
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t ev : c->tp_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

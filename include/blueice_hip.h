@@ -437,6 +437,9 @@ int bi_profile_read(bi_ctx* ctx, int64_t* n_launches, double* total_ms);
  *                     true> as for small batches).  Read-only n_bb_scan_launches
  *   plan_tables       device planner: where the (cell, dataset) keys are few (anchors x datasets < 65 536) the group structure of the
  *                     sorted points comes from tables over the KEYS (one small kernel) instead of three scans over the points (1, default)
+ *   toy_points_overlap   bi_eval_datasets_points over more than 8 points: the log mu pass of the next group of passes and the finish
+ *                     of the last one on a second, low-priority stream beside the dot kernel (1); measured: the kernels run side
+ *                     by side but slow each other by as much -- no gain, hence off (0, default).  The same bits either way
  *   plan_count_sort   device planner: keys of at most 1024 values (a profile scan: one dataset, up to 1023 grid cells) are ordered by
  *                     a one-pass counting sort instead of the radix sort's pass per 4 bits; the same stable order (1, default)
  *   scan_chunk        matrix-core scans over few grid cells with long lists of work items (a rank's share of a dealt scan): the

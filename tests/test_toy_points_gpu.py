@@ -188,6 +188,39 @@ def test_random_shapes(seed):
         ctx.close()
 
 
+def test_second_stream_gives_the_same_bits():
+    """toy_points_overlap = 1: the next group's log mu pass and the last group's finish on a second stream beside the dot kernel, on
+    their own halves of the scratch buffers -- 20 points in random cells (three groups of passes), twice, bitwise what one stream gives."""
+    from blueice_amd.device import DeviceContext
+    from blueice_amd.synthetic import SyntheticModel
+    m = SyntheticModel(3, (3, 3), (150, 120), seed=5)
+    ctx = DeviceContext(0)
+    try:
+        m.upload(ctx)
+        rng = np.random.default_rng(77)
+        T = 150
+        counts = np.zeros((T, m.B))
+        for t in range(T):
+            hit = rng.choice(m.B, size=300, replace=False)
+            counts[t, hit] = rng.integers(1, 7, size=300)
+        ctx.set_param('sparse', 1)
+        ctx.upload_counts(counts)
+        z, r = m.random_points(20, seed=9)
+        z[7, 0] = 99.0                                                    # a rejected point among them
+        one, st1 = ctx.eval_datasets_points(z, r)
+        before = ctx.get_param('n_toy_points_passes')
+        ctx.set_param('toy_points_overlap', 1)
+        for _ in range(2):
+            two, st2 = ctx.eval_datasets_points(z, r)
+            np.testing.assert_array_equal(st1, st2)
+            np.testing.assert_array_equal(one, two)
+        assert ctx.get_param('n_toy_points_passes') == before + 2 * 5     # 19 valid points: five passes per call
+        part, _ = ctx.eval_datasets_points(z, r, 10, 140)
+        np.testing.assert_array_equal(part, one[:, 10:140])
+    finally:
+        ctx.close()
+
+
 def test_through_the_likelihood_class():
     """`lf.eval_toys_points(points)` -- the reference-style entry: a dict of parameter arrays in, ll [P, T] out -- equals one
     `lf.eval_toys(**kw)` per hypothesis (priors, defaults and rejected points included)."""
