@@ -142,30 +142,59 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
             //   * the special case of bins with U_b == 0 (:652-653) costs a division: computed only when some lane has such a bin;
             //   * the logarithm's checked form (zero, subnormal, negative, infinite, nan arguments) only when some lane needs it.
             const bool whole = bin0 + kBbTile <= a.B;                      // (scalar) every bin of the tile is a bin of the model
+            //   * a tile WITHOUT events (all 16 counts zero: 98 % of the tiles of configs[4]'s data) -- wave-uniform: the
+            //     discriminant's four terms with the count as a factor are +0 (finite operands), and x - 0 = x + 0 = x bit for
+            //     bit (the partial sums are positive), likewise `+ n p` of the leading term; and the bin's Poisson term is -mu
+            //     without a logarithm (scipy: xlogy(0, mu) - gammaln(1) - mu).  With a non-finite p (a bin without Monte-Carlo
+            //     events: a = 0) the skipped 0 x inf would have been nan -- where another term already is (2 U a p^2 = 0 x inf).
             double n4[4], mu4[4], A4[4], lead4[4], sq4[4], den4[4];
             bool uzero = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = 4 * r + kq;                               // element r of this lane: bin b of the tile, point col
-                const double n = s_rows[buf][KGT * 4][b];
-                const double U = aU[r], ab = aA[r];
-                const double w = aP[r] / ab * Ntot;
-                const double p = w * p_cal;
-                double lead, sq, den;
-                {
+            for (int r = 0; r < 4; ++r) n4[r] = s_rows[buf][KGT * 4][4 * r + kq];   // element r of this lane: bin 4 r + kq of the tile, point col
+            const bool empty_tile = __builtin_amdgcn_ballot_w64(n4[0] == 0.0 && n4[1] == 0.0 && n4[2] == 0.0 && n4[3] == 0.0) == ~0ull;
+            if (empty_tile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double U = aU[r], ab = aA[r];
+                    const double w = aP[r] / ab * Ntot;
+                    const double p = w * p_cal;
+                    double lead, sq, den;
+                    {
 #pragma clang fp contract(off)
-                    const double U2 = U * U, p2 = p * p, a2 = ab * ab, d2 = n * n;
-                    const double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * ab * p2 + 2 * U * ab * p - 2 * U * n * p2 - 2 * U * n * p +
-                                        a2 * p2 + 2 * ab * n * p2 + d2 * p2;
-                    lead = -U * p - U + ab * p + n * p;
-                    den = 2 * p * (p + 1);
-                    sq = sqrt(disc);
+                        const double U2 = U * U, p2 = p * p, a2 = ab * ab;
+                        const double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * ab * p2 + 2 * U * ab * p + a2 * p2;
+                        lead = -U * p - U + ab * p;
+                        den = 2 * p * (p + 1);
+                        sq = sqrt(disc);
+                    }
+                    lead4[r] = lead; sq4[r] = sq; den4[r] = den;
+                    A4[r] = (lead + sq) / den;
+                    uzero |= (U == 0.0);
+                    mu4[r] = w;
                 }
-                const double r2 = (lead + sq) / den;
-                n4[r] = n; lead4[r] = lead; sq4[r] = sq; den4[r] = den;
-                A4[r] = r2;
-                uzero |= (U == 0.0);
-                mu4[r] = w;                                              // (w for now: mu once A is final)
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double n = n4[r];
+                    const double U = aU[r], ab = aA[r];
+                    const double w = aP[r] / ab * Ntot;
+                    const double p = w * p_cal;
+                    double lead, sq, den;
+                    {
+#pragma clang fp contract(off)
+                        const double U2 = U * U, p2 = p * p, a2 = ab * ab, d2 = n * n;
+                        const double disc = U2 * p2 + 2 * U2 * p + U2 + 2 * U * ab * p2 + 2 * U * ab * p - 2 * U * n * p2 - 2 * U * n * p +
+                                            a2 * p2 + 2 * ab * n * p2 + d2 * p2;
+                        lead = -U * p - U + ab * p + n * p;
+                        den = 2 * p * (p + 1);
+                        sq = sqrt(disc);
+                    }
+                    const double r2 = (lead + sq) / den;
+                    lead4[r] = lead; sq4[r] = sq; den4[r] = den;
+                    A4[r] = r2;
+                    uzero |= (U == 0.0);
+                    mu4[r] = w;                                              // (w for now: mu once A is final)
+                }
             }
             if (__builtin_amdgcn_ballot_w64(uzero) != 0ull) {              // likelihood.py:652-653, scalar p_cal
 #pragma unroll
@@ -193,7 +222,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
                 }
             }
             double term[4];
-            if (__builtin_amdgcn_ballot_w64(checked) == 0ull) {
+            if (empty_tile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) term[r] = poisson_term_nolog(n4[r], mu4[r]);
+            } else if (__builtin_amdgcn_ballot_w64(checked) == 0ull) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) term[r] = poisson_term_fast(n4[r], mu4[r]);
             } else {
