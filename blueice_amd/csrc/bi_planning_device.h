@@ -543,12 +543,19 @@ hipError_t plan_report(bi_ctx* c, ReportPiece a, ReportPiece b = ReportPiece{nul
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (c->poll_result && !c->profiling) {
         const volatile unsigned long long* f = flag;
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        const auto t_start = std::chrono::steady_clock::now();
+        const auto t_spin = t_start + std::chrono::microseconds(100), t_end = t_start + std::chrono::milliseconds(20);
+        bool yielding = false;                 // (the planning kernels of a large batch take a while: the core is given away after 100 us)
         for (unsigned spin = 0; *f != seq; ++spin) {
+            if (yielding) {
+                sched_yield();
+                if (std::chrono::steady_clock::now() > t_end) break;                           // (a fault upstream: the synchronisation below reports it)
+                continue;
+            }
 #if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
 #endif
-            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() > t_end) break;      // (a fault upstream: the synchronisation below reports it)
+            if ((spin & 63u) == 63u && std::chrono::steady_clock::now() > t_spin) yielding = true;
         }
         if (*f == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
