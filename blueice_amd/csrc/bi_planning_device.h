@@ -154,11 +154,20 @@ __device__ __forceinline__ double plan_corner_weight(const PlanMeta& m, const do
 // per point: status and sort key.  Weights and rates are NOT written out (round 4 wrote 96 bytes per point here and gathered
 // them back through the sort's permutation in k_plan_fill: 0.3 of that kernel's 0.5 ms): the fill kernel rebuilds them from
 // the point's 56 bytes of z and rate_scale.
+// MUS_LDS: the anchors' rate table ([A][S] doubles, n_rows of them: 4 KB at C2) is staged in LDS first -- a point reads 2^d S
+// entries of it at ITS cell, a gather in which the 64 lanes of a wave touch up to 64 cache lines per load: 32 such loads per
+// point were the kernel's time (53 us per 10^6 points of C2; from LDS: see DESIGN.md 5.6).
+template <bool MUS_LDS>
 __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t P, const double* __restrict__ z,
                                                             const double* __restrict__ rate_scale,
                                                             const int64_t* __restrict__ dataset,
                                                             uint64_t* __restrict__ keys, int64_t* __restrict__ idx,
                                                             int32_t* __restrict__ status, unsigned long long* __restrict__ n_inf) {
+    extern __shared__ double s_geo_mus[];
+    if (MUS_LDS) {
+        for (int64_t i = threadIdx.x; i < m.n_rows; i += kThreads) s_geo_mus[i] = m.mus[i];
+        __syncthreads();
+    }
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (p >= P) return;
     idx[p] = p;
@@ -191,10 +200,10 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
 #pragma unroll
                 for (int i = 0; i < kMaxDim; ++i)
                     if (i < m.de) wc = wc * (((corner >> (m.de - 1 - i)) & 1) ? teff[i] : (1 - teff[i]));
-                const double* __restrict__ mu = m.mus + (cell + m.corner_off[corner]) * m.S;
+                const int64_t mrow = (cell + m.corner_off[corner]) * m.S;
 #pragma unroll
                 for (int s = 0; s < kFastS; ++s)
-                    if (s < m.S) { const double term = mu[s] * wc; v[s] = v[s] + term; }
+                    if (s < m.S) { const double term = (MUS_LDS ? s_geo_mus[mrow + s] : m.mus[mrow + s]) * wc; v[s] = v[s] + term; }
             }
 #pragma unroll
             for (int s = 0; s < kFastS; ++s)
@@ -203,7 +212,8 @@ __global__ __launch_bounds__(kThreads) void k_plan_geometry(PlanMeta m, int64_t 
             for (int s = 0; s < m.S; ++s) {
                 double v = 0.0;
                 for (int corner = 0; corner < m.nc; ++corner) {
-                    const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * plan_corner_weight(m, t, corner);
+                    const int64_t mi = (cell + m.corner_off[corner]) * m.S + s;
+                    const double term = (MUS_LDS ? s_geo_mus[mi] : m.mus[mi]) * plan_corner_weight(m, t, corner);
                     v = v + term;
                 }
                 judge(s, v);
@@ -338,7 +348,9 @@ __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ 
                             double* __restrict__ slot_lg, unsigned long long* __restrict__ tile_sum,
                             int64_t* __restrict__ rowoff_full /* split scans, else NULL */,
                             double* __restrict__ aux /* Beeston-Barlow: [items][G][2], else NULL */,
-                            unsigned long long* __restrict__ n_zero_u /* Beeston-Barlow, else NULL */) {
+                            unsigned long long* __restrict__ n_zero_u /* Beeston-Barlow, else NULL */,
+                            int mus_lds /* the rate table [n_rows] staged in LDS behind the per-thread arrays */,
+                            int tz_lds /* ... and behind it the per-row constants (row sums, or the T = 1 dataset's Tz) */) {
     // (the items' tile counts are summed per block first: one atomic per work item on ONE address -- 62 500 of them for a
     //  10^6-point scan -- was half of this kernel's 0.5 ms)
     __shared__ unsigned long long s_tiles;
@@ -348,6 +360,13 @@ __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ 
     double* __restrict__ s_rs = s_z + (size_t)m.d * BD;            // [S][BD]   rate scales, then the rates
     double* __restrict__ s_w = s_rs + (size_t)m.S * BD;            // [nc][BD]
     int64_t* __restrict__ s_idx = reinterpret_cast<int64_t*>(s_w + (size_t)m.nc * BD);   // [BD]
+    // the small per-row tables every point gathers from at ITS cell (2^d S entries each: up to 64 cache lines per wave-level load
+    // from global memory) -- staged once per block where they fit (k_plan_geometry<true> does the same)
+    double* __restrict__ s_mus = reinterpret_cast<double*>(s_idx + BD);                  // [n_rows] if mus_lds
+    double* __restrict__ s_tz = s_mus + (mus_lds ? m.n_rows : 0);                        // [n_rows] if tz_lds
+    const double* __restrict__ tz_src = m.linear_outside ? m.rowsum : m.Tz;             // (tz_lds with Tz only when T == 1)
+    if (mus_lds) for (int64_t e = tx; e < m.n_rows; e += BD) s_mus[e] = m.mus[e];
+    if (tz_lds) for (int64_t e = tx; e < m.n_rows; e += BD) s_tz[e] = tz_src[e];
     if (tx == 0) s_tiles = 0ull;
     const int64_t i0 = (int64_t)blockIdx.x * BD;
     const int64_t i = i0 + tx;
@@ -395,7 +414,8 @@ __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ 
     for (int s = 0; s < m.S; ++s) {
         double v = 0.0;
         for (int corner = 0; corner < m.nc; ++corner) {
-            const double term = m.mus[(cell + m.corner_off[corner]) * m.S + s] * s_w[corner * BD + tx];
+            const int64_t mi = (cell + m.corner_off[corner]) * m.S + s;
+            const double term = (mus_lds ? s_mus[mi] : m.mus[mi]) * s_w[corner * BD + tx];
             v = v + term;
         }
         if (rate_scale) v *= s_rs[s * BD + tx];
@@ -417,7 +437,8 @@ __global__ void k_plan_fill(PlanMeta m, int64_t n, const uint64_t* __restrict__ 
         for (int s = 0; s < m.S; ++s) {                     // (unrolled: the Tz loads of a corner go out together)
             if (bb && s == m.bb_source) continue;
             const double cf = wc * R_(s);
-            const double tz = m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0);
+            const double tz = tz_lds ? s_tz[a * m.S + s]
+                                     : (m.linear_outside ? m.rowsum[a * m.S + s] : (m.sparse ? m.Tz[ds * m.n_rows + a * m.S + s] : 0.0));
             for (int gg = g; gg < g_end; ++gg) coef[(item * NS + k) * G + gg] = cf;
             if (m.sparse || m.linear_outside) zsum += cf * tz;
             if (g == 0) {
@@ -898,8 +919,12 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
     // bin can have U_b == 0  [5] points with an infinite rate that the reference evaluates (sources that may go negative)
     int64_t* scal = (int64_t*)d_scal.p;
     HIP_TRY(c, hipMemsetAsync(scal, 0, 128, c->stream));
-    hipLaunchKernelGGL(k_plan_geometry, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
-                       (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p, (unsigned long long*)(scal + 5));
+    if ((size_t)m.n_rows * sizeof(double) <= (size_t)32 * 1024)
+        hipLaunchKernelGGL(k_plan_geometry<true>, dim3(nblk), dim3(kThreads), (size_t)m.n_rows * sizeof(double), c->stream, m, P, z_dev, rs_dev, ds_dev,
+                           (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p, (unsigned long long*)(scal + 5));
+    else
+        hipLaunchKernelGGL(k_plan_geometry<false>, dim3(nblk), dim3(kThreads), 0, c->stream, m, P, z_dev, rs_dev, ds_dev,
+                           (uint64_t*)d_keys.p, (int64_t*)d_idx.p, (int32_t*)plan->status.p, (unsigned long long*)(scal + 5));
     // sort (key, point) pairs: keys are cell * T + dataset < A * T, rejected points carry A * T -- the radix sort walks only the
     // bits that can differ (C2: 7 bits, one pass over the pairs; round 4 sorted all 64 bits of a key whose rejected points were ~0)
     size_t tmp_bytes = 0;
@@ -1048,7 +1073,11 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
             const size_t per_thread = (size_t)(d + 2 * S + nc) * sizeof(double) + sizeof(int64_t);
             int bd = kThreads;
             while (bd > 64 && per_thread * bd > (size_t)64 * 1024) bd >>= 1;
-            const size_t lds = per_thread * bd;
+            // the rate table and the per-row constants behind them where they fit (16 KB each)
+            const size_t table = (size_t)m.n_rows * sizeof(double);
+            const int mus_lds = table <= (size_t)16 * 1024;
+            const int tz_lds = mus_lds && (m.linear_outside || (m.sparse && c->T == 1));
+            const size_t lds = per_thread * bd + (mus_lds ? table : 0) + (tz_lds ? table : 0);
             if (lds > (size_t)48 * 1024) e = hipFuncSetAttribute((const void*)k_plan_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return abort_plan(fail(c, BI_ERR_HIP, "device planning: %s", hipGetErrorString(e)));
             hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)((n_valid + bd - 1) / bd)), dim3((unsigned)bd), lds, c->stream, m, n_valid, keys_s,
@@ -1057,7 +1086,7 @@ int plan_points_device(bi_ctx* c, int64_t P, const double* z, const double* rate
                            rs_dev, (int64_t*)k.rowoff.p, (double*)k.coef.p, (int64_t*)k.item_cnt.p,
                            (int32_t*)k.item_tiles.p, (int64_t*)k.perm.p, (double*)k.slot_lg.p, (unsigned long long*)(scal + 2),
                            split ? (int64_t*)k.rowoff_full.p : (int64_t*)nullptr, bb ? (double*)k.aux.p : (double*)nullptr,
-                           bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr);
+                           bb ? (unsigned long long*)(scal + 4) : (unsigned long long*)nullptr, mus_lds, tz_lds);
         }
         e = hipGetLastError();
         bool tables_done = by_tables;          // (k_plan_key_tables wrote them, and the largest group into scal[3])
