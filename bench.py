@@ -553,17 +553,28 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
 
     result_buffer = np.empty((P, T))                     # (reused: a fresh 2.5 MB array per call costs ~0.1 ms of page faults)
 
-    def step(k):
+    def step(k, fetch=True):
+        """fetch = False: the [P][T] matrix stays in HBM (where a device-side consumer -- a reduction to test statistics, the next
+        stage of a toy-MC chain -- takes it; one rank: this rank's send buffer, N ranks: the gathered [N][n_max T] buffer) and only
+        the status words come back: the leg's `value`, like the scan legs'.  fetch = True: the matrix is also copied to the host."""
         z, r = work[k]
         if world == 1:
-            out, st = ctx.eval_datasets_points(z, r, out=result_buffer)
+            if fetch:
+                out, st = ctx.eval_datasets_points(z, r, out=result_buffer)
+            else:
+                out, st = None, ctx.eval_datasets_points_device(send.ptr, z, r)
             return out, int(np.bitwise_or.reduce(st))
         mine = deals[k][rank]
         st = ctx.eval_datasets_points_device(send.ptr, z[mine], r[mine]) if len(mine) else np.zeros(0, np.int32)
-        parts = ranks.gather(n_max * T)
-        out = np.empty((P, T))
-        for idx, vals in zip(deals[k], parts):
-            out[idx] = vals[:len(idx) * T].reshape(len(idx), T)
+        out = None
+        if fetch:
+            parts = ranks.gather(n_max * T)
+            out = np.empty((P, T))
+            for idx, vals in zip(deals[k], parts):
+                out[idx] = vals[:len(idx) * T].reshape(len(idx), T)
+        else:
+            ranks.gather_on_device(n_max * T)
+            ctx.sync()
         return out, int(np.bitwise_or.reduce(st)) if len(st) else 0
 
     step(-1)
@@ -572,8 +583,23 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
     for k in range(steps):
         out, st = step(k)
     ranks.barrier()
-    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    elapsed_fetch = ranks.max_over_ranks(time.perf_counter() - t0)
     assert st == 0 and out.shape == (P, T) and np.all(np.isfinite(out))
+    step(-1, fetch=False)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        _, st2 = step(k, fetch=False)
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    assert st2 == 0
+    if world == 1:                                       # what was left in HBM is what the fetching step delivered (same call, same bits)
+        kept = send.to_host(np.float64, P * T).reshape(P, T)
+        assert np.array_equal(kept, out), 'toy hypotheses: the matrix left in HBM differs from the one fetched'
+    else:
+        kept = ranks.buffers(n_max * T)[1].to_host(np.float64, world * n_max * T).reshape(world, n_max * T)
+        for idx, vals in zip(deals[steps - 1], kept):
+            assert np.array_equal(vals[:len(idx) * T].reshape(len(idx), T), out[idx]), 'toy hypotheses: the gathered matrix left in HBM differs from the one fetched'
     # cross-rank consistency through ANOTHER path: hypotheses another rank evaluated, re-evaluated here one at a time
     # (bi_eval_datasets: tiles of 8192 bins, one point per pass) -- the same sums in another grouping
     z, r = work[steps - 1]
@@ -582,9 +608,9 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
         one, _ = ctx.eval_datasets(z[p], r[p])
         worst = max(worst, float(np.max(np.abs(one - out[p]) / np.abs(one))))
     assert worst <= 1e-12, 'toy hypotheses: gathered values differ from single-point calls by %.2e' % worst
-    step(0)
+    step(0, fetch=False)
     ctx.profile(True)
-    step(0)
+    step(0, fetch=False)
     n_launch, kernel_ms = ctx.profile_read()
     ctx.profile(False)
     kernel_ms = ranks.max_over_ranks(kernel_ms)
@@ -644,6 +670,9 @@ def toy_points_leg(ctx, ranks, model, T, P, steps):
     return dict(workload='C3: 10^4 toy datasets (drawn on the device) x %d hypotheses per step (%d grid cells x %d signal strengths), '
                          'hypotheses dealt over the ranks by grid cell, every rank holds all datasets' % (P, max(1, P // 8), P // max(1, P // 8)),
                 scaling='strong', datasets=T, hypotheses=P, steps=steps, value=P * T * steps / elapsed, unit='evals/s', ms_per_step=step_ms,
+                results='the [hypotheses][datasets] matrix left in HBM (status words read back); value_results_to_host: the same step with '
+                        'the matrix copied to the host as well',
+                value_results_to_host=P * T * steps / elapsed_fetch, ms_per_step_results_to_host=elapsed_fetch / steps * 1e3,
                 generate_s=gen_s, hypotheses_per_rank_min_max=[min(len(d) for d in deals[0]), max(len(d) for d in deals[0])],
                 max_rel_diff_vs_single_point_calls=worst, nonempty_bins=nnz, gather=ranks.kind, roofline=roof,
                 evals_per_s_per_gpu_by_hypotheses_per_call=per_gpu,

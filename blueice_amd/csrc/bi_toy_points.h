@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kDotTileMulti = 4096;          // bins per tile of the multi-point lists: 4096 x 4 points x 8 B = 128 KB of LDS
 constexpr int kToyPointsMaxPP = 4;
+constexpr int kPartBlock = 32;               // datasets per block of the per-(tile, dataset) partial sums
 
 // ---- (1) log mu of the points of a group of passes ---------------------------------------------------------------------------
 // The table of a group is GC = (passes per group) x PP rows of Bp doubles, row = pass-in-group * PP + column-in-pass.
@@ -140,11 +141,23 @@ __global__ __launch_bounds__(kThreads) void k_morph_logmu_multi(LaunchArgs a, co
 // groups: see there) with PP accumulators per lane.  blockIdx.x = bin tile of TB bins, blockIdx.y = slice of the datasets,
 // blockIdx.z = pass.  LDS: PP / 2 planes of (TB + 1) 16-byte cells (dynamic: more than 64 KB needs the function attribute); the
 // extra cell behind a plane holds 0.0 for the padding entries.
-// partial [passes][n_tl][n][PP].
+// partial [passes][dataset blocks of kPartBlock][n_tl][kPartBlock][PP].
+// The block of tile 0 / slice 0 of every pass first adds up sum mu (and the "some mu negative or nan" flags) of the pass's PP points
+// from the block partials of their log mu work items -- a fixed order: thread-strided, wave, the 16 waves in turn -- into
+// MuTotals::tot / flag [pass in group][PP]: the finish kernel reads PP numbers instead of every one of its blocks adding them up.
+struct MuTotals {
+    const int32_t* colmap;        // [passes of the group][PP][2] = {work item of the log mu kernel, output row} (-1: no point)
+    const double* partial;        // [items][nmu][GC]
+    const unsigned* flags;
+    int nmu, GC;
+    double* tot;
+    unsigned* flag;
+};
+
 template <int L, int AHEAD, int W, int PP, int TB>
 __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* __restrict__ tm_entries_v, const int64_t* __restrict__ tm_off,
                                                                    int64_t T, int n_tl, const double* __restrict__ lm, int64_t B,
-                                                                   int64_t Bp, int64_t t0, int64_t n, double* __restrict__ partial) {
+                                                                   int64_t Bp, int64_t t0, int64_t n, double* __restrict__ partial, MuTotals mt) {
     typedef typename std::conditional<W == 2, uint16_t, uint32_t>::type entry_t;
     constexpr int EPL = 16 / W;                                        // entries per lane and load
     static_assert(EPL * L * AHEAD + 16 <= kDotPad, "the lists' padding must cover the read-ahead");
@@ -157,6 +170,35 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
     constexpr int kPlane = (TB + 1) * 16;                              // bytes per plane (+ the zero cell of the padding entries)
     const entry_t* __restrict__ tm_entries = static_cast<const entry_t*>(tm_entries_v);
     extern __shared__ double s_mu[];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                          // (block-uniform)
+        __shared__ double sh_m[kDotThreads / 64][PP];
+        __shared__ unsigned sh_f[kDotThreads / 64][PP];
+        const int pz = blockIdx.z;
+#pragma unroll
+        for (int g = 0; g < PP; ++g) {
+            const int gc = pz * PP + g;
+            const int item = mt.colmap[2 * gc];
+            double m = 0.0;
+            unsigned f = 0u;
+            if (item >= 0) {
+                const double* __restrict__ mp = mt.partial + (int64_t)item * mt.nmu * mt.GC + gc;
+                const unsigned* __restrict__ mf = mt.flags + (int64_t)item * mt.nmu * mt.GC + gc;
+                for (int b = threadIdx.x; b < mt.nmu; b += kDotThreads) { m += mp[(int64_t)b * mt.GC]; f |= mf[(int64_t)b * mt.GC]; }
+            }
+            const double mw = wave_sum(m);
+            const unsigned fw = wave_or(f);
+            if ((threadIdx.x & 63) == 0) { sh_m[threadIdx.x >> 6][g] = mw; sh_f[threadIdx.x >> 6][g] = fw; }
+        }
+        __syncthreads();
+        if (threadIdx.x < PP) {
+            double mm = 0.0;
+            unsigned ff = 0u;
+#pragma unroll
+            for (int w = 0; w < kDotThreads / 64; ++w) { mm += sh_m[w][threadIdx.x]; ff |= sh_f[w][threadIdx.x]; }
+            mt.tot[pz * PP + threadIdx.x] = mm;
+            mt.flag[pz * PP + threadIdx.x] = ff;
+        }
+    }
     const int tl = blockIdx.x;
     const int pass = blockIdx.z;
     const int64_t bin0 = (int64_t)tl * TB;
@@ -215,7 +257,10 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
     for (int u = 0; u < kDepth; ++u) load_entries(RA[u], E[u]);
     __syncthreads();
     if (c0u >= c1) return;
-    double* __restrict__ pout = partial + ((int64_t)pass * n_tl + tl) * n * PP;
+    // partial sums in blocks of kPartBlock datasets, [pass][dataset block][tile][dataset in block][PP]: the finish of a dataset
+    // block reads ONE contiguous range (all tiles of its datasets), the dot kernel writes whole 1 KB pieces of it
+    const int64_t n_pad = (n + kPartBlock - 1) / kPartBlock * kPartBlock;
+    double* __restrict__ pout = partial + (int64_t)pass * n_tl * n_pad * PP + (int64_t)tl * kPartBlock * PP;
     const int n_iter = (c1 - c0 + kStep - 1) / kStep;
     for (int it = 0; it < n_iter; it += kRing) {
 #pragma unroll
@@ -280,7 +325,7 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
                         double2 w;
                         w.x = s[p];
                         w.y = s[p + 1];
-                        *reinterpret_cast<double2*>(pout + (int64_t)q * PP + p) = w;
+                        *reinterpret_cast<double2*>(pout + ((int64_t)(q / kPartBlock) * n_tl * kPartBlock + q % kPartBlock) * PP + p) = w;
                     }
                 }
             }
@@ -289,62 +334,42 @@ __global__ __launch_bounds__(kDotThreads) void k_dataset_dot_multi(const void* _
 }
 
 // ---- (3) finish: out[point][dataset] ------------------------------------------------------------------------------------
-// blockIdx.y = pass, blockIdx.x = 64 datasets; a thread adds the tiles' partial sums of ITS dataset for all PP columns of the
-// pass (the PP values of a (tile, dataset) are adjacent: 16-byte loads, every byte of a line used once), the tiles split over
-// the block's four waves as in k_dataset_finish_tiled -- a fixed order.  colmap [passes][PP][2] = {work item of the log mu
-// kernel, output row} of every column (-1: no point); mu_partial / mu_flags [items][nmu][GC], GC = gridDim.y * PP rows of the group.
+// mu_tot / mu_flag [passes of the group][PP]: sum mu of every column's point and its flag, added up by the dot kernel's first block
+// of the pass (MuTotals); colmap [passes][PP][2] = {work item of the log mu kernel, output row} of every column (-1: no point).
+// k_dataset_finish_multi: blockIdx.y = pass, blockIdx.x = block of kPartBlock = 32 datasets.  A block is 32 datasets x 8 SLICES
+// of the tiles: a thread adds the partial sums of ITS dataset over its slice of the tiles for all PP columns of the pass (the PP
+// values of a (tile, dataset) are adjacent: 16-byte loads; the block's input is ONE contiguous range, [tile][32 datasets][PP]),
+// the slices are added in order by the first 32 threads -- a fixed order.
 // done != NULL: out is pinned host memory; the block that finishes last publishes `seq` there with a system-scope release.
 template <int PP>
 __global__ __launch_bounds__(kThreads) void k_dataset_finish_multi(const double* __restrict__ partial, int n_tl, const int32_t* __restrict__ colmap,
-                                                                   const double* __restrict__ mu_partial, const unsigned* __restrict__ mu_flags,
-                                                                   int nmu, int GC, const double* __restrict__ lgsum, int64_t t0, int64_t n,
+                                                                   const double* __restrict__ mu_tot, const unsigned* __restrict__ mu_flag,
+                                                                   const double* __restrict__ lgsum, int64_t t0, int64_t n,
                                                                    double* __restrict__ out, int64_t out_stride,
                                                                    unsigned* __restrict__ blocks_done, unsigned long long* done,
                                                                    unsigned long long seq) {
-    static_assert(kThreads == 256, "four waves per block");
-    __shared__ double sh[kThreads / 64][PP];
-    __shared__ unsigned shf[kThreads / 64][PP];
-    __shared__ double part[kThreads / 64][PP][64];
+    constexpr int kDs = kPartBlock, kSl = kThreads / kDs;
+    __shared__ double part[kSl][PP][kDs];
     const int pass = blockIdx.y;
     const int32_t* __restrict__ cm = colmap + (int64_t)pass * PP * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double m[PP];
-    unsigned f[PP];
-#pragma unroll
-    for (int g = 0; g < PP; ++g) {
-        // sum mu of column g's point: the block partials of its work item, in k_dataset_finish_tiled's order
-        m[g] = 0.0;
-        f[g] = 0u;
-        const int item = cm[2 * g];
-        if (item < 0) continue;
-        const double* __restrict__ mp = mu_partial + (int64_t)item * nmu * GC + pass * PP + g;
-        const unsigned* __restrict__ mf = mu_flags + (int64_t)item * nmu * GC + pass * PP + g;
-        double m4[4] = {0.0, 0.0, 0.0, 0.0};
-        int b = threadIdx.x;
-        for (; b + 3 * kThreads < nmu; b += 4 * kThreads) {
-            double vv[4];
-            unsigned gg[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { vv[k] = mp[(int64_t)(b + k * kThreads) * GC]; gg[k] = mf[(int64_t)(b + k * kThreads) * GC]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { m4[k] += vv[k]; f[g] |= gg[k]; }
-        }
-        for (; b < nmu; b += kThreads) { m4[0] += mp[(int64_t)b * GC]; f[g] |= mf[(int64_t)b * GC]; }
-        m[g] = (m4[0] + m4[1]) + (m4[2] + m4[3]);
-    }
-    const int64_t t = (int64_t)blockIdx.x * 64 + lane;
-    const int per = (n_tl + 3) / 4;
-    const int b0 = wave * per, b1 = min(n_tl, b0 + per);
+    const int dsl = threadIdx.x % kDs, sl = threadIdx.x / kDs;
+    const int64_t t = (int64_t)blockIdx.x * kDs + dsl;
+    const int per = (n_tl + kSl - 1) / kSl;
+    const int b0 = min(n_tl, sl * per), b1 = min(n_tl, b0 + per);
     double s[PP];
 #pragma unroll
     for (int g = 0; g < PP; ++g) s[g] = 0.0;
     if (t < n) {
-        const double* __restrict__ p = partial + (int64_t)pass * n_tl * n * PP + t * PP;
-        const int64_t stride = n * PP;
-        constexpr int U = 4;                                         // tiles in flight per thread (PP / 2 16-byte loads each)
-        double acc[U][PP];
+        const int64_t n_pad = (n + kPartBlock - 1) / kPartBlock * kPartBlock;
+        const double* __restrict__ p = partial + (int64_t)pass * n_tl * n_pad * PP + ((int64_t)blockIdx.x * n_tl * kDs + dsl) * PP;
+        const int64_t stride = (int64_t)kDs * PP;
+        // four tiles in flight per thread (PP / 2 16-byte loads each), four running sums (measured: 16 datasets x 16 slices with
+        // eight in flight is slower, 40 against 33 us per pass of 10^4 datasets -- with the results going to pinned host memory
+        // the kernel's floor is their ~320 KB over PCIe)
+        constexpr int U = 4;
+        double acc[4][PP];
 #pragma unroll
-        for (int k = 0; k < U; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int g = 0; g < PP; ++g) acc[k][g] = 0.0;
         int b = b0;
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish_multi(const double*
 #pragma unroll
             for (int k = 0; k < U; ++k)
 #pragma unroll
-                for (int g = 0; g < PP; g += 2) { acc[k][g] += vv[k][g / 2].x; acc[k][g + 1] += vv[k][g / 2].y; }
+                for (int g = 0; g < PP; g += 2) { acc[k & 3][g] += vv[k][g / 2].x; acc[k & 3][g + 1] += vv[k][g / 2].y; }
         }
         for (; b < b1; ++b)
 #pragma unroll
@@ -366,33 +391,28 @@ __global__ __launch_bounds__(kThreads) void k_dataset_finish_multi(const double*
         for (int g = 0; g < PP; ++g) s[g] = (acc[0][g] + acc[1][g]) + (acc[2][g] + acc[3][g]);
     }
 #pragma unroll
-    for (int g = 0; g < PP; ++g) {
-        part[wave][g][lane] = s[g];
-        const double mw = wave_sum(m[g]);
-        const unsigned fw = wave_or(f[g]);
-        if (lane == 0) { sh[wave][g] = mw; shf[wave][g] = fw; }
-    }
+    for (int g = 0; g < PP; ++g) part[sl][g][dsl] = s[g];
     __syncthreads();
-    if (wave == 0 && t < n) {
+    if (sl == 0 && t < n) {
         const double lg = lgsum[t0 + t];
 #pragma unroll
         for (int g = 0; g < PP; ++g) {
             const int orow = cm[2 * g + 1];
             if (orow < 0) continue;
-            double mm = sh[0][g];
-            unsigned ff = shf[0][g];
+            double tot = 0.0;
 #pragma unroll
-            for (int w = 1; w < kThreads / 64; ++w) { mm += sh[w][g]; ff |= shf[w][g]; }
-            const double tot = (part[0][g][lane] + part[1][g][lane]) + (part[2][g][lane] + part[3][g][lane]);
-            double r = (tot - mm) - lg;
-            if (ff) r = __builtin_nan("");
+            for (int q = 0; q < kSl; q += 4)
+                tot += (part[q][g][dsl] + part[q + 1][g][dsl]) + (part[q + 2][g][dsl] + part[q + 3][g][dsl]);
+            double r = (tot - mu_tot[pass * PP + g]) - lg;
+            if (mu_flag[pass * PP + g]) r = __builtin_nan("");
             out[(int64_t)orow * out_stride + t] = r;
         }
     }
     if (!done) return;
-    if (wave == 0) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
         __threadfence_system();
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             const unsigned before = __hip_atomic_fetch_add(blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (before == gridDim.x * gridDim.y - 1) {
                 __hip_atomic_store(blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -558,11 +578,11 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
     const bool overlap = c->toy_points_overlap && n_groups > 1 && !c->profiling;
     const int n_buf = overlap ? 2 : 1;
     const size_t lm_group = (size_t)std::min(n_pass, kPassGroup) * c->Bp * PP;                 // doubles per group
-    const size_t part_group = (size_t)std::min(n_pass, kPassGroup) * n_tl * n * PP;
+    const size_t part_group = (size_t)std::min(n_pass, kPassGroup) * n_tl * ((n + kPartBlock - 1) / kPartBlock * kPartBlock) * PP;
     if ((rc = packed_upload(c, parts, host_out ? (size_t)P * n * sizeof(double) : 0, pu)) ||
         (n_pass > 0 && (rc = dev_alloc(c, d_lm, (size_t)n_buf * lm_group * sizeof(double)))) ||
         (n_pass > 0 && (rc = dev_alloc(c, d_part, (size_t)n_buf * part_group * sizeof(double)))) ||
-        (rc = dev_alloc(c, d_mu, 2 * ((mu_bytes + 63) / 64 * 64))) ||
+        (rc = dev_alloc(c, d_mu, 2 * ((mu_bytes + 63) / 64 * 64) + (size_t)std::max(n_groups, 1) * GC * 16)) ||
         (!host_out && !out_dev && (rc = dev_alloc(c, d_out, (size_t)P * n * sizeof(double))))) {
         cleanup();
         return rc;
@@ -578,6 +598,9 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         a.coef = pu.dev<double>(1);
         a.partial = (double*)d_mu.p;
         a.pflags = (unsigned*)((char*)d_mu.p + (mu_bytes + 63) / 64 * 64);
+        // per group: sum mu and the flag of every column of its table (MuTotals: the dot kernel's first block of a pass)
+        double* mu_tot = (double*)((char*)d_mu.p + 2 * ((mu_bytes + 63) / 64 * 64));
+        unsigned* mu_flag = (unsigned*)(mu_tot + (size_t)std::max(n_groups, 1) * GC);
         a.B = c->B; a.Bp = c->Bp; a.n0 = NS; a.n_tiles = n_tiles; a.chunks = (int)c->tile_chunks;
         const bool nt = c->nt_loads == 1 || (c->nt_loads == 2 && !shared_anchor);
         // the dot kernel: the datasets split over blockIdx.y so that a pass fills the chip once where it can (one resident block per
@@ -586,13 +609,15 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
         const int variant = (c->tmm_width == 2 ? 0 : 2) + (PP == 4 ? 0 : 1);     // {W2 PP4, W2 PP2, W4 PP4, W4 PP2}
         const int lanes = (int)c->toy_points_lanes;
         const unsigned by = (unsigned)std::max<int64_t>({1, std::min<int64_t>((n + 255) / 256, (int64_t)c->prop.multiProcessorCount / n_tl), (n + 262143) / 262144});
-        if (host_out && c->poll_result && !c->profiling && (c->toy_fast_call & 4)) {
+        // the completion word in the pinned block (behind the results, if they go there): polled instead of a stream synchronisation,
+        // whether the results land in pinned host memory or stay in HBM (out_dev)
+        if ((host_out || out_dev) && c->poll_result && !c->profiling && (c->toy_fast_call & 4)) {
             if ((rc = dev_alloc(c, c->toy_blocks_done, 64))) { cleanup(); return rc; }
             if (!c->toy_blocks_done_zeroed) {
                 e = hipMemsetAsync(c->toy_blocks_done.p, 0, 64, c->stream);
                 c->toy_blocks_done_zeroed = true;
             }
-            done_word = (unsigned long long*)((char*)pu.host_out() + ((size_t)P * n * sizeof(double) + 63) / 64 * 64);
+            done_word = (unsigned long long*)((char*)pu.host_out() + (host_out ? ((size_t)P * n * sizeof(double) + 63) / 64 * 64 : 0));
             seq = ++c->toy_seq;
             *(volatile unsigned long long*)done_word = 0ull;
         }
@@ -661,10 +686,12 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             EventScope ev(c);                                                                                              \
             hipLaunchKernelGGL((k_dataset_dot_multi<Lv, Av, Wv, PPv, kDotTileMulti>), dgrid, dim3(kDotThreads), lds, sA,     \
                                (const void*)c->tmm_entries.p, (const int64_t*)c->tmm_off.p, c->T, n_tl, lm,                \
-                               c->B, c->Bp, t0, n, part);                                                                  \
+                               c->B, c->Bp, t0, n, part, mt);                                                              \
         }                                                                                                                  \
     } while (0)
             const dim3 dgrid((unsigned)n_tl, by, (unsigned)np);
+            const MuTotals mt{pu.dev<int32_t>(3) + (int64_t)g0 * PP * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, GC,
+                              mu_tot + (size_t)gr * GC, mu_flag + (size_t)gr * GC};
             if (variant == 0) { if (lanes == 2) BI_DM(2, 3, 2, 4); else if (lanes == 8) BI_DM(8, 1, 2, 4); else BI_DM(4, 2, 2, 4); }
             else if (variant == 1) { if (lanes == 2) BI_DM(2, 3, 2, 2); else if (lanes == 8) BI_DM(8, 1, 2, 2); else BI_DM(4, 2, 2, 2); }
             else if (variant == 2) { if (lanes == 4) BI_DM(4, 3, 4, 4); else BI_DM(8, 2, 4, 4); }
@@ -676,13 +703,13 @@ int eval_datasets_points_impl(bi_ctx* c, int64_t P, const double* z, const doubl
             }
             if (e == hipSuccess) {
                 EventScope ev(c);
-                const dim3 fgrid((unsigned)((n + 63) / 64), (unsigned)np);
+                const dim3 fgrid((unsigned)((n + kPartBlock - 1) / kPartBlock), (unsigned)np);
                 // (the completion word is published by the LAST group's finish: the second stream runs the finishes in order, and a
                 //  group's finish follows its dot kernel)
 #define BI_FM(PPv)                                                                                                          \
     hipLaunchKernelGGL((k_dataset_finish_multi<PPv>), fgrid, dim3(kThreads), 0, sB, (const double*)part, n_tl,              \
-                       pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)a.partial, (const unsigned*)a.pflags, nmu, GC, \
-                       (const double*)c->lgsum.p, t0, n, res, n, (unsigned*)c->toy_blocks_done.p, last ? done_word : (unsigned long long*)nullptr, seq)
+                       pu.dev<int32_t>(3) + (int64_t)g0 * PPv * 2, (const double*)(mu_tot + (size_t)gr * GC),                     \
+                       (const unsigned*)(mu_flag + (size_t)gr * GC), (const double*)c->lgsum.p, t0, n, res, n, (unsigned*)c->toy_blocks_done.p, last ? done_word : (unsigned long long*)nullptr, seq)
                 if (PP == 2) BI_FM(2); else BI_FM(4);
 #undef BI_FM
                 if (overlap) e = hipEventRecord(ev_fin[gr % 2], sB);
