@@ -19,7 +19,10 @@ namespace {
 //   or fail the window test) instead of two compares per element.
 // Measured alternatives (tools/probe/grad_variants.sh, 131 072 points of C2, kernel time): as built 3.59 ms; rows and counts
 // fetched one block ahead 4.34 ms (KG = 8 then spills 30 registers); one wave per SIMD (512 registers, no spills) 4.29 ms, with
-// the fetch ahead 4.18 ms -- two waves hide a block's load latency better than either.
+// the fetch ahead 4.18 ms -- two waves hide a block's load latency better than either.  Nor is it its vector instructions: with
+// the counts' "one value in all 16 bins" test replaced by a table looked up with a scalar load (four loads, eight compares and
+// two ballots per block less: 3.5 -> ~3.0 vector instructions per MFMA) the kernel takes the same 3.57-3.59 ms -- what is left
+// beside the matrix pipe's 66 % is the latency of a block's loads and its trip through LDS under two waves per SIMD.
 #ifndef BI_GRAD_PREFETCH
 #define BI_GRAD_PREFETCH 0
 #endif
