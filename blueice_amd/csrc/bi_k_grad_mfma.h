@@ -17,14 +17,16 @@ namespace {
 //     k_scan_sorted (row j keeps item j) and every row takes the logarithm of another item;
 //   and the range tests are one integer minimum over the high words (negative numbers, zeros, subnormals and nans compare low
 //   or fail the window test) instead of two compares per element.
-// Measured alternatives (tools/probe/grad_variants.sh, 131 072 points of C2, kernel time): as built 3.59 ms; rows and counts
-// fetched one block ahead 4.34 ms (KG = 8 then spills 30 registers); one wave per SIMD (512 registers, no spills) 4.29 ms, with
-// the fetch ahead 4.18 ms -- two waves hide a block's load latency better than either.  Nor is it its vector instructions: with
-// the counts' "one value in all 16 bins" test replaced by a table looked up with a scalar load (four loads, eight compares and
-// two ballots per block less: 3.5 -> ~3.0 vector instructions per MFMA) the kernel takes the same 3.57-3.59 ms -- what is left
-// beside the matrix pipe's 66 % is the latency of a block's loads and its trip through LDS under two waves per SIMD.
+// Where the next block's rows are fetched (BI_GRAD_PREFETCH; tools/probe/grad_variants.sh, 131 072 points of C2, kernel time on one
+// box): at the block's top (0) 3.55-3.61 ms; BEHIND THE BLOCK'S LAST PRODUCT-1 MFMA (2, the default) 3.47-3.55 ms -- the rows'
+// registers are dead from there on, so the loads cost no register and run under the last epilogue and product 2; a whole block
+// ahead (1) 4.31 ms (KG = 8 then spills 30 registers); product 1 of all four items first, then the fetch (3) 3.64-3.67 ms (20
+// spills).  One wave per SIMD (BI_GRAD_WAVES = 1: 512 registers, no spills) 4.28 ms, with the fetch ahead 4.16 ms.  Nor is it its
+// vector instructions: with the counts' "one value in all 16 bins" test replaced by a table looked up with a scalar load (four
+// loads, eight compares and two ballots per block less: 3.5 -> ~3.0 vector instructions per MFMA) the kernel took the same time --
+// what is left beside the matrix pipe's ~67 % is the latency of a block's loads and its trip through LDS under two waves per SIMD.
 #ifndef BI_GRAD_PREFETCH
-#define BI_GRAD_PREFETCH 0
+#define BI_GRAD_PREFETCH 2
 #endif
 #ifndef BI_GRAD_WAVES
 #define BI_GRAD_WAVES 2
@@ -32,7 +34,7 @@ namespace {
 template <int KG, bool MASK>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BI_GRAD_WAVES))) void k_grad_mfma(GradMfmaArgs a) {
     constexpr int NB = KG >= 4 ? KG / 4 : 1;       // blocks of 16 streams (product 2's N dimension)
-    constexpr bool kPrefetch = BI_GRAD_PREFETCH;
+    constexpr int kPrefetch = BI_GRAD_PREFETCH;    // 0: a block's rows at its top; 1: one block ahead; 2: behind the block's last product-1 MFMA; 3: product 1 of all four items first, then the fetch
     constexpr int NSP = 16 * NB;
     const int grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -78,24 +80,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BI_GRA
 
     // (kPrefetch: the rows and counts of a block fetched one block ahead, every load unconditional -- the last block twice)
     double b1n[KG], n4n[4];
-    auto fetch = [&](int blk) {
+    auto fetch_rows = [&](int blk) {
         const int64_t bin0 = (int64_t)min(blk, n_blocks - 1) * 16;
         int kqo = kq;
         asm volatile("" : "+v"(kqo));                      // (opaque: keeps the LDS reads inside the loop)
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) b1n[kg] = a.ps[s_rowoff[kg * 4 + kqo] + bin0 + col];
+    };
+    auto fetch_counts = [&](int blk) {
+        const int64_t bin0 = (int64_t)min(blk, n_blocks - 1) * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) n4n[r] = cnt[bin0 + 4 * r + kq];
     };
-    if (kPrefetch && slice < n_blocks) fetch(slice);
+    if (kPrefetch && slice < n_blocks) fetch_rows(slice);
+    if (kPrefetch == 1 && slice < n_blocks) fetch_counts(slice);
     for (int blk = slice; blk < n_blocks; blk += a.n_slices) {
         double b1[KG], b2[4][NB], n4[4];
-        if (!kPrefetch) fetch(blk);
+        if (!kPrefetch) fetch_rows(blk);
+        if (kPrefetch != 1) fetch_counts(blk);
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) b1[kg] = (MASK && kg * 4 + kq >= NS) ? 0.0 : b1n[kg];
 #pragma unroll
         for (int r = 0; r < 4; ++r) n4[r] = n4n[r];
-        if (kPrefetch) fetch(blk + a.n_slices);
+        if (kPrefetch == 1) { fetch_rows(blk + a.n_slices); fetch_counts(blk + a.n_slices); }
         // the second layout: element (stream s, bin b) sits in lane (s & 3, b), register s >> 2; product 2 wants it in lane
         // (b & 3, s & 15), register (b >> 2, s >> 4).  Through this wave's own LDS rows (the wave's LDS operations complete in order)
 #pragma unroll
@@ -161,14 +168,32 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BI_GRA
         // takes the product form, the rule, the pair's lane products wait in qs for the one logarithm of the four items.
         double qs[4] = {1.0, 1.0, 1.0, 1.0};
         bool any_product = false;
+        bi_double4 mu_all[4];
+        if (kPrefetch == 3) {                              // product 1 of all four items first: the rows are dead before any epilogue
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mu_all[j] = bi_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mu_all[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[j][kg], mu_all[j], 0, 0, 0);
+            fetch_rows(blk + a.n_slices);
+        }
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
             bi_double4 mu0 = bi_double4{0.0, 0.0, 0.0, 0.0}, mu1 = bi_double4{0.0, 0.0, 0.0, 0.0};
+            if (kPrefetch == 3) {
+                mu0 = mu_all[jp];
+                mu1 = mu_all[jp + 1];
+            } else {
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                mu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp][kg], mu0, 0, 0, 0);
-                mu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp + 1][kg], mu1, 0, 0, 0);
+                for (int kg = 0; kg < KG; ++kg) {
+                    mu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp][kg], mu0, 0, 0, 0);
+                    mu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kg], cf[jp + 1][kg], mu1, 0, 0, 0);
+                }
             }
+            // (kPrefetch == 2: the rows are dead from here on -- the next block's go into their registers while this block's
+            //  last epilogue and product 2 run)
+            if (kPrefetch == 2 && jp == 2) fetch_rows(blk + a.n_slices);
             // every factor above 2^-127 (one integer minimum over the eight high words: negative numbers, zeros and subnormals
             // compare low), each lane product inside (2^-255, 2^255) (nan and inf fail): the four-row products are then normal
             // numbers, and so are the reciprocals
