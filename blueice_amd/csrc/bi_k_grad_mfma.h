@@ -24,7 +24,10 @@ namespace {
 // spills).  One wave per SIMD (BI_GRAD_WAVES = 1: 512 registers, no spills) 4.28 ms, with the fetch ahead 4.16 ms.  Nor is it its
 // vector instructions: with the counts' "one value in all 16 bins" test replaced by a table looked up with a scalar load (four
 // loads, eight compares and two ballots per block less: 3.5 -> ~3.0 vector instructions per MFMA) the kernel took the same time --
-// what is left beside the matrix pipe's ~67 % is the latency of a block's loads and its trip through LDS under two waves per SIMD.
+// and with a block's rows going from global memory straight into a double-buffered LDS tile a whole block ahead (global_load_lds_dwordx4,
+// XOR-swizzled columns so that both operand layouts read it without conflicts; correct, tools/micro/global_load_lds.hip checks the
+// instruction's layout) it took 3.83-3.86 ms (17-21 spilled registers).  What is left beside the matrix pipe's ~67 % is not one
+// exposed latency: the vector instructions of the epilogues issue in the matrix pipe's place, and the rest is spread thin.
 #ifndef BI_GRAD_PREFETCH
 #define BI_GRAD_PREFETCH 2
 #endif
