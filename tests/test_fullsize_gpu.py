@@ -217,6 +217,33 @@ def test_counting_sort_plans_what_the_radix_sort_plans(c2):
     ctx.set_param('device_plan_min', 1000)
 
 
+def test_polled_reports_and_stream_synchronisation_agree(c2):
+    """The device planner's counters, a plan's status word and the multi-hypothesis toy call's completion come back through pinned
+    memory the host polls (poll_result = 1, default); with poll_result = 0 every one of them waits on the stream instead: the same
+    plans, the same results."""
+    m, ctx = c2
+    ctx.set_param('sparse', 1)
+    ctx.upload_counts(m.counts())
+    z, r = m.random_points(30000, seed=5)
+    z[::211, 1] = 9.0
+    ctx.set_param('device_plan_min', 1)
+    out = {}
+    for poll in (1, 0, 1):
+        ctx.set_param('poll_result', poll)
+        ll, st = ctx.eval(z, r)
+        plan = ctx.plan(z[:5000], r[:5000])
+        plan.run()
+        word = plan.status()
+        again, _ = plan.read()
+        plan.close()
+        out[poll] = (ll, st, word, again)
+    ctx.set_param('poll_result', 1)
+    ctx.set_param('device_plan_min', 1000)
+    for a, b in zip(out[1], out[0]):
+        np.testing.assert_array_equal(a, b)
+    assert out[1][2] == 1 and np.isneginf(out[1][0]).sum() >= 30000 // 211
+
+
 def test_matrix_core_scan_kernel_matches_vector_kernel(c2):
     """Scans with many points per grid cell run on the fp64 matrix cores (k_scan_mfma): same numbers as the
     vector kernel (k_morph_reduce) and as the oracle, including -inf / nan bins."""
