@@ -287,6 +287,7 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
     send.from_host(np.zeros(stride))
     full = ranks.full_buffer(P) if device_deal else None
     seen = dict(bytes=0, share=[P, P])
+    host_results = np.empty(P)                        # (reused: a fresh 8 MB array per step costs page faults and the copy's slow path)
 
     def step(w, resident=None, fetch=True):
         """fetch = False: the full result vector stays in HBM (where a device-side consumer -- the batched fit engine, a reduction
@@ -299,13 +300,13 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
             word = plan.status()
             recv = ranks.gather_on_device(stride)
             plan.unsort(recv.ptr, stride, full.ptr)
-            out = full.to_host(np.float64, P) if fetch else None
+            out = full.to_host(np.float64, P, out=host_results) if fetch else None
             seen['share'] = [plan.n_valid // world, -(-plan.n_valid // world)]
         elif world == 1:
             plan = ctx.plan_resident(P, resident[0], resident[1]) if resident else ctx.plan(z, r)
             plan.run(send.ptr)
             word = plan.status()
-            out = send.to_host(np.float64, P) if fetch else None
+            out = send.to_host(np.float64, P, out=host_results) if fetch else None
         else:
             deal = deal_points_by_cell(model.anchor_z, z, world)
             mine = deal[rank]
@@ -332,6 +333,7 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
         out = step(w)
     ranks.barrier()
     elapsed_host = ranks.max_over_ranks(time.perf_counter() - t0)
+    out = out.copy()                                      # (the steps reuse one host array)
     # the same steps with the points already in HBM when the clock starts (bi_plan_points_resident): the leg's `value`;
     # the rate with the points handed over as host arrays -- the reference's calling convention, H2D inside -- beside it
     elapsed = elapsed_host
@@ -341,13 +343,15 @@ def scan_leg(ctx, ranks, model, P, steps, label, sample=4):
             bz, br = ctx.device_alloc(z.nbytes), ctx.device_alloc(r.nbytes)
             bz.from_host(z); br.from_host(r)
             held.append((bz, br))
-        step(work[0], held[0])
+        for _ in range(3):                                # (the chip needs a few steps after the uploads above: 11.0, 10.6, 10.1, 9.9 ms)
+            step(work[0], held[0])
         ranks.barrier()
         t0 = time.perf_counter()
         for w, h in zip(work[1:], held[1:]):
             out_res = step(w, h)
         ranks.barrier()
         elapsed_fetch = ranks.max_over_ranks(time.perf_counter() - t0)
+        out_res = out_res.copy()
         # ... and with the full vector LEFT in HBM on every rank (status word checked): inputs and outputs on the device, the
         # form a device-side consumer of a scan sees -- the leg's `value`; the rate with the caller's own host copy beside it
         step(work[0], held[0], fetch=False)

@@ -495,9 +495,14 @@ class DeviceBuffer:
     def __init__(self, ctx, ptr_value, nbytes):
         self.ctx, self.ptr, self.nbytes = ctx, ptr_value, nbytes
 
-    def to_host(self, dtype=np.float64, count=None, offset_bytes=0):
+    def to_host(self, dtype=np.float64, count=None, offset_bytes=0, out=None):
+        """`out`: a C-contiguous array of `count` elements of `dtype` to copy into (a loop that reuses it saves the page faults of a
+        fresh array per call: ~0.5 ms per 8 MB, and the runtime's slow path into memory it has not seen)."""
         n = (self.nbytes - offset_bytes) // np.dtype(dtype).itemsize if count is None else int(count)
-        out = np.empty(n, dtype=dtype)
+        if out is None:
+            out = np.empty(n, dtype=dtype)
+        elif out.size != n or out.dtype != np.dtype(dtype) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous %s array of %d elements" % (np.dtype(dtype), n))
         self.ctx._check(self.ctx._lib.bi_memcpy_to_host(self.ctx._h, ptr(out), C.c_void_p(self.ptr + offset_bytes), out.nbytes))
         return out
 
